@@ -1,0 +1,382 @@
+// block_aligner_amd — per-pair driver (shift right/down, grow, shrink, X-drop), traceback, and kernels.
+// Follows /root/reference/src/scan_block.rs:94-595 (align_core), 1003-1061 (border moves),
+// 1428-1462 (trace stack), 1482-1672 (cigar_core). One wavefront per pair; all driver state is wave-uniform.
+#pragma once
+#include "ba_device.hpp"
+
+namespace ba {
+
+// ------------------------------------------------------------------ LDS border helpers (whole wave cooperates)
+// Lanes exchange border data through LDS. The hardware executes one wave's LDS operations in program order; this
+// keeps the compiler from reordering them across a hand-off point (no instruction is emitted beyond waits).
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_fill0(short* a, uint32_t n) {
+    for (uint32_t k = 2 * lane_id(); k < n; k += 128) *(int*)(a + k) = 0;
+    lds_sync();
+}
+// dst and src may be the two halves of one array (shrink); each 128-entry chunk is read before any of it is written
+__device__ __forceinline__ void lds_copy(short* dst, const short* src, uint32_t n) {
+    lds_sync();
+    for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
+        const int v = *(const int*)(src + k);
+        lds_sync();
+        *(int*)(dst + k) = v;
+    }
+    lds_sync();
+}
+// max of the first 8 entries (scan_block.rs:1020-1022)
+__device__ __forceinline__ int lds_prefix_max8(const short* a) {
+    lds_sync();
+    const int* p = (const int*)a;
+    s16x2 m = vmax(vmax(as_s(p[0]), as_s(p[1])), vmax(as_s(p[2]), as_s(p[3])));
+    return uni(max((int)m.x, (int)m.y));
+}
+// max of the last 2 entries (scan_block.rs:1030-1032, SHRINK_SUFFIX_LEN = 2)
+__device__ __forceinline__ int lds_suffix_max2(const short* a, uint32_t n) {
+    lds_sync();
+    s16x2 m = as_s(*(const int*)(a + n - 2));
+    return uni(max((int)m.x, (int)m.y));
+}
+// buf[k] = buf[k+8] (+) off_add for k < n-8, buf[n-8..n) = temp[0..8); returns buf_old[7] (+) off_add
+// (scan_block.rs:1040-1061)
+__device__ __forceinline__ int lds_shift_and_offset(uint32_t n, short* b1, short* b2, const short* t1, const short* t2, int off_add) {
+    const s16x2 oa = splat(off_add);
+    lds_sync();
+    const int corner = uni((int)adds(splat((int)b1[STEP - 1]), oa).x);
+    for (uint32_t base = 0; base < n; base += 128) {
+        const uint32_t k = base + 2 * lane_id();
+        int v1 = 0, v2 = 0;
+        const bool in = k < n;
+        if (in) {
+            if (k + STEP < n) {
+                v1 = as_i(adds(as_s(*(const int*)(b1 + k + STEP)), oa));
+                v2 = as_i(adds(as_s(*(const int*)(b2 + k + STEP)), oa));
+            } else {
+                v1 = *(const int*)(t1 + (k + STEP - n));
+                v2 = *(const int*)(t2 + (k + STEP - n));
+            }
+        }
+        lds_sync();
+        if (in) { *(int*)(b1 + k) = v1; *(int*)(b2 + k) = v2; }
+        lds_sync();
+    }
+    return corner;
+}
+
+// ------------------------------------------------------------------ traceback (one lane walks the path)
+struct Move { uint32_t op, di, dj, next; };
+// OP_LUT of scan_block.rs:1532-1558 as branches; table: 0 = D, 1 = C, 2 = R; t/t2 as the reference defines them
+__device__ __forceinline__ Move tb_lut(bool right_blk, uint32_t t, uint32_t t2, uint32_t table) {
+    constexpr uint32_t OP_M = 1, OP_I = 4, OP_D = 5;
+    const uint32_t gapA_op = right_blk ? OP_D : OP_I, gapB_op = right_blk ? OP_I : OP_D;
+    const uint32_t A_di = right_blk ? 0 : 1, A_dj = right_blk ? 1 : 0;
+    const uint32_t A_tab = right_blk ? 1 : 2, B_tab = right_blk ? 2 : 1;
+    // "A" = the gap kind tracked by trace bit 0 / trace2 bit 0 (C for right blocks, R for down blocks)
+    if (table == A_tab) return (t2 & 1) ? Move{gapA_op, A_di, A_dj, 0} : Move{gapA_op, A_di, A_dj, A_tab};
+    if (table == B_tab) return (t2 & 2) ? Move{gapB_op, 1 - A_di, 1 - A_dj, 0} : Move{gapB_op, 1 - A_di, 1 - A_dj, B_tab};
+    if (t == 0) return Move{OP_M, 1, 1, 0};
+    if (t & 1) return (t2 & 1) ? Move{gapA_op, A_di, A_dj, 0} : Move{gapA_op, A_di, A_dj, A_tab};
+    return (t2 & 2) ? Move{gapB_op, 1 - A_di, 1 - A_dj, 0} : Move{gapB_op, 1 - A_di, 1 - A_dj, B_tab};
+}
+
+// Walk back from (i, j); emit run-length ops right-aligned into [out_lo, out_hi). Returns run count, or
+// sets *status on failure. Executed by lane 0 only. (scan_block.rs:1482-1672)
+__device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32_t nblocks, const uint32_t* __restrict__ trace,
+                                     uint32_t i, uint32_t j, const uint8_t* __restrict__ q, const uint8_t* __restrict__ r, bool eq,
+                                     uint32_t* __restrict__ out, uint64_t out_lo, uint64_t out_hi, uint32_t* status) {
+    uint64_t wp = out_hi;          // next free slot is wp - 1
+    uint32_t run_op = 0, run_len = 0;
+    uint32_t table = 0;
+    uint32_t bidx = nblocks;
+    while (i > 0 || j > 0) {
+        BlockRec br;
+        for (;;) {
+            if (bidx == 0) { *status |= ST_TRACEBACK_LOST; return 0; }
+            bidx--;
+            br = blocks[bidx];
+            if (i >= br.i && j >= br.j) break;
+        }
+        const bool right_blk = br.trace_base >> 31;
+        const uint32_t tbase = br.trace_base & 0x7fffffffu;
+        const uint32_t Hv = right_blk ? br.h : br.w;          // cells along the vector axis
+        const uint32_t K = Hv >= 128 ? Hv / 64 : 2, P = K / 2, nl = Hv / K;
+        while (i >= br.i && j >= br.j && (i > 0 || j > 0)) {
+            const uint32_t ci = i - br.i, cj = j - br.j;
+            const uint32_t v = right_blk ? ci : cj, w = right_blk ? cj : ci;
+            const uint32_t lane = v / K, tt = v % K;
+            const uint32_t word = trace[tbase + ((w >> 2) * P + (tt >> 1)) * nl + lane];
+            const uint32_t nib = ~(word >> ((tt & 1) * 16 + (w & 3) * 4)) & 15u;   // stored as "differs" bits
+            const Move m = tb_lut(right_blk, nib & 3, nib >> 2, table);
+            uint32_t op = m.op;
+            if (eq && op == 1) op = q[i] == r[j] ? 2 : 3;
+            i -= m.di; j -= m.dj; table = m.next;
+            if (op == run_op) run_len++;
+            else {
+                if (run_len) {
+                    if (wp == out_lo) { *status |= ST_CIGAR_OVERFLOW; return 0; }
+                    out[--wp] = (run_len << 4) | run_op;
+                }
+                run_op = op; run_len = 1;
+            }
+        }
+    }
+    if (run_len) {
+        if (wp == out_lo) { *status |= ST_CIGAR_OVERFLOW; return 0; }
+        out[--wp] = (run_len << 4) | run_op;
+    }
+    return (uint32_t)(out_hi - wp);
+}
+
+// ------------------------------------------------------------------ driver
+template <int PMAX, int KIND, bool TRACE, bool XDROP>
+struct Aligner {
+    const BatchParams& bp;
+    const WaveLds& L;
+    const uint8_t* q; const uint8_t* r;
+    uint32_t qlen, rlen;
+    uint32_t* trace; BlockRec* blocks;
+    uint32_t trace_top = 0, nblocks = 0, ck_trace_top = 0, ck_nblocks = 0;
+    uint32_t status = 0;
+    unsigned long long cells = 0;
+
+    __device__ Aligner(const BatchParams& bp_, const WaveLds& L_) : bp(bp_), L(L_) {}
+
+    __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
+        if (nblocks >= bp.blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
+        if ((uint64_t)trace_top + (uint64_t)w * h / 8 > bp.trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
+        if (lane_id() == 0) {
+            BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
+            br.trace_base = trace_top | (right ? 0x80000000u : 0u);
+            blocks[nblocks] = br;
+        }
+        nblocks++;
+        trace_top += w * h / 8;
+    }
+
+    // vectors along seqV; trace words for this rect start at trace_top_before
+    __device__ __forceinline__ Best place(const uint8_t* seqV, const uint8_t* seqC, uint32_t lenV, uint32_t lenC,
+                                          uint32_t si, uint32_t sj, uint32_t w, uint32_t h, short* Dc, short* Cc, short* Dr, short* Rr,
+                                          int corner, int rel_zero, int off_add, uint32_t tbase) {
+        uint32_t* tout = TRACE ? trace + tbase : nullptr;
+        const int go = bp.gap_open, ge = bp.gap_extend;
+#define BA_PLACE(PP) return place_block<PP, KIND, TRACE, XDROP>(L, seqV, seqC, lenV, lenC, si, sj, w, h, Dc, Cc, Dr, Rr, corner, rel_zero, off_add, go, ge, tout, cells)
+        if (h <= 128) BA_PLACE(1);
+        if constexpr (PMAX >= 2) { if (h == 256) BA_PLACE(2); }
+        if constexpr (PMAX >= 4) { if (h == 512) BA_PLACE(4); }
+        if constexpr (PMAX >= 8) { if (h == 1024) BA_PLACE(8); }
+        if constexpr (PMAX >= 16) { if (h == 2048) BA_PLACE(16); }
+#undef BA_PLACE
+        return Best{0, 0, 0};
+    }
+
+    __device__ void save_ckpt_borders(uint32_t n) {
+        lds_copy(L.D_col_ck, L.D_col, n); lds_copy(L.C_col_ck, L.C_col, n);
+        lds_copy(L.D_row_ck, L.D_row, n); lds_copy(L.R_row_ck, L.R_row, n);
+    }
+
+    __device__ void run(uint32_t pair) {
+        q = bp.pool + bp.q_off[pair]; r = bp.pool + bp.r_off[pair];
+        qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
+        const uint32_t min_size = bp.min_size, max_size = bp.max_size;
+        // scratch reset (scan_block.rs:1322-1339): all eight borders to MIN = 0
+        lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size);
+        lds_fill0(L.D_col_ck, max_size); lds_fill0(L.C_col_ck, max_size); lds_fill0(L.D_row_ck, max_size); lds_fill0(L.R_row_ck, max_size);
+        short* temp1 = L.vtab + 16; short* temp2 = L.vtab + 32;
+        lds_fill0(temp1, 32);
+
+        uint32_t si = 0, sj = 0;
+        int best_max = 0; uint32_t best_i = 0, best_j = 0;
+        int prev_dir = DIR_GROW, dir = DIR_GROW;
+        uint32_t prev_size = 0, block_size = min_size;
+        int off = 0, prev_off, off_max = 0;
+        uint32_t y_drop_iter = 0; int x_drop_iter = 0;
+        uint32_t i_ckpt = 0, j_ckpt = 0; int off_ckpt = 0;
+        int D_corner = 0;
+
+        for (;;) {
+            prev_off = off;
+            Best grow{0, 0, 0}, cur;
+            int right_max, down_max;
+            if (dir == DIR_RIGHT) {
+                off = off_max;
+                const int off_add = clamp16(prev_off - off);
+                const uint32_t tb = trace_top;
+                if (TRACE) add_block(si, sj + block_size - STEP, STEP, block_size, true);
+                if (status) break;
+                cur = place(q, r, qlen, rlen, si, sj + block_size - STEP, STEP, block_size, L.D_col, L.C_col, temp1, temp2,
+                            prev_dir == DIR_DOWN ? (int)adds(splat(D_corner), splat(off_add)).x : 0, clamp16(-off + ZERO), off_add, tb);
+                right_max = lds_prefix_max8(L.D_col);
+                D_corner = lds_shift_and_offset(block_size, L.D_row, L.R_row, temp1, temp2, off_add);
+                down_max = lds_prefix_max8(L.D_row);
+            } else if (dir == DIR_DOWN) {
+                off = off_max;
+                const int off_add = clamp16(prev_off - off);
+                const uint32_t tb = trace_top;
+                if (TRACE) add_block(si + block_size - STEP, sj, block_size, STEP, false);
+                if (status) break;
+                cur = place(r, q, rlen, qlen, sj, si + block_size - STEP, STEP, block_size, L.D_row, L.R_row, temp1, temp2,
+                            prev_dir == DIR_RIGHT ? (int)adds(splat(D_corner), splat(off_add)).x : 0, clamp16(-off + ZERO), off_add, tb);
+                down_max = lds_prefix_max8(L.D_row);
+                D_corner = lds_shift_and_offset(block_size, L.D_col, L.C_col, temp1, temp2, off_add);
+                right_max = lds_prefix_max8(L.D_col);
+            } else {
+                D_corner = 0;
+                const uint32_t grow_step = block_size - prev_size;
+                const int rz = clamp16(-off + ZERO);
+                uint32_t tb = trace_top;
+                if (TRACE) add_block(si + prev_size, sj, prev_size, grow_step, false);
+                if (status) break;
+                grow = place(r, q, rlen, qlen, sj, si + prev_size, grow_step, prev_size, L.D_row, L.R_row,
+                             L.D_col + prev_size, L.C_col + prev_size, 0, rz, 0, tb);
+                tb = trace_top;
+                if (TRACE) add_block(si, sj + prev_size, grow_step, block_size, true);
+                if (status) break;
+                cur = place(q, r, qlen, rlen, si, sj + prev_size, grow_step, block_size, L.D_col, L.C_col,
+                            L.D_row + prev_size, L.R_row + prev_size, 0, rz, 0, tb);
+                right_max = lds_prefix_max8(L.D_col);
+                down_max = lds_prefix_max8(L.D_row);
+                save_ckpt_borders(block_size);
+                if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
+            }
+
+            const int this_dir = dir;
+            prev_dir = dir;
+            const int D_max_max = cur.mx, grow_max = grow.mx;
+            const int mx = max(D_max_max, grow_max);
+            off_max = off + mx - ZERO;
+            y_drop_iter++;
+            bool grow_no_max = this_dir == DIR_GROW;
+
+            if (off_max > best_max) {
+                if (XDROP) {   // scan_block.rs:370-404
+                    if (this_dir == DIR_RIGHT) { best_i = si + cur.row; best_j = sj + (block_size - STEP) + cur.col; }
+                    else if (this_dir == DIR_DOWN) { best_i = si + (block_size - STEP) + cur.col; best_j = sj + cur.row; }
+                    else if (D_max_max >= grow_max) { best_i = si + cur.row; best_j = sj + prev_size + cur.col; }
+                    else { best_i = si + prev_size + grow.col; best_j = sj + grow.row; }
+                }
+                if (block_size < max_size) {
+                    i_ckpt = si; j_ckpt = sj; off_ckpt = off;
+                    save_ckpt_borders(block_size);
+                    if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
+                    grow_no_max = false;
+                }
+                best_max = off_max;
+                y_drop_iter = 0;
+            }
+            if (XDROP) {
+                if (off_max < best_max - bp.x_drop) {
+                    if (x_drop_iter < 1) x_drop_iter++;   // X_DROP_ITER = 2
+                    else break;
+                } else x_drop_iter = 0;
+            }
+            if (si + block_size > qlen && sj + block_size > rlen) break;
+            if (sj + block_size > rlen) { si += STEP; dir = DIR_DOWN; continue; }
+            if (si + block_size > qlen) { sj += STEP; dir = DIR_RIGHT; continue; }
+
+            const uint32_t next_size = block_size * 2;
+            if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
+                prev_size = block_size; block_size = next_size; dir = DIR_GROW;
+                si = i_ckpt; sj = j_ckpt; off = off_ckpt;
+                lds_copy(L.D_col, L.D_col_ck, prev_size); lds_copy(L.C_col, L.C_col_ck, prev_size);
+                lds_copy(L.D_row, L.D_row_ck, prev_size); lds_copy(L.R_row, L.R_row_ck, prev_size);
+                if (TRACE) { trace_top = ck_trace_top; nblocks = ck_nblocks; }
+                y_drop_iter = 0;
+                continue;
+            }
+            if (block_size > min_size && y_drop_iter == 0) {   // SHRINK
+                const int shrink_max = max(lds_suffix_max2(L.D_row, block_size), lds_suffix_max2(L.D_col, block_size));
+                if (shrink_max >= mx) {
+                    prev_dir = DIR_GROW;
+                    block_size /= 2;
+                    lds_copy(L.D_col, L.D_col + block_size, block_size); lds_copy(L.C_col, L.C_col + block_size, block_size);
+                    lds_copy(L.D_row, L.D_row + block_size, block_size); lds_copy(L.R_row, L.R_row + block_size, block_size);
+                    si += block_size; sj += block_size;
+                    i_ckpt = si; j_ckpt = sj; off_ckpt = off;
+                    save_ckpt_borders(block_size);
+                    right_max = lds_prefix_max8(L.D_col);
+                    down_max = lds_prefix_max8(L.D_row);
+                    if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
+                    y_drop_iter = 0;
+                }
+            }
+            if (down_max > right_max) { si += STEP; dir = DIR_DOWN; }
+            else { sj += STEP; dir = DIR_RIGHT; }
+        }
+
+        int score; uint32_t ri, rj;
+        if (XDROP) { score = best_max; ri = best_i; rj = best_j; }
+        else {
+            lds_sync();
+            if (dir == DIR_DOWN) score = off + uni((int)L.D_row[rlen - sj]) - ZERO;
+            else score = off + uni((int)L.D_col[qlen - si]) - ZERO;
+            ri = qlen; rj = rlen;
+        }
+        uint32_t ncig = 0;
+        if (TRACE && bp.cig_ops && !status) {
+            // the trace words and rectangle list were written with plain stores and this slot's arena was read
+            // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            if (lane_id() == 0) {
+                uint32_t st = 0;
+                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, bp.flags & F_CIGAR_EQ, bp.cig_ops,
+                                 bp.cig_off[pair], bp.cig_off[pair + 1], &st);
+                status |= st;
+            }
+        }
+        if (lane_id() == 0) {
+            bp.score[pair] = score; bp.query_idx[pair] = ri; bp.reference_idx[pair] = rj;
+            if (bp.cig_len) bp.cig_len[pair] = ncig;
+            if (bp.cells) bp.cells[pair] = cells;
+            if (bp.status) bp.status[pair] = status;
+            if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
+        }
+    }
+};
+
+__device__ __forceinline__ WaveLds carve_lds(char* base, uint32_t max_size) {
+    const uint32_t ab = lds_array_bytes(max_size);
+    WaveLds L;
+    L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
+    L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
+    L.D_col_ck = (short*)(base + 4 * ab); L.C_col_ck = (short*)(base + 5 * ab);
+    L.D_row_ck = (short*)(base + 6 * ab); L.R_row_ck = (short*)(base + 7 * ab);
+    L.vtab = (short*)(base + 8 * ab);                  // 16 consts + temp1[16] + temp2[16] = 96 B
+    L.mat = (const int8_t*)(base + 8 * ab + 128);      // up to 864 B
+    return L;
+}
+
+// Persistent kernel: one wave per workgroup; waves pull pair indices from a global counter.
+template <int PMAX, int KIND, bool TRACE, bool XDROP>
+__global__ void __launch_bounds__(64) k_align(const BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WaveLds L = carve_lds(smem, bp.max_size);
+    const int lane = lane_id();
+    {   // scoring table and scan artefact constants into LDS
+        int8_t* m = (int8_t*)L.mat;
+        const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_NUC ? 8 * 16 : 2);
+        for (int k = lane; k < nbytes; k += 64) m[k] = bp.matrix[k];
+        if (lane < 16) {
+            // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 see
+            // a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
+            const int mult = lane == 15 ? 0 : (lane == 7 ? 12 : (lane & 7) + 1);
+            L.vtab[lane] = (short)(mult ? max(-32768, mult * bp.gap_extend) : -32768);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const uint32_t slot = blockIdx.x;
+    for (;;) {
+        uint32_t pair = 0;
+        if (lane == 0) pair = atomicAdd(bp.work_counter, 1u);
+        pair = (uint32_t)uni((int)pair);
+        if (pair >= bp.n) break;
+        Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L);
+        al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
+        al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
+        al.run(pair);
+    }
+}
+
+}  // namespace ba

@@ -1,0 +1,646 @@
+// block_aligner_amd — host side of the C ABI declared in include/block_aligner_hip.h.
+// Owns device memory, builds PaddedBytes images, launches the gfx950 kernels (ba_kernels.hip) and mirrors the
+// reference's ffi.rs objects (PaddedBytes, AAMatrix, AAProfile, Cigar, Block handles). No alignment arithmetic is
+// done on the host: without a usable HIP device every align call fails (batch API: error code; reference API: abort).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/block_aligner_hip.h"
+#include "aa_matrices.inc"
+#include "ba_params.h"
+
+using ba::BatchParams;
+using ba::BlockRec;
+
+// ------------------------------------------------------------------ kernel entry points (one TU per kind x class)
+#define BA_DECL(K, P)                                                                                                 \
+    extern "C" hipError_t ba_launch_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);       \
+    extern "C" hipError_t ba_occupancy_k##K##_p##P(int, int, unsigned, int*);
+#define BA_DECL_KIND(K) BA_DECL(K, 1) BA_DECL(K, 2) BA_DECL(K, 4) BA_DECL(K, 8) BA_DECL(K, 16)
+BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2)
+extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
+extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
+
+typedef hipError_t (*LaunchFn)(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+typedef hipError_t (*OccFn)(int, int, unsigned, int*);
+#define BA_ROW(K) {ba_launch_k##K##_p1, ba_launch_k##K##_p2, ba_launch_k##K##_p4, ba_launch_k##K##_p8, ba_launch_k##K##_p16}
+#define BA_OROW(K) {ba_occupancy_k##K##_p1, ba_occupancy_k##K##_p2, ba_occupancy_k##K##_p4, ba_occupancy_k##K##_p8, ba_occupancy_k##K##_p16}
+static const LaunchFn g_launch[3][5] = {BA_ROW(0), BA_ROW(1), BA_ROW(2)};
+static const OccFn g_occ[3][5] = {BA_OROW(0), BA_OROW(1), BA_OROW(2)};
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return 1;
+}
+[[noreturn]] static void die(const char* fmt, ...) {   // reference contract: assert! -> panic = abort (Cargo.toml:41)
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    fprintf(stderr, "block_aligner_hip: %s\n", buf);
+    abort();
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+static int g_device = -1;
+static int ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail("no usable HIP device (hipGetDeviceCount: %s); block_aligner_hip has no CPU fallback", hipGetErrorString(e));
+    if (g_device < 0) g_device = 0;
+    HIP_TRY(hipSetDevice(g_device));
+    return 0;
+}
+
+// ------------------------------------------------------------------ matrices (layouts fixed by the reference ABI)
+struct AAMatrix { alignas(32) int8_t scores[27 * 32]; };
+struct NucMatrix { alignas(32) int8_t scores[8 * 16]; };
+
+static constexpr AAMatrix expand_tri(const signed char* tri) {
+    AAMatrix m{};
+    for (int k = 0; k < 27 * 32; k++) m.scores[k] = -128;
+    int idx = 0;
+    const char* letters = BA_AA_LETTERS;
+    for (int a = 0; a < BA_AA_NLETTERS; a++)
+        for (int b = 0; b <= a; b++) {
+            const int ia = letters[a] - 'A', ib = letters[b] - 'A';
+            m.scores[ia * 32 + ib] = tri[idx];
+            m.scores[ib * 32 + ia] = tri[idx];
+            idx++;
+        }
+    return m;
+}
+static constexpr NucMatrix nuc_simple(int8_t match, int8_t mismatch) {   // scores.rs:150-164
+    NucMatrix m{};
+    for (int k = 0; k < 8 * 16; k++) m.scores[k] = -128;
+    const char alpha[5] = {'A', 'T', 'C', 'G', 'N'};
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 5; j++) m.scores[(alpha[i] & 7) * 16 + (alpha[j] & 15)] = i == j ? match : mismatch;
+    return m;
+}
+extern "C" {
+extern const NucMatrix NW1 = nuc_simple(1, -1);
+extern const AAMatrix BLOSUM45 = expand_tri(BA_TRI_BLOSUM45);
+extern const AAMatrix BLOSUM50 = expand_tri(BA_TRI_BLOSUM50);
+extern const AAMatrix BLOSUM62 = expand_tri(BA_TRI_BLOSUM62);
+extern const AAMatrix BLOSUM80 = expand_tri(BA_TRI_BLOSUM80);
+extern const AAMatrix BLOSUM90 = expand_tri(BA_TRI_BLOSUM90);
+extern const AAMatrix PAM100 = expand_tri(BA_TRI_PAM100);
+extern const AAMatrix PAM120 = expand_tri(BA_TRI_PAM120);
+extern const AAMatrix PAM160 = expand_tri(BA_TRI_PAM160);
+extern const AAMatrix PAM200 = expand_tri(BA_TRI_PAM200);
+extern const AAMatrix PAM250 = expand_tri(BA_TRI_PAM250);
+extern const ByteMatrix BYTES1 = {1, -1};
+}
+
+static inline uint8_t upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+static inline uint8_t null_byte(int kind) { return kind == BA_KIND_AA ? 26 : (kind == BA_KIND_NUC ? 'Z' : 0); }
+// convert_char of scores.rs:130-134 / 212-216 / 270-272; returns false on a byte the reference would assert on
+static inline bool convert_char(int kind, uint8_t c, uint8_t* out) {
+    if (kind == BA_KIND_BYTES) { *out = c; return true; }
+    c = upper(c);
+    if (kind == BA_KIND_AA) { if (c < 'A' || c > 'A' + 26) return false; *out = (uint8_t)(c - 'A'); return true; }
+    if (c < 'A' || c > 'Z') return false;
+    *out = c;
+    return true;
+}
+
+// ------------------------------------------------------------------ host mirrors of the reference's opaque objects
+struct PaddedBytes {   // scan_block.rs:1790-1884
+    std::vector<uint8_t> s;
+    size_t len;
+    int kind;
+};
+struct Cigar {         // cigar.rs:42-145; runs kept in alignment order
+    std::vector<OpLen> ops;
+    size_t capacity;   // query_len + reference_len + 5 (cigar.rs:50)
+};
+struct AAProfile {     // scores.rs:452-468
+    std::vector<int8_t> pos_aa;                    // [curr_len][32]
+    std::vector<int16_t> gap_open_C, gap_close_C, gap_open_R;
+    int8_t gap_extend;
+    size_t max_len, curr_len, str_len;
+};
+
+// ------------------------------------------------------------------ device batch
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        free_();
+        if (n == 0) n = 4;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e)); }
+        bytes = n;
+        return 0;
+    }
+    void free_() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    ~DevBuf() { free_(); }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct BaBatch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int kind = 0; uint32_t mode = 0;
+    uint32_t n = 0, min_size = 0, max_size = 0, pclass = 0;
+    int gap_open = 0, gap_extend = 0, x_drop = 0;
+    uint32_t grid = 0, lds = 0;
+    uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
+    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, trace, blocks, counter;
+    std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
+    bool ran = false;
+    BatchParams params() const {
+        BatchParams bp{};
+        bp.pool = pool.as<uint8_t>();
+        bp.q_off = q_off.as<uint64_t>(); bp.q_len = q_len.as<uint32_t>();
+        bp.r_off = r_off.as<uint64_t>(); bp.r_len = r_len.as<uint32_t>();
+        bp.n = n; bp.gap_open = gap_open; bp.gap_extend = gap_extend;
+        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode;
+        bp.matrix = matrix.as<int8_t>();
+        bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
+        bp.cig_ops = (mode & BA_TRACE) ? cig_ops.as<uint32_t>() : nullptr;
+        bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
+        bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>();
+        bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
+        bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
+        bp.work_counter = counter.as<uint32_t>();
+        return bp;
+    }
+    ~BaBatch() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int check_align_params(Gaps g, size_t min_size, size_t max_size, int32_t x_drop, uint32_t mode, std::string* why) {
+    // scan_block.rs:847-862
+    if (!(g.open < 0 && g.extend < 0)) { *why = "Gap costs must be negative!"; return 1; }
+    if (!(g.open < g.extend)) { *why = "Gap open must cost more than gap extend!"; return 1; }
+    if (!(min_size < 65535 && max_size < 65535)) { *why = "Block sizes must be smaller than 2^16 - 1!"; return 1; }
+    if ((min_size & (min_size - 1)) || (max_size & (max_size - 1))) { *why = "Block sizes must be powers of two!"; return 1; }
+    if ((mode & BA_X_DROP) && x_drop < 0) { *why = "X-drop threshold amount must be nonnegative!"; return 1; }
+    if ((mode & BA_LOCAL_START) && (mode & BA_FREE_QUERY_START_GAPS)) { *why = "Cannot set both LOCAL_START and FREE_QUERY_START_GAPS!"; return 1; }
+    if ((mode & BA_X_DROP) && (mode & BA_FREE_QUERY_END_GAPS)) { *why = "Cannot set both X_DROP and FREE_QUERY_END_GAPS!"; return 1; }
+    return 0;
+}
+
+static int pclass_of(size_t max_size) {   // index into {1,2,4,8,16} packed registers per lane
+    if (max_size <= 128) return 0;
+    if (max_size == 256) return 1;
+    if (max_size == 512) return 2;
+    if (max_size == 1024) return 3;
+    if (max_size == 2048) return 4;
+    return -1;
+}
+
+// Build a batch from already-converted byte ranges. `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1).
+template <class GetSeq>
+static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, size_t n,
+                            bool already_converted, GetSeq get) {
+    if (ensure_device()) return nullptr;
+    if (kind < 0 || kind > 2) { fail("unknown matrix kind %d", kind); return nullptr; }
+    const size_t min_size = size.min < 16 ? 16 : size.min, max_size = size.max < 16 ? 16 : size.max;   // clamp to L (scan_block.rs:853-854)
+    std::string why;
+    if (check_align_params(gaps, min_size, max_size, x_drop, mode, &why)) { fail("%s", why.c_str()); return nullptr; }
+    if (min_size > max_size) { fail("min block size exceeds max block size"); return nullptr; }
+    if (mode & (BA_LOCAL_START | BA_FREE_QUERY_START_GAPS | BA_FREE_QUERY_END_GAPS)) {
+        fail("LOCAL_START / FREE_QUERY_*_GAPS are not implemented in the HIP backend yet"); return nullptr;
+    }
+    if (kind == BA_KIND_BYTES && (mode & BA_X_DROP)) { /* allowed by the reference, documented as inaccurate (scores.rs:235-239) */ }
+    const int pc = pclass_of(max_size);
+    if (pc < 0) { fail("max block size %zu not supported by the HIP backend (16..2048)", max_size); return nullptr; }
+    if (n == 0 || n > 0x7fffffffu) { fail("batch must hold between 1 and 2^31-1 pairs"); return nullptr; }
+
+    std::unique_ptr<BaBatch> b(new BaBatch);
+    b->device = g_device; b->kind = kind; b->mode = mode; b->n = (uint32_t)n;
+    b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
+    b->gap_open = gaps.open; b->gap_extend = gaps.extend; b->x_drop = x_drop;
+
+    // ---- PaddedBytes images: [NULL] + bytes + NULL x (max_size + 16)
+    const size_t pad = max_size + 16;
+    std::vector<uint64_t>& qo = b->h_q_off; std::vector<uint64_t>& ro = b->h_r_off;
+    qo.resize(n); ro.resize(n);
+    std::vector<uint32_t> ql(n), rl(n);
+    uint64_t total = 0, maxlen2 = 0, cig_total = 0;
+    std::vector<uint64_t> cig_off(n + 1);
+    for (size_t p = 0; p < n; p++) {
+        const uint8_t* ptr; size_t len;
+        get(p, 0, &ptr, &len);
+        if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
+        ql[p] = (uint32_t)len; qo[p] = total; total += 1 + len + pad;
+        get(p, 1, &ptr, &len);
+        if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
+        rl[p] = (uint32_t)len; ro[p] = total; total += 1 + len + pad;
+        maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
+        cig_off[p] = cig_total;
+        cig_total += (uint64_t)ql[p] + rl[p] + 1;
+    }
+    cig_off[n] = cig_total;
+    total += 64;
+    std::vector<uint8_t> image(total, null_byte(kind));
+    for (size_t p = 0; p < n; p++) {
+        for (int w = 0; w < 2; w++) {
+            const uint8_t* ptr; size_t len;
+            get(p, w, &ptr, &len);
+            uint8_t* dst = image.data() + (w ? ro[p] : qo[p]) + 1;
+            if (already_converted) memcpy(dst, ptr, len);
+            else for (size_t k = 0; k < len; k++) {
+                if (!convert_char(kind, ptr[k], dst + k)) { fail("pair %zu: byte 0x%02x is outside the matrix alphabet", p, ptr[k]); return nullptr; }
+            }
+        }
+    }
+    b->pool_bytes = total;
+
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return nullptr; }
+    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { fail("hipEventCreate failed"); return nullptr; }
+
+    const bool trace = mode & BA_TRACE;
+    const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : 2);
+    // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return nullptr; }
+    b->lds = ba::lds_wave_bytes_h((uint32_t)max_size);
+    int per_cu = 0;
+    if (g_occ[kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
+        fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return nullptr;
+    }
+    if (per_cu > 32) per_cu = 32;
+    uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
+    if (const char* env = getenv("BA_WAVES_PER_CU")) { int v = atoi(env); if (v > 0) grid = (uint64_t)prop.multiProcessorCount * v; }
+    if (grid > n) grid = n;
+    b->grid = (uint32_t)grid;
+    // trace stack capacity per resident wave: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
+    b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 : 0;
+    b->blocks_stride = trace ? maxlen2 : 0;
+    if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
+    b->cig_total = trace ? cig_total : 0;
+
+#define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return nullptr
+    BA_ALLOC(pool, total); BA_ALLOC(q_off, n * 8); BA_ALLOC(q_len, n * 4); BA_ALLOC(r_off, n * 8); BA_ALLOC(r_len, n * 4);
+    BA_ALLOC(matrix, 1024);
+    BA_ALLOC(score, n * 4); BA_ALLOC(qidx, n * 4); BA_ALLOC(ridx, n * 4); BA_ALLOC(cig_len, n * 4); BA_ALLOC(cells, n * 8);
+    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(counter, 64);
+    BA_ALLOC(cig_off, (n + 1) * 8);
+    BA_ALLOC(cig_ops, b->cig_total * 4);
+    BA_ALLOC(trace, b->trace_stride * 4 * b->grid);
+    BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->grid);
+#undef BA_ALLOC
+#define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
+    BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
+    BA_H2D(r_off, ro.data(), n * 8); BA_H2D(r_len, rl.data(), n * 4); BA_H2D(cig_off, cig_off.data(), (n + 1) * 8);
+    {
+        int8_t tmp[1024] = {0};
+        if (kind == BA_KIND_BYTES) { const ByteMatrix* bm = (const ByteMatrix*)matrix; tmp[0] = bm->match_score; tmp[1] = bm->mismatch_score; }
+        else memcpy(tmp, matrix, mat_bytes);
+        BA_H2D(matrix, tmp, 1024);
+    }
+#undef BA_H2D
+    if (hipMemset(b->cig_len.p, 0, n * 4) != hipSuccess || hipMemset(b->status.p, 0, n * 4) != hipSuccess) { fail("hipMemset failed"); return nullptr; }
+    return b.release();
+}
+
+static int batch_run(BaBatch* b, float* kernel_ms) {
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+    const BatchParams bp = b->params();
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    HIP_TRY(g_launch[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));
+    b->ran = true;
+    return 0;
+}
+
+template <class T>
+static int d2h(const DevBuf& buf, T* dst, size_t count) {
+    if (!dst) return 0;
+    HIP_TRY(hipMemcpy(dst, buf.p, count * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------ C ABI, Part 2
+extern "C" {
+
+const char* ba_last_error(void) { return g_err.c_str(); }
+int ba_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int ba_set_device(int device) {
+    int n = ba_device_count();
+    if (device < 0 || device >= n) return fail("device %d out of range (%d devices)", device, n);
+    g_device = device;
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+uintptr_t block_percent_len(uintptr_t len, float p) {   // lib.rs:109-111
+    size_t v = (size_t)std::round(p * (float)len);
+    if (v < 32) v = 32;
+    size_t pw = 1;
+    while (pw < v) pw <<= 1;
+    return pw < ((size_t)1 << 14) ? pw : ((size_t)1 << 14);
+}
+
+BaBatch* ba_batch_create(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, const uint8_t* pool,
+                         const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n) {
+    if (!matrix || !pool || !q_off || !q_len || !r_off || !r_len) { fail("null argument"); return nullptr; }
+    return batch_build(kind, matrix, gaps, size, x_drop, mode, n, false, [&](size_t p, int w, const uint8_t** ptr, size_t* len) {
+        if (w == 0) { *ptr = pool + q_off[p]; *len = q_len[p]; } else { *ptr = pool + r_off[p]; *len = r_len[p]; }
+    });
+}
+int ba_batch_run(BaBatch* b, float* kernel_ms) { return b ? batch_run(b, kernel_ms) : fail("null batch"); }
+int ba_batch_results(BaBatch* b, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {
+    if (!b) return fail("null batch");
+    if (!b->ran) return fail("ba_batch_run has not been called");
+    HIP_TRY(hipSetDevice(b->device));
+    if (d2h(b->score, score, b->n) || d2h(b->qidx, qi, b->n) || d2h(b->ridx, ri, b->n) || d2h(b->cells, cells, b->n) ||
+        d2h(b->cig_len, cigar_len, b->n) || d2h(b->status, status, b->n)) return 1;
+    return 0;
+}
+int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
+    if (!b) return fail("null batch");
+    if (!(b->mode & BA_TRACE)) return fail("batch was created without BA_TRACE");
+    if (!b->ran) return fail("ba_batch_run has not been called");
+    HIP_TRY(hipSetDevice(b->device));
+    std::vector<uint32_t> len(b->n);
+    if (d2h(b->cig_len, len.data(), b->n)) return 1;
+    std::vector<uint64_t> out_off(b->n);
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < b->n; p++) { out_off[p] = total; total += len[p]; }
+    if (total > capacity) return fail("cigar buffer too small: need %llu entries", (unsigned long long)total);
+    if (total == 0) return 0;
+    DevBuf d_off, d_out;
+    if (d_off.alloc(b->n * 8) || d_out.alloc(total * 4)) return 1;
+    HIP_TRY(hipMemcpy(d_off.p, out_off.data(), b->n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ba_launch_compact_cigars(b->stream, b->cig_ops.as<uint32_t>(), b->cig_off.as<uint64_t>(), b->cig_len.as<uint32_t>(),
+                                     d_off.as<uint64_t>(), d_out.as<uint32_t>(), b->n));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(runs, d_out.p, total * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int ba_batch_info(BaBatch* b, uint64_t out[4]) {
+    if (!b) return fail("null batch");
+    out[0] = b->grid; out[1] = b->lds; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
+    return 0;
+}
+void ba_batch_destroy(BaBatch* b) { delete b; }
+
+int block_batch_align(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, const uint8_t* pool,
+                      const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n,
+                      AlignResult* results, uint32_t* cigar_runs, uint64_t cigar_capacity, uint32_t* cigar_len) {
+    std::unique_ptr<BaBatch> b(ba_batch_create(kind, matrix, gaps, size, x_drop, mode, pool, q_off, q_len, r_off, r_len, n));
+    if (!b) return 1;
+    if (ba_batch_run(b.get(), nullptr)) return 1;
+    std::vector<int32_t> sc(n); std::vector<uint32_t> qi(n), ri(n), st(n);
+    if (ba_batch_results(b.get(), sc.data(), qi.data(), ri.data(), nullptr, cigar_len, st.data())) return 1;
+    for (size_t p = 0; p < n; p++) {
+        if (st[p]) return fail("pair %zu failed on the device (status 0x%x)", p, st[p]);
+        if (results) results[p] = AlignResult{sc[p], qi[p], ri[p]};
+    }
+    if ((mode & BA_TRACE) && cigar_runs) return ba_batch_cigars(b.get(), cigar_runs, cigar_capacity);
+    return 0;
+}
+
+// ------------------------------------------------------------------ nucleotide / byte objects
+NucMatrix* block_new_simple_nucmatrix(int8_t match_score, int8_t mismatch_score) { return new NucMatrix(nuc_simple(match_score, mismatch_score)); }
+void block_set_nucmatrix(NucMatrix* m, uint8_t a, uint8_t b, int8_t score) {   // scores.rs:174-183
+    a = upper(a); b = upper(b);
+    if (!(a >= 'A' && a <= 'Z' && b >= 'A' && b <= 'Z')) die("NucMatrix::set: bytes must be in 'A'..='Z'");
+    m->scores[(a & 7) * 16 + (b & 15)] = score;
+    m->scores[(b & 7) * 16 + (a & 15)] = score;
+}
+void block_free_nucmatrix(NucMatrix* m) { delete m; }
+
+static PaddedBytes* padded_new(int kind, size_t len, size_t max_size) {   // scan_block.rs:1798-1803
+    PaddedBytes* p = new PaddedBytes;
+    p->s.assign(1 + len + max_size, null_byte(kind));
+    p->len = len; p->kind = kind;
+    return p;
+}
+static void padded_set(PaddedBytes* p, const uint8_t* s, size_t len, size_t max_size, bool rev) {   // scan_block.rs:1806-1822
+    if (1 + len + max_size > p->s.size()) die("PaddedBytes::set_bytes: %zu bytes + %zu padding exceed the allocated %zu", len, max_size, p->s.size());
+    p->s[0] = null_byte(p->kind);
+    for (size_t k = 0; k < len; k++) {
+        uint8_t c;
+        if (!convert_char(p->kind, s[rev ? len - 1 - k : k], &c)) die("byte 0x%02x is outside the matrix alphabet", s[rev ? len - 1 - k : k]);
+        p->s[1 + k] = c;
+    }
+    std::fill(p->s.begin() + 1 + len, p->s.begin() + 1 + len + max_size, null_byte(p->kind));
+    p->len = len;
+}
+PaddedBytes* block_new_padded_nuc(uintptr_t len, uintptr_t max_size) { return padded_new(BA_KIND_NUC, len, max_size); }
+void block_set_bytes_padded_nuc(PaddedBytes* p, const uint8_t* s, uintptr_t len, uintptr_t max_size) { padded_set(p, s, len, max_size, false); }
+void block_set_bytes_rev_padded_nuc(PaddedBytes* p, const uint8_t* s, uintptr_t len, uintptr_t max_size) { padded_set(p, s, len, max_size, true); }
+void block_free_padded_nuc(PaddedBytes* p) { delete p; }
+PaddedBytes* block_new_padded_bytes(uintptr_t len, uintptr_t max_size) { return padded_new(BA_KIND_BYTES, len, max_size); }
+void block_set_bytes_padded_bytes(PaddedBytes* p, const uint8_t* s, uintptr_t len, uintptr_t max_size) { padded_set(p, s, len, max_size, false); }
+void block_free_padded_bytes(PaddedBytes* p) { delete p; }
+
+// ------------------------------------------------------------------ Part 1: AAMatrix, PaddedBytes (aa), Cigar
+AAMatrix* block_new_simple_aamatrix(int8_t match_score, int8_t mismatch_score) {   // scores.rs:48-61
+    AAMatrix* m = new AAMatrix;
+    memset(m->scores, 0x80, sizeof m->scores);
+    for (int i = 0; i < 26; i++)
+        for (int j = 0; j < 26; j++) m->scores[i * 32 + j] = i == j ? match_score : mismatch_score;
+    return m;
+}
+void block_set_aamatrix(AAMatrix* m, uint8_t a, uint8_t b, int8_t score) {   // scores.rs:89-98
+    a = upper(a); b = upper(b);
+    if (!(a >= 'A' && a <= 'Z' + 1 && b >= 'A' && b <= 'Z' + 1)) die("AAMatrix::set: bytes must be in 'A'..='['");
+    m->scores[(a - 'A') * 32 + (b - 'A')] = score;
+    m->scores[(b - 'A') * 32 + (a - 'A')] = score;
+}
+void block_free_aamatrix(AAMatrix* m) { delete m; }
+
+PaddedBytes* block_new_padded_aa(uintptr_t len, uintptr_t max_size) { return padded_new(BA_KIND_AA, len, max_size); }
+void block_set_bytes_padded_aa(PaddedBytes* p, const uint8_t* s, uintptr_t len, uintptr_t max_size) { padded_set(p, s, len, max_size, false); }
+void block_set_bytes_rev_padded_aa(PaddedBytes* p, const uint8_t* s, uintptr_t len, uintptr_t max_size) { padded_set(p, s, len, max_size, true); }
+void block_free_padded_aa(PaddedBytes* p) { delete p; }
+
+Cigar* block_new_cigar(uintptr_t query_len, uintptr_t reference_len) {   // cigar.rs:49-54
+    Cigar* c = new Cigar;
+    c->capacity = query_len + reference_len + 5;
+    return c;
+}
+OpLen block_get_cigar(const Cigar* c, uintptr_t i) {   // cigar.rs:92-94 (i-th run from the start of the alignment)
+    if (i >= c->ops.size()) die("Cigar::get: index %zu out of range (%zu runs)", (size_t)i, c->ops.size());
+    return c->ops[i];
+}
+uintptr_t block_len_cigar(const Cigar* c) { return c->ops.size(); }
+void block_free_cigar(Cigar* c) { delete c; }
+
+// ------------------------------------------------------------------ Part 1: AAProfile (host object; scores.rs:470-715)
+AAProfile* block_new_aaprofile(uintptr_t str_len, uintptr_t block_size, int8_t gap_extend) {
+    AAProfile* p = new AAProfile;
+    p->max_len = p->curr_len = str_len + block_size + 1;
+    p->str_len = str_len; p->gap_extend = gap_extend;
+    p->pos_aa.assign(p->max_len * 32, (int8_t)-128);
+    p->gap_open_C.assign(p->max_len, -128); p->gap_close_C.assign(p->max_len, -128); p->gap_open_R.assign(p->max_len, -128);
+    return p;
+}
+uintptr_t block_len_aaprofile(const AAProfile* p) { return p->str_len; }
+void block_clear_aaprofile(AAProfile* p, uintptr_t str_len, uintptr_t block_size) {
+    const size_t cl = str_len + block_size + 1;
+    if (cl > p->max_len) die("AAProfile::clear: length exceeds the allocation");
+    std::fill(p->pos_aa.begin(), p->pos_aa.begin() + cl * 32, (int8_t)-128);
+    std::fill(p->gap_open_C.begin(), p->gap_open_C.begin() + cl, (int16_t)-128);
+    std::fill(p->gap_close_C.begin(), p->gap_close_C.begin() + cl, (int16_t)-128);
+    std::fill(p->gap_open_R.begin(), p->gap_open_R.begin() + cl, (int16_t)-128);
+    p->str_len = str_len; p->curr_len = cl;
+}
+void block_set_aaprofile(AAProfile* p, uintptr_t i, uint8_t b, int8_t score) {
+    b = upper(b);
+    if (!(b >= 'A' && b <= 'Z' + 1)) die("AAProfile::set: byte must be in 'A'..='['");
+    if (i >= p->curr_len) die("AAProfile::set: position out of range");
+    p->pos_aa[i * 32 + (b - 'A')] = score;
+}
+static void profile_set_all(AAProfile* p, const uint8_t* order, size_t order_len, const int8_t* scores, size_t scores_len,
+                            size_t left_shift, size_t right_shift, bool rev) {   // scores.rs:677-714
+    if (order_len == 0 || order_len > 32) die("AAProfile::set_all: order length must be in 1..=32");
+    uint8_t o[32];
+    for (size_t k = 0; k < order_len; k++) {
+        const uint8_t b = upper(order[k]);
+        if (!(b >= 'A' && b <= 'Z' + 1)) die("AAProfile::set_all: order byte out of range");
+        o[k] = (uint8_t)(b - 'A');
+    }
+    if (scores_len / order_len != p->str_len) die("AAProfile::set_all: scores length does not match the profile length");
+    size_t idx = 0;
+    for (size_t n = 0; n < p->str_len; n++) {
+        const size_t i = rev ? p->str_len - n : 1 + n;
+        for (size_t j = 0; j < order_len; j++) {
+            const int8_t sc = (int8_t)((int8_t)((uint8_t)scores[idx] << left_shift) >> right_shift);
+            p->pos_aa[i * 32 + o[j]] = sc;
+            idx++;
+        }
+    }
+}
+void block_set_all_aaprofile(AAProfile* p, const uint8_t* order, uintptr_t order_len, const int8_t* scores, uintptr_t scores_len,
+                             uintptr_t left_shift, uintptr_t right_shift) { profile_set_all(p, order, order_len, scores, scores_len, left_shift, right_shift, false); }
+void block_set_all_rev_aaprofile(AAProfile* p, const uint8_t* order, uintptr_t order_len, const int8_t* scores, uintptr_t scores_len,
+                                 uintptr_t left_shift, uintptr_t right_shift) { profile_set_all(p, order, order_len, scores, scores_len, left_shift, right_shift, true); }
+void block_set_gap_open_C_aaprofile(AAProfile* p, uintptr_t i, int8_t gap) { if (gap >= 0) die("Gap open cost must be negative!"); p->gap_open_C.at(i) = gap; }
+void block_set_gap_close_C_aaprofile(AAProfile* p, uintptr_t i, int8_t gap) { p->gap_close_C.at(i) = gap; }
+void block_set_gap_open_R_aaprofile(AAProfile* p, uintptr_t i, int8_t gap) { if (gap >= 0) die("Gap open cost must be negative!"); p->gap_open_R.at(i) = gap; }
+void block_set_all_gap_open_C_aaprofile(AAProfile* p, int8_t gap) { if (gap >= 0) die("Gap open cost must be negative!"); std::fill(p->gap_open_C.begin(), p->gap_open_C.begin() + p->str_len + 1, (int16_t)gap); }
+void block_set_all_gap_close_C_aaprofile(AAProfile* p, int8_t gap) { std::fill(p->gap_close_C.begin(), p->gap_close_C.begin() + p->str_len + 1, (int16_t)gap); }
+void block_set_all_gap_open_R_aaprofile(AAProfile* p, int8_t gap) { if (gap >= 0) die("Gap open cost must be negative!"); std::fill(p->gap_open_R.begin(), p->gap_open_R.begin() + p->str_len + 1, (int16_t)gap); }
+int8_t block_get_aaprofile(const AAProfile* p, uintptr_t i, uint8_t b) {
+    b = upper(b);
+    if (!(b >= 'A' && b <= 'Z' + 1)) die("AAProfile::get: byte must be in 'A'..='['");
+    return p->pos_aa.at(i * 32 + (b - 'A'));
+}
+int8_t block_get_gap_extend_aaprofile(const AAProfile* p) { return p->gap_extend; }
+void block_free_aaprofile(AAProfile* p) { delete p; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ Block handles (Part 1 + generic)
+struct BlockImpl {
+    uint32_t mode;                 // BA_TRACE | BA_X_DROP | ...
+    size_t query_len, reference_len, max_size;   // upper bounds from Block::new (scan_block.rs:798-805)
+    AlignResult res{0, 0, 0};
+    std::unique_ptr<BaBatch> last;               // device state of the latest align (trace stack for later cigar calls)
+};
+
+static BlockImpl* block_new_impl(uint32_t mode, size_t query_len, size_t reference_len, size_t max_size) {
+    if (max_size == 0 || (max_size & (max_size - 1))) die("Block size must be a power of two!");
+    BlockImpl* b = new BlockImpl;
+    b->mode = mode; b->query_len = query_len; b->reference_len = reference_len; b->max_size = max_size;
+    return b;
+}
+
+static void block_align_impl(BlockImpl* b, int kind, const PaddedBytes* q, const PaddedBytes* r, const void* matrix, Gaps g, SizeRange s, int32_t x) {
+    if (q->kind != kind || r->kind != kind) die("PaddedBytes were built for a different matrix kind");
+    const size_t min_size = s.min < 16 ? 16 : s.min, max_size = s.max < 16 ? 16 : s.max;
+    std::string why;
+    if (check_align_params(g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    // Allocated::clear (scan_block.rs:1324-1326)
+    if (q->len + r->len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
+    if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
+    b->last.reset(batch_build(kind, matrix, g, SizeRange{min_size, max_size}, x, b->mode & ~(uint32_t)BA_CIGAR_EQ, 1, true,
+                              [&](size_t, int w, const uint8_t** ptr, size_t* len) {
+                                  const PaddedBytes* p = w ? r : q;
+                                  *ptr = p->s.data() + 1; *len = p->len;
+                              }));
+    if (!b->last) die("%s", g_err.c_str());
+    if (batch_run(b->last.get(), nullptr)) die("%s", g_err.c_str());
+    int32_t sc; uint32_t qi, ri, st;
+    if (ba_batch_results(b->last.get(), &sc, &qi, &ri, nullptr, nullptr, &st)) die("%s", g_err.c_str());
+    if (st) die("device alignment failed (status 0x%x)", st);
+    b->res = AlignResult{sc, qi, ri};
+}
+
+static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const PaddedBytes* r, size_t i, size_t j, Cigar* cigar) {
+    if (!(b->mode & BA_TRACE)) die("trace() requires a Block created with TRACE");   // scan_block.rs:1241-1243
+    BaBatch* d = b->last.get();
+    if (!d) die("cigar requested before any alignment");
+    uint32_t ql, rl, nb;
+    if (d2h(d->q_len, &ql, 1) || d2h(d->r_len, &rl, 1) || d2h(d->nblocks, &nb, 1)) die("%s", g_err.c_str());
+    if (!(i <= ql && j <= rl)) die("Traceback cigar end position must be in bounds!");   // scan_block.rs:1483
+    if (i + j + 5 > cigar->capacity) die("Cigar was created for shorter sequences than this traceback needs");   // cigar.rs:58-60 slice bound
+    (void)q; (void)r;   // the padded images of the aligned pair are already resident on the device
+    BatchParams bp = d->params();
+    bp.flags = eq ? (bp.flags | ba::F_CIGAR_EQ) : (bp.flags & ~ba::F_CIGAR_EQ);
+    bp.tb_i = (uint32_t)i; bp.tb_j = (uint32_t)j; bp.tb_nblocks = nb;
+    if (hipSetDevice(d->device) != hipSuccess || ba_launch_traceback(d->stream, &bp) != hipSuccess ||
+        hipStreamSynchronize(d->stream) != hipSuccess) die("traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    uint32_t n, st;
+    if (d2h(d->cig_len, &n, 1) || d2h(d->status, &st, 1)) die("%s", g_err.c_str());
+    if (st) die("device traceback failed (status 0x%x)", st);
+    std::vector<uint32_t> runs(n);
+    if (n && hipMemcpy(runs.data(), d->cig_ops.as<uint32_t>() + (d->cig_total - n), (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        die("hipMemcpy of cigar runs failed");
+    cigar->ops.resize(n);
+    for (uint32_t k = 0; k < n; k++) cigar->ops[k] = OpLen{(Operation)(runs[k] & 15), (uintptr_t)(runs[k] >> 4)};
+}
+
+extern "C" {
+
+BlockHandle block_new_generic(uint32_t mode, uintptr_t ql, uintptr_t rl, uintptr_t max_size) { return block_new_impl(mode, ql, rl, max_size); }
+void block_align_generic(BlockHandle b, int kind, const PaddedBytes* q, const PaddedBytes* r, const void* matrix, Gaps g, SizeRange s, int32_t x) {
+    block_align_impl((BlockImpl*)b, kind, q, r, matrix, g, s, x);
+}
+AlignResult block_res_generic(BlockHandle b) { return ((BlockImpl*)b)->res; }
+void block_cigar_generic(BlockHandle b, uintptr_t i, uintptr_t j, Cigar* c) { block_cigar_impl((BlockImpl*)b, false, nullptr, nullptr, i, j, c); }
+void block_cigar_eq_generic(BlockHandle b, const PaddedBytes* q, const PaddedBytes* r, uintptr_t i, uintptr_t j, Cigar* c) {
+    block_cigar_impl((BlockImpl*)b, true, q, r, i, j, c);
+}
+void block_free_generic(BlockHandle b) { delete (BlockImpl*)b; }
+
+#define BA_DEFINE_BLOCK_FNS(S, CIG, CIGEQ, MODE)                                                                                    \
+    BlockHandle block_new_##S(uintptr_t ql, uintptr_t rl, uintptr_t max_size) { return block_new_impl(MODE, ql, rl, max_size); }   \
+    void block_align_##S(BlockHandle b, const PaddedBytes* q, const PaddedBytes* r, const AAMatrix* m, Gaps g, SizeRange s, int32_t x) { \
+        block_align_impl((BlockImpl*)b, BA_KIND_AA, q, r, m, g, s, x);                                                            \
+    }                                                                                                                             \
+    void block_align_profile_##S(BlockHandle, const PaddedBytes*, const AAProfile*, SizeRange, int32_t) {                         \
+        die("sequence-to-profile alignment is not implemented in the HIP backend yet");                                           \
+    }                                                                                                                             \
+    AlignResult block_res_##S(BlockHandle b) { return ((BlockImpl*)b)->res; }                                                      \
+    void CIG(BlockHandle b, uintptr_t i, uintptr_t j, Cigar* c) { block_cigar_impl((BlockImpl*)b, false, nullptr, nullptr, i, j, c); } \
+    void CIGEQ(BlockHandle b, const PaddedBytes* q, const PaddedBytes* r, uintptr_t i, uintptr_t j, Cigar* c) {                    \
+        block_cigar_impl((BlockImpl*)b, true, q, r, i, j, c);                                                                     \
+    }                                                                                                                             \
+    void block_free_##S(BlockHandle b) { delete (BlockImpl*)b; }
+
+BA_DEFINE_BLOCK_FNS(aa, _block_cigar_aa, _block_cigar_eq_aa, 0)
+BA_DEFINE_BLOCK_FNS(aa_xdrop, _block_cigar_aa_xdrop, _block_cigar_eq_aa_xdrop, BA_X_DROP)
+BA_DEFINE_BLOCK_FNS(aa_trace, block_cigar_aa_trace, block_cigar_eq_aa_trace, BA_TRACE)
+BA_DEFINE_BLOCK_FNS(aa_trace_xdrop, block_cigar_aa_trace_xdrop, block_cigar_eq_aa_trace_xdrop, BA_TRACE | BA_X_DROP)
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// One translation unit per (matrix kind, max-block class): compiled with -DBA_KIND=<0|1|2> -DBA_PMAX=<1|2|4|8|16>.
+// BA_PMAX = max block size / 128 (packed VGPRs per border array per lane); a smaller class keeps the kernel's VGPR
+// budget (and so its occupancy) matched to the batch's max block size.
+#include "ba_driver.hpp"
+
+#ifndef BA_KIND
+#error "define BA_KIND"
+#endif
+#ifndef BA_PMAX
+#error "define BA_PMAX"
+#endif
+
+#define BA_CAT_(a, b, c, d) a##b##c##d
+#define BA_CAT(a, b, c, d) BA_CAT_(a, b, c, d)
+#define BA_LAUNCH BA_CAT(ba_launch_k, BA_KIND, _p, BA_PMAX)
+#define BA_OCC BA_CAT(ba_occupancy_k, BA_KIND, _p, BA_PMAX)
+
+template <bool TRACE, bool XDROP>
+static hipError_t launch1(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP>
+static hipError_t occ1(int* blocks_per_cu, unsigned lds) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, 64, lds);
+}
+
+extern "C" hipError_t BA_LAUNCH(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch1<true, true>(grid, lds, s, *bp) : launch1<true, false>(grid, lds, s, *bp);
+    return xdrop ? launch1<false, true>(grid, lds, s, *bp) : launch1<false, false>(grid, lds, s, *bp);
+}
+extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    if (trace) return xdrop ? occ1<true, true>(blocks_per_cu, lds) : occ1<true, false>(blocks_per_cu, lds);
+    return xdrop ? occ1<false, true>(blocks_per_cu, lds) : occ1<false, false>(blocks_per_cu, lds);
+}
+
+#if BA_KIND == 0 && BA_PMAX == 1
+// kernels that exist once
+// Traceback from an arbitrary end cell over slot 0's trace (the per-handle API: block_cigar_* after block_align_*).
+__global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {
+    using namespace ba;
+    if (lane_id() != 0) return;
+    uint32_t st = 0;
+    const uint32_t n = traceback(bp.blocks, bp.tb_nblocks, bp.trace_arena, bp.tb_i, bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0],
+                                 bp.flags & F_CIGAR_EQ, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
+    bp.cig_len[0] = n;
+    bp.status[0] = st;
+}
+
+__global__ void __launch_bounds__(256) k_compact_cigars(const uint32_t* __restrict__ ops, const uint64_t* __restrict__ cig_off,
+                                                        const uint32_t* __restrict__ cig_len, const uint64_t* __restrict__ out_off,
+                                                        uint32_t* __restrict__ out, uint32_t n) {
+    for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
+        const uint32_t len = cig_len[p];
+        const uint64_t src = cig_off[p + 1] - len, dst = out_off[p];
+        for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) out[dst + k] = ops[src + k];
+    }
+}
+extern "C" hipError_t ba_launch_compact_cigars(hipStream_t s, const uint32_t* ops, const uint64_t* cig_off, const uint32_t* cig_len,
+                                               const uint64_t* out_off, uint32_t* out, uint32_t n) {
+    const unsigned grid = n < 4096 ? (n ? n : 1) : 4096;
+    k_compact_cigars<<<dim3(grid), dim3(256), 0, s>>>(ops, cig_off, cig_len, out_off, out, n);
+    return hipGetLastError();
+}
+extern "C" hipError_t ba_launch_traceback(hipStream_t s, const ba::BatchParams* bp) {
+    k_traceback<<<dim3(1), dim3(64), 0, s>>>(*bp);
+    return hipGetLastError();
+}
+#endif

@@ -1,0 +1,52 @@
+// block_aligner_amd — structures shared by the host library and the gfx950 kernels (plain C++, no device code).
+#pragma once
+#include <stdint.h>
+
+namespace ba {
+
+constexpr int ZERO = 1 << 14;     // avx2.rs:15
+constexpr int STEP = 8;           // scan_block.rs:787
+constexpr int KIND_AA = 0, KIND_NUC = 1, KIND_BYTES = 2;
+constexpr int DIR_RIGHT = 0, DIR_DOWN = 1, DIR_GROW = 2;
+
+enum : uint32_t {
+    F_TRACE = 1u << 0, F_XDROP = 1u << 1, F_LOCAL = 1u << 2, F_FQS = 1u << 3, F_FQE = 1u << 4, F_CIGAR_EQ = 1u << 5
+};
+enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8 };
+
+struct BlockRec {   // one computed rectangle (scan_block.rs:1428-1443), 16 bytes
+    uint32_t i, j;
+    uint16_t h, w;        // h = rows, w = columns of the rectangle
+    uint32_t trace_base;  // dword index into this slot's trace arena; bit 31 = "right" (vectors along rows)
+};
+
+struct BatchParams {
+    // inputs: pool holds PaddedBytes images: [NULL] + converted bytes + NULL x pad (scan_block.rs:1790-1812)
+    const uint8_t* pool;
+    const uint64_t* q_off; const uint32_t* q_len;
+    const uint64_t* r_off; const uint32_t* r_len;
+    uint32_t n;
+    int32_t gap_open, gap_extend;
+    uint32_t min_size, max_size;
+    int32_t x_drop;
+    uint32_t flags;
+    const int8_t* matrix;      // AA 27x32, NUC 8x16, BYTES {match, mismatch}
+    // outputs
+    int32_t* score; uint32_t* query_idx; uint32_t* reference_idx;
+    uint32_t* cig_ops; const uint64_t* cig_off; uint32_t* cig_start; uint32_t* cig_len;   // runs (len << 4 | op)
+    unsigned long long* cells;   // per pair: computed DP cells, may be null
+    uint32_t* status;            // per pair error bits
+    uint32_t* nblocks_out;       // per pair: rectangles on the trace stack at the end (may be null)
+    // scratch, one region per resident wave
+    uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
+    BlockRec* blocks; uint64_t blocks_stride;         // records per slot
+    uint32_t* work_counter;
+    // single-pair traceback request (k_traceback): end position
+    uint32_t tb_i, tb_j, tb_nblocks, tb_trace_top;
+};
+
+
+inline uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
+inline uint32_t lds_wave_bytes_h(uint32_t max_size) { return 8 * lds_array_bytes_h(max_size) + 128 + 896; }
+
+}  // namespace ba

@@ -1,0 +1,319 @@
+"""ctypes binding of libblock_aligner_hip.so (include/block_aligner_hip.h) and a host-side mirror of the reference's
+Rust API for this path: `PaddedBytes`, `Block` (const-generic modes as constructor flags), `Cigar`, `AlignResult`,
+`percent_len` (src/scan_block.rs, src/cigar.rs, src/lib.rs), plus `BatchAligner` over the batch launcher.
+
+There is no CPU fallback: importing works anywhere (so the symbol table can be checked without a GPU), but every
+alignment call goes to the HIP kernels and fails loudly if the library or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import scores as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libblock_aligner_hip.so")
+
+TRACE, X_DROP, LOCAL_START, FREE_QUERY_START_GAPS, FREE_QUERY_END_GAPS, CIGAR_EQ = 1, 2, 4, 8, 16, 32
+OP_CHARS = " M=XID"
+
+
+class GapsC(C.Structure):
+    _fields_ = [("open", C.c_int8), ("extend", C.c_int8)]
+
+
+class SizeRangeC(C.Structure):
+    _fields_ = [("min", C.c_size_t), ("max", C.c_size_t)]
+
+
+class AlignResultC(C.Structure):
+    _fields_ = [("score", C.c_int32), ("query_idx", C.c_size_t), ("reference_idx", C.c_size_t)]
+
+
+class OpLenC(C.Structure):
+    _fields_ = [("op", C.c_uint8), ("len", C.c_size_t)]
+
+
+@dataclass(frozen=True)
+class AlignResult:
+    score: int
+    query_idx: int
+    reference_idx: int
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "block_aligner_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, sz, u32, i32, i8, u8p = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32, C.c_int8, C.c_char_p
+        L.ba_last_error.restype = C.c_char_p
+        L.ba_set_device.argtypes = [C.c_int]
+        L.block_percent_len.restype = sz
+        L.block_percent_len.argtypes = [sz, C.c_float]
+        for k in ("aa", "nuc", "bytes"):
+            getattr(L, f"block_new_padded_{k}").restype = vp
+            getattr(L, f"block_new_padded_{k}").argtypes = [sz, sz]
+            getattr(L, f"block_set_bytes_padded_{k}").argtypes = [vp, u8p, sz, sz]
+            getattr(L, f"block_free_padded_{k}").argtypes = [vp]
+        for k in ("aa", "nuc"):
+            getattr(L, f"block_set_bytes_rev_padded_{k}").argtypes = [vp, u8p, sz, sz]
+        L.block_new_cigar.restype = vp
+        L.block_new_cigar.argtypes = [sz, sz]
+        L.block_get_cigar.restype = OpLenC
+        L.block_get_cigar.argtypes = [vp, sz]
+        L.block_len_cigar.restype = sz
+        L.block_len_cigar.argtypes = [vp]
+        L.block_free_cigar.argtypes = [vp]
+        L.block_new_generic.restype = vp
+        L.block_new_generic.argtypes = [u32, sz, sz, sz]
+        L.block_align_generic.argtypes = [vp, C.c_int, vp, vp, vp, GapsC, SizeRangeC, i32]
+        L.block_res_generic.restype = AlignResultC
+        L.block_res_generic.argtypes = [vp]
+        L.block_cigar_generic.argtypes = [vp, sz, sz, vp]
+        L.block_cigar_eq_generic.argtypes = [vp, vp, vp, sz, sz, vp]
+        L.block_free_generic.argtypes = [vp]
+        L.ba_batch_create.restype = vp
+        L.ba_batch_create.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, u32, vp, vp, vp, vp, vp, sz]
+        L.ba_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
+        L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
+        L.ba_batch_info.argtypes = [vp, vp]
+        L.ba_batch_destroy.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().ba_last_error().decode()
+
+
+def device_count() -> int:
+    return lib().ba_device_count()
+
+
+def set_device(d: int) -> None:
+    if lib().ba_set_device(d):
+        raise RuntimeError(last_error())
+
+
+def percent_len(length: int, p: float) -> int:
+    """lib.rs:109-111"""
+    return lib().block_percent_len(length, p)
+
+
+def _kind_name(matrix_cls) -> str:
+    return {0: "aa", 1: "nuc", 2: "bytes"}[matrix_cls.KIND]
+
+
+def _size(size) -> SizeRangeC:
+    if isinstance(size, range):  # Rust `a..=b` written as range(a, b + 1)
+        return SizeRangeC(size.start, size.stop - 1)
+    return SizeRangeC(int(size[0]), int(size[1]))
+
+
+class PaddedBytes:
+    """scan_block.rs:1790-1884. `matrix_cls` plays the role of the `<M: Matrix>` type parameter."""
+
+    def __init__(self, length: int, block_size: int, matrix_cls=S.AAMatrix):
+        self.kind = matrix_cls.KIND
+        self._k = _kind_name(matrix_cls)
+        self._h = getattr(lib(), f"block_new_padded_{self._k}")(length, block_size)
+        self._len = length
+        self._cap = length
+
+    new = classmethod(lambda cls, length, block_size, matrix_cls=S.AAMatrix: cls(length, block_size, matrix_cls))
+
+    @classmethod
+    def from_bytes(cls, b: bytes, block_size: int, matrix_cls=S.AAMatrix) -> "PaddedBytes":
+        p = cls(len(b), block_size, matrix_cls)
+        p.set_bytes(b, block_size)
+        return p
+
+    from_str = classmethod(lambda cls, s, block_size, matrix_cls=S.AAMatrix: cls.from_bytes(s.encode(), block_size, matrix_cls))
+
+    def set_bytes(self, b: bytes, block_size: int) -> None:
+        getattr(lib(), f"block_set_bytes_padded_{self._k}")(self._h, bytes(b), len(b), block_size)
+        self._len = len(b)
+
+    def set_bytes_rev(self, b: bytes, block_size: int) -> None:
+        getattr(lib(), f"block_set_bytes_rev_padded_{self._k}")(self._h, bytes(b), len(b), block_size)
+        self._len = len(b)
+
+    def len(self) -> int:
+        return self._len
+
+    __len__ = len
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            getattr(_lib, f"block_free_padded_{self._k}")(self._h)
+            self._h = None
+
+
+class Cigar:
+    """cigar.rs:42-163"""
+
+    def __init__(self, query_len: int, reference_len: int):
+        self._h = lib().block_new_cigar(query_len, reference_len)
+
+    new = classmethod(lambda cls, q, r: cls(q, r))
+
+    def len(self) -> int:
+        return lib().block_len_cigar(self._h)
+
+    __len__ = len
+
+    def get(self, i: int):
+        o = lib().block_get_cigar(self._h, i)
+        return (o.op, o.len)
+
+    def to_vec(self):
+        return [self.get(i) for i in range(self.len())]
+
+    def __str__(self) -> str:
+        return "".join(f"{n}{OP_CHARS[op]}" for op, n in self.to_vec() if op)
+
+    to_string = __str__
+
+    def format(self, q: bytes, r: bytes):
+        a, b, i, j = [], [], 0, 0
+        for op, n in self.to_vec():
+            for _ in range(n):
+                if op in (1, 2, 3):
+                    a.append(chr(q[i])); b.append(chr(r[j])); i += 1; j += 1
+                elif op == 4:
+                    a.append(chr(q[i])); b.append("-"); i += 1
+                elif op == 5:
+                    a.append("-"); b.append(chr(r[j])); j += 1
+        return "".join(a), "".join(b)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.block_free_cigar(self._h)
+            self._h = None
+
+
+class _Trace:
+    def __init__(self, block: "Block"):
+        self._b = block
+
+    def cigar(self, i: int, j: int, cigar: Cigar) -> None:
+        lib().block_cigar_generic(self._b._h, i, j, cigar._h)
+
+    def cigar_eq(self, q: PaddedBytes, r: PaddedBytes, i: int, j: int, cigar: Cigar) -> None:
+        lib().block_cigar_eq_generic(self._b._h, q._h, r._h, i, j, cigar._h)
+
+
+class Block:
+    """Block::<TRACE, X_DROP, LOCAL_START, FREE_QUERY_START_GAPS, FREE_QUERY_END_GAPS> (scan_block.rs:89, 798-1244)."""
+
+    def __init__(self, query_len: int, reference_len: int, max_size: int, trace: bool = False, x_drop: bool = False,
+                 local_start: bool = False, free_query_start_gaps: bool = False, free_query_end_gaps: bool = False):
+        self.mode = (TRACE * trace) | (X_DROP * x_drop) | (LOCAL_START * local_start) | \
+                    (FREE_QUERY_START_GAPS * free_query_start_gaps) | (FREE_QUERY_END_GAPS * free_query_end_gaps)
+        self._h = lib().block_new_generic(self.mode, query_len, reference_len, max_size)
+
+    new = classmethod(lambda cls, *a, **k: cls(*a, **k))
+
+    def align(self, query: PaddedBytes, reference: PaddedBytes, matrix, gaps, size, x_drop: int = 0) -> None:
+        raw = matrix.raw()
+        g = GapsC(gaps.open, gaps.extend) if isinstance(gaps, S.Gaps) else GapsC(gaps[0], gaps[1])
+        lib().block_align_generic(self._h, matrix.KIND, query._h, reference._h, raw.ctypes.data, g, _size(size), x_drop)
+
+    def align_exp(self, query, reference, matrix, gaps, size, x_drop: int, target_score: int):
+        """scan_block.rs:884-902: double the min block size until the score reaches the target."""
+        s = _size(size)
+        mn, mx = max(s.min, 16), max(s.max, 16)
+        while mn <= mx:
+            self.align(query, reference, matrix, gaps, (mn, mx), x_drop)
+            if self.res().score >= target_score:
+                return mn
+            mn *= 2
+        return None
+
+    def res(self) -> AlignResult:
+        r = lib().block_res_generic(self._h)
+        return AlignResult(r.score, r.query_idx, r.reference_idx)
+
+    def trace(self) -> _Trace:
+        assert self.mode & TRACE, "Block was created without TRACE"
+        return _Trace(self)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.block_free_generic(self._h)
+            self._h = None
+
+
+class BatchAligner:
+    """Batch launcher: many independent pairs, one persistent kernel launch, one wavefront per pair.
+
+    pool: uint8 array of raw sequence bytes; pair p = pool[q_off[p]:+q_len[p]] (query) vs pool[r_off[p]:+r_len[p]].
+    """
+
+    def __init__(self, matrix, gaps, size, x_drop: int, mode: int, pool, q_off, q_len, r_off, r_len):
+        L = lib()
+        self.n = len(q_len)
+        self.mode = mode
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64); r_off = np.ascontiguousarray(r_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32); r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+        raw = matrix.raw()
+        g = GapsC(gaps.open, gaps.extend) if isinstance(gaps, S.Gaps) else GapsC(gaps[0], gaps[1])
+        self._h = L.ba_batch_create(matrix.KIND, raw.ctypes.data, g, _size(size), x_drop, mode, pool.ctypes.data,
+                                    q_off.ctypes.data, q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, self.n)
+        if not self._h:
+            raise RuntimeError(last_error())
+
+    def run(self) -> float:
+        """Launch and wait; returns the kernel's HIP-event time in milliseconds."""
+        ms = C.c_float()
+        if lib().ba_batch_run(self._h, C.byref(ms)):
+            raise RuntimeError(last_error())
+        return ms.value
+
+    def results(self):
+        n = self.n
+        out = dict(score=np.zeros(n, np.int32), query_idx=np.zeros(n, np.uint32), reference_idx=np.zeros(n, np.uint32),
+                   cells=np.zeros(n, np.uint64), cigar_len=np.zeros(n, np.uint32), status=np.zeros(n, np.uint32))
+        if lib().ba_batch_results(self._h, *(out[k].ctypes.data for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"))):
+            raise RuntimeError(last_error())
+        return out
+
+    def cigars(self, cigar_len=None):
+        """-> (runs, offsets): runs[offsets[p]:offsets[p+1]] are pair p's packed (len << 4 | op) runs."""
+        if cigar_len is None:
+            cigar_len = self.results()["cigar_len"]
+        off = np.zeros(self.n + 1, np.uint64)
+        np.cumsum(cigar_len, out=off[1:])
+        runs = np.zeros(int(off[-1]), np.uint32)
+        if lib().ba_batch_cigars(self._h, runs.ctypes.data, runs.size):
+            raise RuntimeError(last_error())
+        return runs, off
+
+    def info(self):
+        o = np.zeros(4, np.uint64)
+        lib().ba_batch_info(self._h, o.ctypes.data)
+        return dict(grid=int(o[0]), lds_bytes_per_wave=int(o[1]), trace_arena_bytes=int(o[2]), pool_bytes=int(o[3]))
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.ba_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def runs_to_string(runs) -> str:
+    return "".join(f"{int(x) >> 4}{OP_CHARS[int(x) & 15]}" for x in runs)

@@ -1,0 +1,196 @@
+/*
+ * block_aligner_hip.h — C ABI of the MI355X (gfx950) backend for block-aligner.
+ *
+ * Part 1 is, symbol for symbol, the reference's C API (/root/reference/c/block_aligner.h, generated from
+ * /root/reference/src/ffi.rs): a program written against that header links against libblock_aligner_hip.so
+ * unchanged (see tests/c/example_ref.c, the counterpart of /root/reference/c/example.c). Every alignment is
+ * executed by the HIP kernels in block_aligner_amd/csrc; there is no CPU fallback — if no gfx950 device or
+ * HIP runtime is usable the call aborts with a message, like the reference's panic=abort.
+ *
+ * Part 2 adds what the reference's FFI lacks for the hot path named in BASELINE.json: nucleotide / byte
+ * matrices (ffi.rs:5 "do not have bindings yet") and a batch launcher that aligns many independent pairs in
+ * one kernel launch (one wavefront per pair). A Rust `simd_hip` backend binds exactly these.
+ *
+ * Error behaviour: Part 1 functions keep the reference contract (no error codes; a violated precondition
+ * aborts the process with the reference's assert message). Part 2 functions return 0 on success and a
+ * non-zero code otherwise, with ba_last_error() giving the message.
+ */
+#ifndef BLOCK_ALIGNER_HIP_H
+#define BLOCK_ALIGNER_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Part 1 — the reference C API                                                                           */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* cigar.rs:10-31, c/block_aligner.h:17-57 */
+enum BaOperation { Sentinel = 0, M = 1, Eq = 2, X = 3, I = 4, D = 5 };
+typedef uint8_t Operation;
+
+typedef struct AAMatrix AAMatrix;       /* scores.rs:40-44: 27 x 32 int8, 32-byte aligned, 864 bytes */
+typedef struct NucMatrix NucMatrix;     /* scores.rs:142-146: 8 x 16 int8, 32-byte aligned, 128 bytes */
+typedef struct AAProfile AAProfile;     /* opaque */
+typedef struct Cigar Cigar;             /* opaque */
+typedef struct PaddedBytes PaddedBytes; /* opaque */
+
+typedef struct OpLen { Operation op; uintptr_t len; } OpLen;                                   /* cigar.rs:34-39 */
+typedef void* BlockHandle;                                                                      /* ffi.rs:15 */
+typedef struct Gaps { int8_t open; int8_t extend; } Gaps;                                       /* scores.rs:333-338 */
+typedef struct SizeRange { uintptr_t min; uintptr_t max; } SizeRange;                           /* ffi.rs:18-23 */
+typedef struct AlignResult { int32_t score; uintptr_t query_idx; uintptr_t reference_idx; } AlignResult; /* scan_block.rs:1887-1893 */
+typedef struct ByteMatrix { int8_t match_score; int8_t mismatch_score; } ByteMatrix;           /* scores.rs:220-225 */
+
+/* data symbols (scores.rs:275-311, c/block_aligner.h:140-162); C callers take their address */
+extern const struct NucMatrix NW1;
+extern const struct AAMatrix BLOSUM45, BLOSUM50, BLOSUM62, BLOSUM80, BLOSUM90;
+extern const struct AAMatrix PAM100, PAM120, PAM160, PAM200, PAM250;
+extern const struct ByteMatrix BYTES1;
+
+/* AAMatrix — ffi.rs:31-48 */
+struct AAMatrix* block_new_simple_aamatrix(int8_t match_score, int8_t mismatch_score);
+void block_set_aamatrix(struct AAMatrix* matrix, uint8_t a, uint8_t b, int8_t score);
+void block_free_aamatrix(struct AAMatrix* matrix);
+
+/* AAProfile — ffi.rs:60-195 */
+struct AAProfile* block_new_aaprofile(uintptr_t str_len, uintptr_t block_size, int8_t gap_extend);
+uintptr_t block_len_aaprofile(const struct AAProfile* profile);
+void block_clear_aaprofile(struct AAProfile* profile, uintptr_t str_len, uintptr_t block_size);
+void block_set_aaprofile(struct AAProfile* profile, uintptr_t i, uint8_t b, int8_t score);
+void block_set_all_aaprofile(struct AAProfile* profile, const uint8_t* order, uintptr_t order_len, const int8_t* scores,
+                             uintptr_t scores_len, uintptr_t left_shift, uintptr_t right_shift);
+void block_set_all_rev_aaprofile(struct AAProfile* profile, const uint8_t* order, uintptr_t order_len, const int8_t* scores,
+                                 uintptr_t scores_len, uintptr_t left_shift, uintptr_t right_shift);
+void block_set_gap_open_C_aaprofile(struct AAProfile* profile, uintptr_t i, int8_t gap);
+void block_set_gap_close_C_aaprofile(struct AAProfile* profile, uintptr_t i, int8_t gap);
+void block_set_gap_open_R_aaprofile(struct AAProfile* profile, uintptr_t i, int8_t gap);
+void block_set_all_gap_open_C_aaprofile(struct AAProfile* profile, int8_t gap);
+void block_set_all_gap_close_C_aaprofile(struct AAProfile* profile, int8_t gap);
+void block_set_all_gap_open_R_aaprofile(struct AAProfile* profile, int8_t gap);
+int8_t block_get_aaprofile(const struct AAProfile* profile, uintptr_t i, uint8_t b);
+int8_t block_get_gap_extend_aaprofile(const struct AAProfile* profile);
+void block_free_aaprofile(struct AAProfile* profile);
+
+/* Cigar — ffi.rs:201-225 */
+struct Cigar* block_new_cigar(uintptr_t query_len, uintptr_t reference_len);
+struct OpLen block_get_cigar(const struct Cigar* cigar, uintptr_t i);
+uintptr_t block_len_cigar(const struct Cigar* cigar);
+void block_free_cigar(struct Cigar* cigar);
+
+/* PaddedBytes (amino acids) — ffi.rs:231-257 */
+struct PaddedBytes* block_new_padded_aa(uintptr_t len, uintptr_t max_size);
+void block_set_bytes_padded_aa(struct PaddedBytes* padded, const uint8_t* s, uintptr_t len, uintptr_t max_size);
+void block_set_bytes_rev_padded_aa(struct PaddedBytes* padded, const uint8_t* s, uintptr_t len, uintptr_t max_size);
+void block_free_padded_aa(struct PaddedBytes* padded);
+
+/* Block<TRACE, X_DROP> over AAMatrix / AAProfile — ffi.rs:262-403 (gen_functions! x 4) */
+#define BA_DECLARE_BLOCK_FNS(S, CIG, CIGEQ)                                                                                   \
+    BlockHandle block_new_##S(uintptr_t query_len, uintptr_t reference_len, uintptr_t max_size);                              \
+    void block_align_##S(BlockHandle b, const struct PaddedBytes* q, const struct PaddedBytes* r, const struct AAMatrix* m,   \
+                         struct Gaps g, struct SizeRange s, int32_t x);                                                       \
+    void block_align_profile_##S(BlockHandle b, const struct PaddedBytes* q, const struct AAProfile* r, struct SizeRange s,   \
+                                 int32_t x);                                                                                  \
+    struct AlignResult block_res_##S(BlockHandle b);                                                                          \
+    void CIG(BlockHandle b, uintptr_t query_idx, uintptr_t reference_idx, struct Cigar* cigar);                               \
+    void CIGEQ(BlockHandle b, const struct PaddedBytes* q, const struct PaddedBytes* r, uintptr_t query_idx,                  \
+               uintptr_t reference_idx, struct Cigar* cigar);                                                                 \
+    void block_free_##S(BlockHandle b);
+
+BA_DECLARE_BLOCK_FNS(aa, _block_cigar_aa, _block_cigar_eq_aa)                                   /* ffi.rs:333-349 */
+BA_DECLARE_BLOCK_FNS(aa_xdrop, _block_cigar_aa_xdrop, _block_cigar_eq_aa_xdrop)                 /* ffi.rs:351-367 */
+BA_DECLARE_BLOCK_FNS(aa_trace, block_cigar_aa_trace, block_cigar_eq_aa_trace)                   /* ffi.rs:369-385 */
+BA_DECLARE_BLOCK_FNS(aa_trace_xdrop, block_cigar_aa_trace_xdrop, block_cigar_eq_aa_trace_xdrop) /* ffi.rs:387-403 */
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Part 2 — extensions for the MI355X hot path                                                            */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* thread-local message for the last failing Part 2 call */
+const char* ba_last_error(void);
+/* number of usable HIP devices (0 if the runtime is unusable); ba_set_device selects the one later calls use */
+int ba_device_count(void);
+int ba_set_device(int device);
+/* lib.rs:109-111 */
+uintptr_t block_percent_len(uintptr_t len, float p);
+
+/* Nucleotide / byte matrices and padded strings (the reference has Rust API only: scores.rs:142-273,
+ * scan_block.rs:1798-1822 instantiated with NucMatrix / ByteMatrix). */
+struct NucMatrix* block_new_simple_nucmatrix(int8_t match_score, int8_t mismatch_score);
+void block_set_nucmatrix(struct NucMatrix* matrix, uint8_t a, uint8_t b, int8_t score);
+void block_free_nucmatrix(struct NucMatrix* matrix);
+struct PaddedBytes* block_new_padded_nuc(uintptr_t len, uintptr_t max_size);
+void block_set_bytes_padded_nuc(struct PaddedBytes* padded, const uint8_t* s, uintptr_t len, uintptr_t max_size);
+void block_set_bytes_rev_padded_nuc(struct PaddedBytes* padded, const uint8_t* s, uintptr_t len, uintptr_t max_size);
+void block_free_padded_nuc(struct PaddedBytes* padded);
+struct PaddedBytes* block_new_padded_bytes(uintptr_t len, uintptr_t max_size);
+void block_set_bytes_padded_bytes(struct PaddedBytes* padded, const uint8_t* s, uintptr_t len, uintptr_t max_size);
+void block_free_padded_bytes(struct PaddedBytes* padded);
+
+/* mode bits of Block<TRACE, X_DROP, LOCAL_START, FREE_QUERY_START_GAPS, FREE_QUERY_END_GAPS> (scan_block.rs:89) */
+enum {
+    BA_TRACE = 1u << 0,
+    BA_X_DROP = 1u << 1,
+    BA_LOCAL_START = 1u << 2,
+    BA_FREE_QUERY_START_GAPS = 1u << 3,
+    BA_FREE_QUERY_END_GAPS = 1u << 4,
+    BA_CIGAR_EQ = 1u << 5 /* batch only: emit =/X instead of M (Trace::cigar_eq, scan_block.rs:1478-1480) */
+};
+enum { BA_KIND_AA = 0, BA_KIND_NUC = 1, BA_KIND_BYTES = 2 };
+
+/* Generic per-pair block: Block::<mode>::new / align::<matrix kind> / res / trace().cigar[_eq]
+ * (scan_block.rs:798-805, 847-878, 1235-1244, 1469-1480). `matrix` points at an AAMatrix, NucMatrix or
+ * ByteMatrix according to `kind`; q and r must have been built for the same kind. */
+BlockHandle block_new_generic(uint32_t mode, uintptr_t query_len, uintptr_t reference_len, uintptr_t max_size);
+void block_align_generic(BlockHandle b, int kind, const struct PaddedBytes* q, const struct PaddedBytes* r, const void* matrix,
+                         struct Gaps g, struct SizeRange s, int32_t x);
+struct AlignResult block_res_generic(BlockHandle b);
+void block_cigar_generic(BlockHandle b, uintptr_t query_idx, uintptr_t reference_idx, struct Cigar* cigar);
+void block_cigar_eq_generic(BlockHandle b, const struct PaddedBytes* q, const struct PaddedBytes* r, uintptr_t query_idx,
+                            uintptr_t reference_idx, struct Cigar* cigar);
+void block_free_generic(BlockHandle b);
+
+/* ---- batch launcher: many independent pairs, one persistent kernel launch, one wavefront per pair.
+ *
+ * `pool` holds the raw (unpadded, unconverted) sequence bytes; pair p is query pool[q_off[p] .. +q_len[p]) against
+ * reference pool[r_off[p] .. +r_len[p]). The library builds the PaddedBytes images (scan_block.rs:1798-1812) and keeps
+ * them, the matrix and all scratch resident in device memory for the life of the batch object, so ba_batch_run can
+ * be timed with inputs already in HBM.
+ *
+ * Results per pair: score / query_idx / reference_idx as AlignResult (scan_block.rs:567-592); computed DP cells
+ * (sum over every block-fill call of columns iterated x height: the GCUPS numerator); CIGAR runs when BA_TRACE is set,
+ * each run packed as (len << 4 | Operation), in alignment order. */
+typedef struct BaBatch BaBatch;
+
+BaBatch* ba_batch_create(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,
+                         const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
+                         const uint32_t* r_len, uintptr_t n_pairs);
+/* Launch on the batch's stream and wait. kernel_ms (optional) = HIP-event time of the alignment kernel alone. */
+int ba_batch_run(BaBatch* batch, float* kernel_ms);
+/* Copy results to host arrays of n_pairs elements; any pointer may be NULL. status: 0 = ok, else BA_ST_* bits. */
+int ba_batch_results(BaBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells,
+                     uint32_t* cigar_len, uint32_t* status);
+/* CIGAR runs of all pairs, concatenated in pair order (pair p occupies cigar_len[p] entries after the pairs before it).
+ * `capacity` = number of uint32 entries available in `runs`; fails if too small. */
+int ba_batch_cigars(BaBatch* batch, uint32_t* runs, uint64_t capacity);
+/* Facts about the launch: out[0] grid (resident waves), [1] LDS bytes per wave, [2] trace arena bytes, [3] padded pool bytes */
+int ba_batch_info(BaBatch* batch, uint64_t out[4]);
+void ba_batch_destroy(BaBatch* batch);
+
+enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8 };
+
+/* One-shot convenience over create/run/results/cigars/destroy. */
+int block_batch_align(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,
+                      const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
+                      const uint32_t* r_len, uintptr_t n_pairs, struct AlignResult* results, uint32_t* cigar_runs,
+                      uint64_t cigar_capacity, uint32_t* cigar_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOCK_ALIGNER_HIP_H */

@@ -1,0 +1,74 @@
+"""GPU: the reference's own known answers, driven through the C ABI exactly as the reference's tests drive the
+Rust API (Block::new / align / res / trace().cigar[_eq]); scan_block.rs:1908-2120, lib.rs:8-35."""
+import pytest
+
+from block_aligner_amd import scores as S
+from tests.common import check_expect, kat_matrix
+
+pytestmark = pytest.mark.gpu
+
+MCLS = {"aa": S.AAMatrix, "nuc": S.NucMatrix, "bytes": S.ByteMatrix}
+SUPPORTED = {"trace", "x_drop"}
+
+
+def run_kat(H, k):
+    cls = MCLS[k["kind"]]
+    pad = k["size"][1]
+    q = H.PaddedBytes.from_bytes(k["q"].encode(), pad, cls)
+    r = H.PaddedBytes.from_bytes(k["r"].encode(), pad, cls)
+    mode = set(k["mode"])
+    a = H.Block(k["alloc"][0], k["alloc"][1], k["alloc"][2], trace="trace" in mode, x_drop="x_drop" in mode)
+    a.align(q, r, kat_matrix(k), S.Gaps(*k["gaps"]), tuple(k["size"]), k["x_drop"])
+    res = a.res()
+    out = dict(score=res.score, query_idx=res.query_idx, reference_idx=res.reference_idx)
+    cig = cig_eq = None
+    e = k["expect"]
+    if "cigar" in e or "cigar_eq" in e:
+        c = H.Cigar(res.query_idx, res.reference_idx)
+        if "cigar" in e:
+            a.trace().cigar(res.query_idx, res.reference_idx, c)
+            cig = str(c)
+        if "cigar_eq" in e:
+            a.trace().cigar_eq(q, r, res.query_idx, res.reference_idx, c)
+            cig_eq = str(c)
+    check_expect(k["name"], e, out, cigar=cig, cigar_eq=cig_eq)
+
+
+def test_reference_kats_seq_seq(hip, kats):
+    n = 0
+    for k in kats["align"] + kats["inferred"]:
+        if k["kind"] == "profile" or not set(k["mode"]) <= SUPPORTED:
+            continue
+        run_kat(hip, k)
+        n += 1
+    assert n >= 34
+
+
+def test_c_example_flow(hip):
+    """c/example.c:6-78 (example1 + example2) through the AA-specific entry points of the reference header."""
+    import ctypes as C
+    L = hip.lib()
+    L.block_new_padded_aa.restype = C.c_void_p
+    L.block_new_aa_trace.restype = C.c_void_p
+    L.block_new_aa_trace.argtypes = [C.c_size_t] * 3
+    L.block_align_aa_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, hip.GapsC, hip.SizeRangeC, C.c_int32]
+    L.block_res_aa_trace.restype = hip.AlignResultC
+    L.block_res_aa_trace.argtypes = [C.c_void_p]
+    L.block_cigar_aa_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.block_free_aa_trace.argtypes = [C.c_void_p]
+    a_str, b_str = b"AAAAAAAA", b"AARAAAA"
+    a = L.block_new_padded_aa(len(a_str), 32)
+    b = L.block_new_padded_aa(len(b_str), 32)
+    L.block_set_bytes_padded_aa(a, a_str, len(a_str), 32)
+    L.block_set_bytes_padded_aa(b, b_str, len(b_str), 32)
+    blk = L.block_new_aa_trace(len(a_str), len(b_str), 32)
+    blosum62 = C.c_void_p.in_dll(L, "BLOSUM62")
+    L.block_align_aa_trace(blk, a, b, C.addressof(blosum62), hip.GapsC(-11, -1), hip.SizeRangeC(32, 32), 0)
+    res = L.block_res_aa_trace(blk)
+    assert (res.score, res.query_idx, res.reference_idx) == (12, 8, 7)   # inferred (see golden file)
+    cig = L.block_new_cigar(res.query_idx, res.reference_idx)
+    L.block_cigar_aa_trace(blk, res.query_idx, res.reference_idx, cig)
+    n = L.block_len_cigar(cig)
+    ops = [L.block_get_cigar(cig, i) for i in range(n)]
+    assert sum(o.len for o in ops if o.op in (1, 4)) == 8 and sum(o.len for o in ops if o.op in (1, 5)) == 7
+    L.block_free_cigar(cig); L.block_free_aa_trace(blk); L.block_free_padded_aa(a); L.block_free_padded_aa(b)
