@@ -112,6 +112,7 @@ __device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32
             const Move m = tb_lut(right_blk, nib & 3, nib >> 2, table);
             uint32_t op = m.op;
             if (eq && op == 1) op = q[i] == r[j] ? 2 : 3;
+            if (m.di > i || m.dj > j) { *status |= ST_TRACEBACK_LOST; return 0; }   // would leave the matrix: corrupt trace
             i -= m.di; j -= m.dj; table = m.next;
             if (op == run_op) run_len++;
             else {
@@ -196,7 +197,10 @@ struct Aligner {
         uint32_t i_ckpt = 0, j_ckpt = 0; int off_ckpt = 0;
         int D_corner = 0;
 
+        const uint32_t max_steps = 64u * ((qlen + rlen) / STEP + 64u);   // watchdog: far above any legal run
+        uint32_t steps = 0;
         for (;;) {
+            if (++steps > max_steps) { status |= ST_WATCHDOG; break; }
             prev_off = off;
             Best grow{0, 0, 0}, cur;
             int right_max, down_max;

@@ -182,7 +182,7 @@ int ba_batch_cigars(BaBatch* batch, uint32_t* runs, uint64_t capacity);
 int ba_batch_info(BaBatch* batch, uint64_t out[4]);
 void ba_batch_destroy(BaBatch* batch);
 
-enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8 };
+enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16 };
 
 /* One-shot convenience over create/run/results/cigars/destroy. */
 int block_batch_align(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,
