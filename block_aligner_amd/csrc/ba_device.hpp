@@ -25,6 +25,15 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------ cross-lane helpers (wave64)
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & 63; }
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// Single-lane side effects (global stores, the work-queue atomic) sit inside wave-uniform control flow. The lane id is
+// laundered through an empty asm at every such site: if the compiler can prove two `lane == 0` tests equal it
+// jump-threads one into the other across the persistent loop's back edge, peels lane 0 out of the loop and the
+// other 63 lanes spin on a stale pair index (observed with ROCm 7.2 clang 22 on gfx950).
+__device__ __forceinline__ bool is_lane(int k) {
+    int l = lane_id();
+    asm volatile("" : "+v"(l));
+    return l == k;
+}
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_keep(int old, int src) {
@@ -215,7 +224,7 @@ __device__ __forceinline__ Best place_block(const WaveLds& L, const uint8_t* __r
             }
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-        if (lane == nl - 1) { Dr[j] = d[P - 1].y; Rr[j] = r[P - 1].y; }
+        if (is_lane(nl - 1)) { Dr[j] = d[P - 1].y; Rr[j] = r[P - 1].y; }
         cells += height;
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {

@@ -4,6 +4,14 @@
 #pragma once
 #include "ba_device.hpp"
 
+// development aid: -DBA_DEBUG makes the kernels drop progress markers into host-mapped memory
+#ifdef BA_DEBUG
+extern __device__ volatile uint32_t* g_ba_dbg;
+#define BA_DBG(slot, val) do { if (ba::is_lane(0)) { g_ba_dbg[slot] = (uint32_t)(val); __threadfence_system(); } } while (0)
+#else
+#define BA_DBG(slot, val) do { } while (0)
+#endif
+
 namespace ba {
 
 // ------------------------------------------------------------------ LDS border helpers (whole wave cooperates)
@@ -148,7 +156,7 @@ struct Aligner {
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
         if (nblocks >= bp.blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
         if ((uint64_t)trace_top + (uint64_t)w * h / 8 > bp.trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
-        if (lane_id() == 0) {
+        if (is_lane(0)) {
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
             blocks[nblocks] = br;
@@ -188,6 +196,7 @@ struct Aligner {
         short* temp1 = L.vtab + 16; short* temp2 = L.vtab + 32;
         lds_fill0(temp1, 32);
 
+        BA_DBG(0, 0x100 + pair);
         uint32_t si = 0, sj = 0;
         int best_max = 0; uint32_t best_i = 0, best_j = 0;
         int prev_dir = DIR_GROW, dir = DIR_GROW;
@@ -201,6 +210,7 @@ struct Aligner {
         uint32_t steps = 0;
         for (;;) {
             if (++steps > max_steps) { status |= ST_WATCHDOG; break; }
+            BA_DBG(1, steps); BA_DBG(2, dir); BA_DBG(3, si); BA_DBG(4, sj); BA_DBG(5, block_size);
             prev_off = off;
             Best grow{0, 0, 0}, cur;
             int right_max, down_max;
@@ -246,6 +256,7 @@ struct Aligner {
                 if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
             }
 
+            BA_DBG(6, steps);
             const int this_dir = dir;
             prev_dir = dir;
             const int D_max_max = cur.mx, grow_max = grow.mx;
@@ -310,6 +321,7 @@ struct Aligner {
             else { sj += STEP; dir = DIR_RIGHT; }
         }
 
+        BA_DBG(7, steps);
         int score; uint32_t ri, rj;
         if (XDROP) { score = best_max; ri = best_i; rj = best_j; }
         else {
@@ -318,25 +330,27 @@ struct Aligner {
             else score = off + uni((int)L.D_col[qlen - si]) - ZERO;
             ri = qlen; rj = rlen;
         }
+        BA_DBG(8, score);
         uint32_t ncig = 0;
         if (TRACE && bp.cig_ops && !status) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            if (lane_id() == 0) {
+            if (is_lane(0)) {
                 uint32_t st = 0;
                 ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, bp.flags & F_CIGAR_EQ, bp.cig_ops,
                                  bp.cig_off[pair], bp.cig_off[pair + 1], &st);
                 status |= st;
             }
         }
-        if (lane_id() == 0) {
+        if (is_lane(0)) {
             bp.score[pair] = score; bp.query_idx[pair] = ri; bp.reference_idx[pair] = rj;
             if (bp.cig_len) bp.cig_len[pair] = ncig;
             if (bp.cells) bp.cells[pair] = cells;
             if (bp.status) bp.status[pair] = status;
             if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
         }
+        BA_DBG(9, 77);
     }
 };
 
@@ -373,14 +387,17 @@ __global__ void __launch_bounds__(64) k_align(const BatchParams bp) {
     const uint32_t slot = blockIdx.x;
     for (;;) {
         uint32_t pair = 0;
-        if (lane == 0) pair = atomicAdd(bp.work_counter, 1u);
+        if (is_lane(0)) pair = atomicAdd(bp.work_counter, 1u);
         pair = (uint32_t)uni((int)pair);
+        BA_DBG(10, pair);
         if (pair >= bp.n) break;
         Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L);
         al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
         al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
         al.run(pair);
+        BA_DBG(11, 88);
     }
+    BA_DBG(12, 99);
 }
 
 }  // namespace ba
