@@ -76,14 +76,14 @@ class PairSet:
         return cls(pool, np.array(qo, np.uint64), np.array(ql, np.uint32), np.array(ro, np.uint64), np.array(rl, np.uint32))
 
 
-def make_pairs(n: int, length, k_edits, tail: int, alphabet: np.ndarray = DNA, seed: int = 1234,
-               indels: int = 0, indel_len=(20, 100)) -> PairSet:
-    """n pairs: reference = random(length), query = mutate(reference, k_edits) [+ `indels` long insert/delete
-    events of length U[indel_len] to exercise block growth], both + random(tail).
-    `length` and `k_edits` may be ints or (lo, hi) ranges drawn uniformly per pair."""
+CHUNK = 1024   # pairs per independently seeded chunk (seed = base seed + chunk index), so results do not depend on workers
+
+
+def _make_chunk(args):
+    n, length, k_edits, tail, alphabet, seed, indels, indel_len = args
     rng = np.random.default_rng(seed)
-    pairs = []
-    for _ in range(n):
+    seqs, lens = [], np.zeros((n, 2), np.uint32)
+    for p in range(n):
         L = int(rng.integers(length[0], length[1] + 1)) if isinstance(length, tuple) else int(length)
         k = int(rng.integers(k_edits[0], k_edits[1] + 1)) if isinstance(k_edits, tuple) else int(k_edits)
         ref = rand_str(rng, L, alphabet)
@@ -92,18 +92,35 @@ def make_pairs(n: int, length, k_edits, tail: int, alphabet: np.ndarray = DNA, s
             if len(qry) < 2:
                 break
             ln = int(rng.integers(indel_len[0], indel_len[1] + 1))
-            p = int(rng.integers(0, len(qry)))
+            pos = int(rng.integers(0, len(qry)))
             if rng.integers(0, 2):
-                qry = np.concatenate([qry[:p], rand_str(rng, ln, alphabet), qry[p:]])
+                qry = np.concatenate([qry[:pos], rand_str(rng, ln, alphabet), qry[pos:]])
             else:
-                qry = np.concatenate([qry[:p], qry[p + ln:]])
+                qry = np.concatenate([qry[:pos], qry[pos + ln:]])
         ref = np.concatenate([ref, rand_str(rng, tail, alphabet)])
         qry = np.concatenate([qry, rand_str(rng, tail, alphabet)])
-        pairs.append((qry, ref))
-    chunks, qo, ql, ro, rl, off = [], np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.uint32), 0
-    for p, (q, r) in enumerate(pairs):
-        qo[p] = off; ql[p] = len(q); off += len(q)
-        ro[p] = off; rl[p] = len(r); off += len(r)
-        chunks.append(q); chunks.append(r)
-    chunks.append(np.zeros(8, np.uint8))
-    return PairSet(np.concatenate(chunks), qo, ql, ro, rl)
+        lens[p] = (len(qry), len(ref))
+        seqs.append(qry); seqs.append(ref)
+    return (np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)), lens
+
+
+def make_pairs(n: int, length, k_edits, tail: int, alphabet: np.ndarray = DNA, seed: int = 1234,
+               indels: int = 0, indel_len=(20, 100), workers: int = 1) -> PairSet:
+    """n pairs: reference = random(length), query = mutate(reference, k_edits) [+ `indels` long insert/delete
+    events of length U[indel_len] to exercise block growth], both + random(tail).
+    `length` and `k_edits` may be ints or (lo, hi) ranges drawn uniformly per pair.
+    workers > 1 generates chunks in forked processes (call before any GPU initialisation)."""
+    jobs = [(min(CHUNK, n - s), length, k_edits, tail, alphabet, seed + c, indels, indel_len)
+            for c, s in enumerate(range(0, n, CHUNK))]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.map(_make_chunk, jobs)
+    else:
+        parts = [_make_chunk(j) for j in jobs]
+    lens = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, 2), np.uint32)
+    pool_arr = np.concatenate([p[0] for p in parts] + [np.zeros(8, np.uint8)])
+    flat = lens.astype(np.uint64).reshape(-1)
+    offs = np.zeros(flat.size, np.uint64)
+    np.cumsum(flat[:-1], out=offs[1:])
+    return PairSet(pool_arr, offs[0::2].copy(), lens[:, 0].copy(), offs[1::2].copy(), lens[:, 1].copy())
