@@ -57,11 +57,12 @@ def main():
 
     import numpy as np
     from block_aligner_amd import scores as S, synth
+    from block_aligner_amd.shard import reduce_job, shard_seed
 
     # ---- synthetic workload (forked workers: must happen before any GPU initialisation)
     t0 = time.time()
     workers = a.gen_workers or min(32, max(1, (os.cpu_count() or 8) // max(1, world)))
-    pairs = synth.make_pairs(a.pairs, a.len, a.edits, a.tail, synth.DNA, seed=1234 + 100003 * rank, workers=workers)
+    pairs = synth.make_pairs(a.pairs, a.len, a.edits, a.tail, synth.DNA, seed=shard_seed(1234, rank), workers=workers)
     t_gen = time.time() - t0
 
     import torch
@@ -100,19 +101,11 @@ def main():
         kernel_ms.append(batch.run())          # launches on the library's stream and waits for it
     sync_all()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
     res = batch.results()
     if res["status"].any():
         raise RuntimeError(f"rank {rank}: {int((res['status'] != 0).sum())} pairs failed on the device")
     cells_rank = int(res["cells"].sum())
-    tot = torch.tensor([cells_rank], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    cells_total = float(tot.item())
+    elapsed, cells_total = reduce_job(elapsed, float(cells_rank), device="cuda")
 
     out = None
     if rank == 0:
