@@ -1,16 +1,15 @@
 // block_aligner_amd — device side of the adaptive block aligner for gfx950 (CDNA4, wave64).
 //
-// One wavefront aligns one sequence pair. The block's vector axis (rows for a right shift, columns for a
-// down shift) is spread over the 64 lanes, K consecutive cells per lane held as K/2 packed 2 x i16 VGPRs
-// (v_pk_add_i16 clamp / v_pk_max_i16). The four block borders and their checkpoint copies live in LDS;
-// the 32-bit block offset and all driver state are wave-uniform (SGPRs). The in-column gap recurrence is a
-// max-plus prefix scan: lane-local serial scan + a 6-step DPP prefix-max over lanes on 32-bit re-based values.
+// One wavefront aligns one sequence pair. A rectangle of the DP matrix is filled column by column; the column (the
+// "vector axis": rows for a right shift, columns for a down shift) is cut into chunks of 128 cells, and inside a chunk
+// lane l owns cells 2l and 2l+1 as one packed 2 x i16 VGPR (v_pk_add_i16 clamp / v_pk_max_i16). Chunks of a column are
+// processed top to bottom, each with a 64-lane max-plus prefix scan built from six DPP-fused v_max_i32 on 32-bit
+// values re-based by lane * 2g; the carry between chunks is a wave-uniform scalar. The four block borders live in
+// LDS, the 32-bit block offset and all driver state are wave-uniform (SGPRs).
 //
 // Semantics follow the reference's AVX2 (L = 16) backend bit for bit:
-//   driver        /root/reference/src/scan_block.rs:94-595
 //   block fill    /root/reference/src/scan_block.rs:1083-1228 (+ avx2.rs:297-338 scan incl. its zero-shift-in quirk)
 //   border moves  /root/reference/src/scan_block.rs:1003-1061
-//   trace/CIGAR   /root/reference/src/scan_block.rs:1344-1672
 // The trace encoding, LDS layout and work distribution are this implementation's own.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -42,14 +41,19 @@ __device__ __forceinline__ int dpp_keep(int old, int src) {
 // lane l <- lane l-1; lane 0 <- fill
 __device__ __forceinline__ int wave_shr1(int src, int fill) { return dpp_keep<0x138, 0xf>(fill, src); }
 
-// inclusive prefix max over the 64 lanes (row_shr 1/2/4/8, row_bcast:15, row_bcast:31)
+// inclusive prefix max over the 64 lanes: row_shr 1/2/4/8 inside rows of 16, then row_bcast:15 / row_bcast:31.
+// The DPP control is fused into v_max_i32 (lanes without a valid source keep their value); a DPP read needs two wait
+// states after the VALU write of its source, and hipcc does not pad inside an asm statement, hence the s_nop 1.
 __device__ __forceinline__ int wave_prefix_max(int v) {
-    v = max(v, dpp_keep<0x111, 0xf>(v, v));
-    v = max(v, dpp_keep<0x112, 0xf>(v, v));
-    v = max(v, dpp_keep<0x114, 0xf>(v, v));
-    v = max(v, dpp_keep<0x118, 0xf>(v, v));
-    v = max(v, dpp_keep<0x142, 0xa>(v, v));
-    v = max(v, dpp_keep<0x143, 0xc>(v, v));
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_prefix_max(v), 63); }
@@ -57,179 +61,196 @@ __device__ __forceinline__ int wave_min(int v) { return -wave_max(-v); }
 
 __device__ __forceinline__ s16x2 as_s(int x) { return __builtin_bit_cast(s16x2, x); }
 __device__ __forceinline__ int as_i(s16x2 x) { return __builtin_bit_cast(int, x); }
-__device__ __forceinline__ u16x2 as_u(s16x2 x) { return __builtin_bit_cast(u16x2, x); }
-__device__ __forceinline__ s16x2 splat(int v) { return s16x2{(short)v, (short)v}; }
-__device__ __forceinline__ s16x2 adds(s16x2 a, s16x2 b) { return __builtin_elementwise_add_sat(a, b); }
-__device__ __forceinline__ s16x2 subs(s16x2 a, s16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
-__device__ __forceinline__ s16x2 vmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
-// 1 where the 16-bit halves differ, 0 where equal
-__device__ __forceinline__ u16x2 neq01(s16x2 a, s16x2 b) {
-    return __builtin_elementwise_min((u16x2)(as_u(a) - as_u(b)), u16x2{1, 1});
+__device__ __forceinline__ int pk(int lo, int hi) { return (lo & 0xffff) | (int)((uint32_t)hi << 16); }
+__device__ __forceinline__ int splat(int v) { return pk(v, v); }
+__device__ __forceinline__ int adds(int a, int b) { return as_i(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }
+__device__ __forceinline__ int subs(int a, int b) { return as_i(__builtin_elementwise_sub_sat(as_s(a), as_s(b))); }
+__device__ __forceinline__ int vmax(int a, int b) { return as_i(__builtin_elementwise_max(as_s(a), as_s(b))); }
+__device__ __forceinline__ int vmaxu(int a, int b) {
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// per 16-bit half: 1 where a != b, else 0. Forced to two packed ops (sub, unsigned min with 1): left to itself the
+// compiler canonicalises umin(a - b, 1) into compare/select/permute sequences that cost five issue slots.
+__device__ __forceinline__ int neq01(int a, int b, int ones) {
+    int t;
+    asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(t) : "v"(a), "v"(b), "s"(ones));
+    return t;
+}
+// per half: a * m + c (mod 2^16), m wave-uniform
+__device__ __forceinline__ int pk_mad(int a, int m, int c) {
+    int t;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(t) : "v"(a), "s"(m), "v"(c));
+    return t;
 }
 __device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
 
-// ------------------------------------------------------------------ per-wave LDS image
+// ------------------------------------------------------------------ LDS image
 struct WaveLds {
-    short* D_col; short* C_col; short* D_row; short* R_row;
-    short* D_col_ck; short* C_col_ck; short* D_row_ck; short* R_row_ck;
-    short* vtab;          // 16 scan artefact constants (avx2.rs:315-338)
-    const int8_t* mat;    // scoring table copy
+    short* D_col; short* C_col; short* D_row; short* R_row;   // per wave
+    short* misc;          // per wave: 16 scan artefact constants, temp1[16], temp2[16]
+    const char* table;    // per workgroup: NUC packed-pair score table (8 KB) / AA 27x32 bytes / BYTES {match, mismatch}
 };
-__host__ __device__ inline uint32_t lds_array_bytes(uint32_t max_size) { return max_size * 2 + 32; }
-__host__ __device__ inline uint32_t lds_wave_bytes(uint32_t max_size) { return 8 * lds_array_bytes(max_size) + 128 + 896; }
-
 struct Best { int mx; int row; int col; };   // rect max (i16 value) and, for X-drop, its resolved location
 
-// ------------------------------------------------------------------ block fill
-// Fills a width x height rectangle column by column; lanes own K = 2P consecutive cells of the vector axis.
-// seqV runs along the vector axis, seqC supplies one byte per column (scan_block.rs:1083-1228; for a down
-// shift the caller swaps the sequences exactly as the reference does).
-template <int P, int KIND, bool TRACE, bool XDROP>
-__device__ __forceinline__ Best place_block(const WaveLds& L, const uint8_t* __restrict__ seqV, const uint8_t* __restrict__ seqC,
-                            uint32_t lenV, uint32_t lenC, uint32_t start_i, uint32_t start_j, uint32_t width, uint32_t height,
-                            short* Dc, short* Cc, short* Dr, short* Rr, int corner, int rel_zero, int off_add,
-                            int gap_open, int gap_extend, uint32_t* __restrict__ trace_out, unsigned long long& cells) {
-    constexpr int K = 2 * P;
-    const int lane = lane_id();
-    const int nl = (int)(height / K);          // active lanes (64 when height >= 128)
-    const bool active = lane < nl;
-    const int r0 = lane * K;
-    Best res{0, 0, 0};                          // MIN = 0 (avx2.rs:16)
-    if (width == 0 || height == 0) return res;
+// loop-invariant per-lane / per-kernel values
+struct FillConsts {
+    int go2, ge2, ome2;       // splat(gap_open), splat(gap_extend), splat(open (-) extend)
+    int g12;                  // {g, 2g}
+    int ones;                 // 0x00010001
+    int laneKG, lanem1KG;     // lane * 2g, (lane - 1) * 2g
+    int vconst;               // scan artefact constants of this lane's two cells (avx2.rs:315-338)
+    int gap_extend;
+};
 
-    const s16x2 go2 = splat(gap_open), ge2 = splat(gap_extend), ome2 = subs(splat(gap_open), splat(gap_extend));
-    const s16x2 offa = splat(off_add);
+// per-chunk substitution-score lookup state, set up once per rectangle from the chunk's two vector-axis bytes
+template <int KIND> struct ScoreKey;
+template <> struct ScoreKey<KIND_NUC> { int off; };          // byte offset of the (a, b) pair inside one 1 KB table row
+template <> struct ScoreKey<KIND_AA> { int a, b; };          // column indices (0..31)
+template <> struct ScoreKey<KIND_BYTES> { int a, b; };       // raw bytes
+
+template <int KIND>
+__device__ __forceinline__ ScoreKey<KIND> make_key(int a, int b) {
+    ScoreKey<KIND> k;
+    if constexpr (KIND == KIND_NUC) k.off = (((a & 15) << 4) | (b & 15)) << 2;
+    else if constexpr (KIND == KIND_AA) { k.a = a & 31; k.b = b & 31; }
+    else { k.a = a; k.b = b; }
+    return k;
+}
+// packed {score(cb, a), score(cb, b)} for column byte cb (scores.rs:121-127, 204-209, 263-267)
+template <int KIND>
+__device__ __forceinline__ int fetch_score(const char* table, const ScoreKey<KIND>& k, int cb) {
+    if constexpr (KIND == KIND_NUC) return *(const int*)(table + ((cb & 7) << 10) + k.off);
+    else if constexpr (KIND == KIND_AA) {
+        const signed char* row = (const signed char*)table + cb * 32;
+        return pk(row[k.a], row[k.b]);
+    } else {
+        const signed char* t = (const signed char*)table;
+        return pk(k.a == cb ? t[0] : t[1], k.b == cb ? t[0] : t[1]);
+    }
+}
+
+// ------------------------------------------------------------------ block fill
+// Fills a width x height rectangle column by column (scan_block.rs:1083-1228; for a down shift the caller swaps the
+// sequences exactly as the reference does). NCH = chunks of 128 cells per column; below 128 cells NCH = 1 and only
+// height / 2 lanes are active. width is a multiple of 8.
+template <int NCH, int KIND, bool TRACE, bool XDROP>
+__device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
+                                           const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
+                                           uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
+                                           short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out,
+                                           unsigned long long& cells) {
+    const int lane = lane_id();
+    const int nl = NCH > 1 ? 64 : (int)(height >> 1);   // active lanes
+    const bool active = lane < nl;
+    Best res{0, 0, 0};                                   // MIN = 0 (avx2.rs:16)
+    if (width == 0 || height == 0) return res;
 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    s16x2 d[P], c[P], dmax[P], vconst[P];
-    u16x2 jlast[P];
-    int qidx[K];
+    int d[NCH], c[NCH], dmax[NCH], jlast[NCH], tacc[NCH];
+    ScoreKey<KIND> key[NCH];
+    const int offa = splat(off_add);
 #pragma unroll
-    for (int p = 0; p < P; p++) {
-        int dv = 0, cv = 0;
-        if (active) { dv = *(const int*)(Dc + r0 + 2 * p); cv = *(const int*)(Cc + r0 + 2 * p); }
-        d[p] = adds(as_s(dv), offa);            // just_offset folded into the load (scan_block.rs:1003-1012)
-        c[p] = adds(as_s(cv), offa);
-        dmax[p] = splat(0);
-        jlast[p] = u16x2{0, 0};
-        vconst[p] = as_s(*(const int*)(L.vtab + ((r0 + 2 * p) & 15)));
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            int b = active ? (int)seqV[start_i + r0 + 2 * p + h] : 0;
-            qidx[2 * p + h] = KIND == KIND_NUC ? (b & 15) : (KIND == KIND_AA ? (b & 31) : b);
+    for (int ch = 0; ch < NCH; ch++) {
+        const int r0 = ch * 128 + 2 * lane;
+        int dv = 0, cv = 0, a = 0, b = 0;
+        if (active) {
+            dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0);
+            a = seqV[start_i + r0]; b = seqV[start_i + r0 + 1];
         }
+        d[ch] = adds(dv, offa);                 // just_offset folded into the load (scan_block.rs:1003-1012)
+        c[ch] = adds(cv, offa);
+        dmax[ch] = 0; jlast[ch] = 0; tacc[ch] = 0;
+        key[ch] = make_key<KIND>(a, b);
     }
-    const int KG = K * gap_extend;
     const bool break_armed = !XDROP && (start_i + height > lenV);
-    uint32_t tacc[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) tacc[p] = 0;
+    const int NEG = -(1 << 29);
     int corner_cur = corner;
+    int cvec = (int)seqC[start_j + (lane & 7)];       // 8 column bytes at a time, one per lane (lanes 0..7)
+    int sc_next[NCH];
+    {
+        const int cb0 = __builtin_amdgcn_readlane(cvec, 0);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) sc_next[ch] = fetch_score<KIND>(L.table, key[ch], cb0);
+    }
     uint32_t j = 0;
-    int cvec = 0;   // the next 8 column bytes, one per lane (lanes 0..7), fetched once per 8 columns
     for (; j < width; j++) {
-        if ((j & 7) == 0) cvec = (int)seqC[start_j + j + (lane & 7)];
-        const int cb = __builtin_amdgcn_readlane(cvec, (int)(j & 7));
-        // ---- substitution scores for this column
-        s16x2 sc[P];
+        int sc[NCH];
 #pragma unroll
-        for (int p = 0; p < P; p++) {
-            int s0, s1;
-            if (KIND == KIND_NUC) { const int8_t* row = L.mat + (cb & 7) * 16; s0 = row[qidx[2 * p]]; s1 = row[qidx[2 * p + 1]]; }
-            else if (KIND == KIND_AA) { const int8_t* row = L.mat + cb * 32; s0 = row[qidx[2 * p]]; s1 = row[qidx[2 * p + 1]]; }
-            else { s0 = qidx[2 * p] == cb ? L.mat[0] : L.mat[1]; s1 = qidx[2 * p + 1] == cb ? L.mat[0] : L.mat[1]; }
-            sc[p] = s16x2{(short)s0, (short)s1};
-        }
-        // ---- D00: the previous column shifted down by one cell; lane 0 takes the corner (MIN after column 0)
-        const int prev_last = wave_shr1(as_i(d[P - 1]), (int)((uint32_t)corner_cur << 16));
-        corner_cur = 0;
-        s16x2 x[P], cnew[P], copen[P], dpart[P];
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const int below = p == 0 ? prev_last : as_i(d[p - 1]);
-            const s16x2 d00 = as_s(__builtin_amdgcn_alignbit(as_i(d[p]), below, 16));
-            s16x2 d11 = adds(d00, sc[p]);
-            if (p == 0 && start_i == 0 && start_j + j == 0 && lane == 0) d11.x = (short)rel_zero;   // cell (0,0), scan_block.rs:1130-1132
-            copen[p] = adds(d[p], go2);
-            cnew[p] = vmax(adds(c[p], ge2), copen[p]);
-            d11 = vmax(d11, cnew[p]);
-            dpart[p] = d11;
-            x[p] = adds(d11, ome2);             // D11_open
-        }
-        // ---- R11: max-plus scan down the column. lane-local serial part:
-        s16x2 r[P];
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const s16x2 t2 = adds(x[p], ge2);
-            s16x2 m1 = vmax(x[p], s16x2{t2.x, t2.x});
-            if (p > 0) {
-                const s16x2 up = s16x2{r[p - 1].y, r[p - 1].y};
-                m1 = vmax(m1, adds(up, s16x2{(short)gap_extend, (short)(2 * gap_extend)}));
-            }
-            r[p] = m1;
-        }
-        // cross-lane part on 32-bit values re-based by lane * K * g, so the distance term becomes a plain max
+        for (int ch = 0; ch < NCH; ch++) sc[ch] = sc_next[ch];
+        // scores of the next column are fetched while this one is computed
+        if (((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
         {
-            const int A = (int)r[P - 1].y;
-            const int pm = wave_prefix_max(A - lane * KG);
-            const int pmx = wave_shr1(pm, -(1 << 29));
-            int cin = max(lane * KG, (lane - 1) * KG + pmx);   // lane*KG = the MIN (0) carry above row 0 of the column
-            cin = max(cin, -32768);
-            const s16x2 cin2 = splat(cin);
+            const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
 #pragma unroll
-            for (int p = 0; p < P; p++) {
-                const s16x2 t = adds(cin2, s16x2{(short)((2 * p + 1) * gap_extend), (short)((2 * p + 2) * gap_extend)});
-                r[p] = vmax(vmax(r[p], t), vconst[p]);
-            }
+            for (int ch = 0; ch < NCH; ch++) sc_next[ch] = fetch_score<KIND>(L.table, key[ch], cbn);
         }
-        // ---- finish D11, bookkeeping
-        uint32_t tnib[P];
-        int prev_neqR = 0;
-        if (TRACE) prev_neqR = wave_shr1(as_i(__builtin_bit_cast(s16x2, neq01(r[P - 1], x[P - 1]))), 1 << 16);
+        const bool first_cell = start_i == 0 && start_j + j == 0;
+        int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
+        corner_cur = 0;
+        int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
+        int up_nr = 1 << 16;                             // "R not opened" above the chunk
+        const int jj = splat((int)j), njj = splat(-(int)j);
+        int r_last = 0;
 #pragma unroll
-        for (int p = 0; p < P; p++) {
-            const s16x2 d11 = vmax(dpart[p], r[p]);
+        for (int ch = 0; ch < NCH; ch++) {
+            // D00: previous column shifted down one cell (scan_block.rs:1125)
+            const int prev = wave_shr1(d[ch], up_d);
+            if (NCH > 1) up_d = __builtin_amdgcn_readlane(d[ch], 63);
+            const int d00 = __builtin_amdgcn_alignbit(d[ch], prev, 16);
+            int d11 = adds(d00, sc[ch]);
+            if (ch == 0 && first_cell && lane == 0) d11 = pk(rel_zero, d11 >> 16);   // cell (0,0), scan_block.rs:1130-1132
+            const int copen = adds(d[ch], fc.go2);
+            const int cn = vmax(adds(c[ch], fc.ge2), copen);
+            d11 = vmax(d11, cn);
+            const int x = adds(d11, fc.ome2);                                         // D11_open
+            // R11: in-lane step, then the 64-lane scan on values re-based by lane * 2g
+            const s16x2 t2 = as_s(adds(x, fc.ge2));
+            int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
+            const int A = (int)as_s(r).y - fc.laneKG;
+            const int pm = wave_prefix_max(A);
+            const int pmx = wave_shr1(pm, NEG);
+            // lane*2g (+ carry) = what the cell above the chunk contributes: MIN = 0 at the top of the column
+            int cin = max(max(pmx + fc.lanem1KG, fc.laneKG + carry_r), -32768);
+            const s16x2 cs = as_s(cin);
+            r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst);
+            if (NCH > 1) carry_r = (int)(short)(__builtin_amdgcn_readlane(r, 63) >> 16);
+            const int dn = vmax(d11, r);
             if (TRACE) {
-                const u16x2 nC = neq01(d11, cnew[p]);
-                const u16x2 nR = neq01(d11, r[p]);
-                const u16x2 nCo = neq01(cnew[p], copen[p]);
-                const u16x2 nRo = neq01(r[p], x[p]);
-                // "R opened" flag belongs to the cell below it (scan_block.rs:1179-1182): shift down by one cell
-                const u16x2 nRs = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(__builtin_bit_cast(int, nRo), prev_neqR, 16));
-                prev_neqR = __builtin_bit_cast(int, nRo);
-                const u16x2 nib = nC + nR * (u16x2){2, 2} + nCo * (u16x2){4, 4} + nRs * (u16x2){8, 8};
-                tnib[p] = __builtin_bit_cast(uint32_t, nib);
+                const int nC = neq01(dn, cn, fc.ones), nR = neq01(dn, r, fc.ones);
+                const int nCo = neq01(cn, copen, fc.ones), nRo = neq01(r, x, fc.ones);
+                // "R opened" belongs to the cell below it (scan_block.rs:1179-1182)
+                const int pn = wave_shr1(nRo, up_nr);
+                if (NCH > 1) up_nr = __builtin_amdgcn_readlane(nRo, 63);
+                const int nRs = __builtin_amdgcn_alignbit(nRo, pn, 16);
+                int nib = pk_mad(nR, 0x00020002, nC);
+                nib = pk_mad(nCo, 0x00040004, nib);
+                nib = pk_mad(nRs, 0x00080008, nib);
+                tacc[ch] |= nib << ((j & 3) * 4);
             }
-            dmax[p] = vmax(dmax[p], d11);
+            dmax[ch] = vmax(dmax[ch], dn);
             if (XDROP) {
-                const u16x2 ne = neq01(dmax[p], d11);
-                const u16x2 jj = u16x2{(unsigned short)j, (unsigned short)j};
-                jlast[p] = (u16x2)(jlast[p] - jj) * ne + jj;
+                const int ne = neq01(dmax[ch], dn, fc.ones);
+                jlast[ch] = vmaxu(jlast[ch], pk_mad(ne, njj, jj));   // j where this cell ties or raises its row's max, else 0
             }
-            d[p] = d11;
-            c[p] = cnew[p];
+            d[ch] = dn; c[ch] = cn;
+            if (ch == NCH - 1) r_last = r;
         }
-        if (TRACE) {
-            const uint32_t sh = (j & 3) * 4;
+        if (TRACE && (j & 3) == 3) {
+            if (active) {
 #pragma unroll
-            for (int p = 0; p < P; p++) tacc[p] |= tnib[p] << sh;
-            if ((j & 3) == 3) {
-                if (active) {
-#pragma unroll
-                    for (int p = 0; p < P; p++) trace_out[((j >> 2) * P + p) * nl + lane] = tacc[p];
-                }
-#pragma unroll
-                for (int p = 0; p < P; p++) tacc[p] = 0;
+                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCH + ch) * nl + lane] = (uint32_t)tacc[ch];
             }
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) tacc[ch] = 0;
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-        if (is_lane(nl - 1)) { Dr[j] = d[P - 1].y; Rr[j] = r[P - 1].y; }
+        if (is_lane(nl - 1)) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
         cells += height;
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {
 #pragma unroll
-                for (int p = 0; p < P; p++) trace_out[((j >> 2) * P + p) * nl + lane] = tacc[p];
+                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCH + ch) * nl + lane] = (uint32_t)tacc[ch];
             }
             break;
         }
@@ -237,7 +258,7 @@ __device__ __forceinline__ Best place_block(const WaveLds& L, const uint8_t* __r
     // ---- write the vector-axis border back
     if (active) {
 #pragma unroll
-        for (int p = 0; p < P; p++) { *(int*)(Dc + r0 + 2 * p) = as_i(d[p]); *(int*)(Cc + r0 + 2 * p) = as_i(c[p]); }
+        for (int ch = 0; ch < NCH; ch++) { *(int*)(Dc + ch * 128 + 2 * lane) = d[ch]; *(int*)(Cc + ch * 128 + 2 * lane) = c[ch]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -245,26 +266,26 @@ __device__ __forceinline__ Best place_block(const WaveLds& L, const uint8_t* __r
     // largest column, then largest row (avx2.rs:271-274 + scan_block.rs:1198-1200 last-writer-wins per lane)
     int lm = -32768;
 #pragma unroll
-    for (int p = 0; p < P; p++) lm = max(lm, max((int)dmax[p].x, (int)dmax[p].y));
+    for (int ch = 0; ch < NCH; ch++) lm = max(lm, max((int)as_s(dmax[ch]).x, (int)as_s(dmax[ch]).y));
     if (!active) lm = -32768;
     const int M = wave_max(lm);
     res.mx = M;
     if (XDROP) {
-        int key = 0x7fffffff;
+        int kmin = 0x7fffffff;
 #pragma unroll
-        for (int p = 0; p < P; p++) {
+        for (int ch = 0; ch < NCH; ch++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int v = h ? (int)dmax[p].y : (int)dmax[p].x;
-                const int jl = h ? (int)jlast[p].y : (int)jlast[p].x;
-                const int row = r0 + 2 * p + h;
+                const int v = h ? (int)as_s(dmax[ch]).y : (int)as_s(dmax[ch]).x;
+                const int jl = h ? (jlast[ch] >> 16) & 0xffff : jlast[ch] & 0xffff;
+                const int row = ch * 128 + 2 * lane + h;
                 const int k = ((row & 15) << 24) | ((4095 - jl) << 12) | (4095 - row);
-                if (active && v == M) key = min(key, k);
+                if (active && v == M) kmin = min(kmin, k);
             }
         }
-        key = wave_min(key);
-        res.col = 4095 - ((key >> 12) & 4095);
-        res.row = 4095 - (key & 4095);
+        kmin = wave_min(kmin);
+        res.col = 4095 - ((kmin >> 12) & 4095);
+        res.row = 4095 - (kmin & 4095);
     }
     return res;
 }

@@ -7,7 +7,7 @@
 // development aid: -DBA_DEBUG makes the kernels drop progress markers into host-mapped memory
 #ifdef BA_DEBUG
 extern __device__ volatile uint32_t* g_ba_dbg;
-#define BA_DBG(slot, val) do { if (ba::is_lane(0)) { g_ba_dbg[slot] = (uint32_t)(val); __threadfence_system(); } } while (0)
+#define __threadfence_system(); } } while (0)
 #else
 #define BA_DBG(slot, val) do { } while (0)
 #endif
@@ -39,7 +39,7 @@ __device__ __forceinline__ void lds_copy(short* dst, const short* src, uint32_t 
 __device__ __forceinline__ int lds_prefix_max8(const short* a) {
     lds_sync();
     const int* p = (const int*)a;
-    s16x2 m = vmax(vmax(as_s(p[0]), as_s(p[1])), vmax(as_s(p[2]), as_s(p[3])));
+    const s16x2 m = as_s(vmax(vmax(p[0], p[1]), vmax(p[2], p[3])));
     return uni(max((int)m.x, (int)m.y));
 }
 // max of the last 2 entries (scan_block.rs:1030-1032, SHRINK_SUFFIX_LEN = 2)
@@ -51,17 +51,17 @@ __device__ __forceinline__ int lds_suffix_max2(const short* a, uint32_t n) {
 // buf[k] = buf[k+8] (+) off_add for k < n-8, buf[n-8..n) = temp[0..8); returns buf_old[7] (+) off_add
 // (scan_block.rs:1040-1061)
 __device__ __forceinline__ int lds_shift_and_offset(uint32_t n, short* b1, short* b2, const short* t1, const short* t2, int off_add) {
-    const s16x2 oa = splat(off_add);
+    const int oa = splat(off_add);
     lds_sync();
-    const int corner = uni((int)adds(splat((int)b1[STEP - 1]), oa).x);
+    const int corner = uni((int)as_s(adds(splat((int)b1[STEP - 1]), oa)).x);
     for (uint32_t base = 0; base < n; base += 128) {
         const uint32_t k = base + 2 * lane_id();
         int v1 = 0, v2 = 0;
         const bool in = k < n;
         if (in) {
             if (k + STEP < n) {
-                v1 = as_i(adds(as_s(*(const int*)(b1 + k + STEP)), oa));
-                v2 = as_i(adds(as_s(*(const int*)(b2 + k + STEP)), oa));
+                v1 = adds(*(const int*)(b1 + k + STEP), oa);
+                v2 = adds(*(const int*)(b2 + k + STEP), oa);
             } else {
                 v1 = *(const int*)(t1 + (k + STEP - n));
                 v2 = *(const int*)(t2 + (k + STEP - n));
@@ -110,13 +110,13 @@ __device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32
         const bool right_blk = br.trace_base >> 31;
         const uint32_t tbase = br.trace_base & 0x7fffffffu;
         const uint32_t Hv = right_blk ? br.h : br.w;          // cells along the vector axis
-        const uint32_t K = Hv >= 128 ? Hv / 64 : 2, P = K / 2, nl = Hv / K;
+        const uint32_t nch = Hv > 128 ? Hv / 128 : 1, nl = Hv > 128 ? 64 : Hv / 2;   // chunks of 128 cells, lanes per chunk
         while (i >= br.i && j >= br.j && (i > 0 || j > 0)) {
             const uint32_t ci = i - br.i, cj = j - br.j;
             const uint32_t v = right_blk ? ci : cj, w = right_blk ? cj : ci;
-            const uint32_t lane = v / K, tt = v % K;
-            const uint32_t word = trace[tbase + ((w >> 2) * P + (tt >> 1)) * nl + lane];
-            const uint32_t nib = ~(word >> ((tt & 1) * 16 + (w & 3) * 4)) & 15u;   // stored as "differs" bits
+            const uint32_t chunk = v >> 7, lane = (v & 127) >> 1;
+            const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
+            const uint32_t nib = ~(word >> ((v & 1) * 16 + (w & 3) * 4)) & 15u;   // stored as "differs" bits
             const Move m = tb_lut(right_blk, nib & 3, nib >> 2, table);
             uint32_t op = m.op;
             if (eq && op == 1) op = q[i] == r[j] ? 2 : 3;
@@ -144,14 +144,15 @@ template <int PMAX, int KIND, bool TRACE, bool XDROP>
 struct Aligner {
     const BatchParams& bp;
     const WaveLds& L;
+    const FillConsts& fc;
     const uint8_t* q; const uint8_t* r;
     uint32_t qlen, rlen;
-    uint32_t* trace; BlockRec* blocks;
+    uint32_t* trace; BlockRec* blocks; short* ckpt;   // this wave's slot in the global scratch arenas
     uint32_t trace_top = 0, nblocks = 0, ck_trace_top = 0, ck_nblocks = 0;
     uint32_t status = 0;
     unsigned long long cells = 0;
 
-    __device__ Aligner(const BatchParams& bp_, const WaveLds& L_) : bp(bp_), L(L_) {}
+    __device__ Aligner(const BatchParams& bp_, const WaveLds& L_, const FillConsts& fc_) : bp(bp_), L(L_), fc(fc_) {}
 
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
         if (nblocks >= bp.blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
@@ -165,98 +166,122 @@ struct Aligner {
         trace_top += w * h / 8;
     }
 
-    // vectors along seqV; trace words for this rect start at trace_top_before
-    __device__ __forceinline__ Best place(const uint8_t* seqV, const uint8_t* seqC, uint32_t lenV, uint32_t lenC,
-                                          uint32_t si, uint32_t sj, uint32_t w, uint32_t h, short* Dc, short* Cc, short* Dr, short* Rr,
-                                          int corner, int rel_zero, int off_add, uint32_t tbase) {
-        uint32_t* tout = TRACE ? trace + tbase : nullptr;
-        const int go = bp.gap_open, ge = bp.gap_extend;
-#define BA_PLACE(PP) return place_block<PP, KIND, TRACE, XDROP>(L, seqV, seqC, lenV, lenC, si, sj, w, h, Dc, Cc, Dr, Rr, corner, rel_zero, off_add, go, ge, tout, cells)
-        if (h <= 128) BA_PLACE(1);
-        if constexpr (PMAX >= 2) { if (h == 256) BA_PLACE(2); }
-        if constexpr (PMAX >= 4) { if (h == 512) BA_PLACE(4); }
-        if constexpr (PMAX >= 8) { if (h == 1024) BA_PLACE(8); }
-        if constexpr (PMAX >= 16) { if (h == 2048) BA_PLACE(16); }
-#undef BA_PLACE
-        return Best{0, 0, 0};
+    // The block borders of the best-so-far position (scan_block.rs:406-427) are parked in this wave's slot of a global
+    // scratch arena (L2-resident, 8 * max_size bytes): they are written on every improving step but read back only
+    // when the block grows, and keeping them out of LDS doubles the number of resident waves per CU.
+    __device__ __forceinline__ void save_ckpt_borders(uint32_t n) {
+        lds_sync();
+        const uint32_t ms = bp.max_size;
+        for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
+            *(int*)(ckpt + k) = *(const int*)(L.D_col + k);
+            *(int*)(ckpt + ms + k) = *(const int*)(L.C_col + k);
+            *(int*)(ckpt + 2 * ms + k) = *(const int*)(L.D_row + k);
+            *(int*)(ckpt + 3 * ms + k) = *(const int*)(L.R_row + k);
+        }
     }
-
-    __device__ void save_ckpt_borders(uint32_t n) {
-        lds_copy(L.D_col_ck, L.D_col, n); lds_copy(L.C_col_ck, L.C_col, n);
-        lds_copy(L.D_row_ck, L.D_row, n); lds_copy(L.R_row_ck, L.R_row, n);
+    __device__ __forceinline__ void restore_ckpt_borders(uint32_t n) {
+        // drain this wave's checkpoint stores and drop stale L1 lines before reading them back
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const uint32_t ms = bp.max_size;
+        for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
+            *(int*)(L.D_col + k) = *(const int*)(ckpt + k);
+            *(int*)(L.C_col + k) = *(const int*)(ckpt + ms + k);
+            *(int*)(L.D_row + k) = *(const int*)(ckpt + 2 * ms + k);
+            *(int*)(L.R_row + k) = *(const int*)(ckpt + 3 * ms + k);
+        }
+        lds_sync();
     }
 
     __device__ void run(uint32_t pair) {
         q = bp.pool + bp.q_off[pair]; r = bp.pool + bp.r_off[pair];
         qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
         const uint32_t min_size = bp.min_size, max_size = bp.max_size;
-        // scratch reset (scan_block.rs:1322-1339): all eight borders to MIN = 0
+        // scratch reset (scan_block.rs:1322-1339): borders to MIN = 0. The checkpoint copies need no reset: they are
+        // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
         lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size);
-        lds_fill0(L.D_col_ck, max_size); lds_fill0(L.C_col_ck, max_size); lds_fill0(L.D_row_ck, max_size); lds_fill0(L.R_row_ck, max_size);
-        short* temp1 = L.vtab + 16; short* temp2 = L.vtab + 32;
+        short* temp1 = L.misc + 16; short* temp2 = L.misc + 32;
         lds_fill0(temp1, 32);
 
-        BA_DBG(0, 0x100 + pair);
         uint32_t si = 0, sj = 0;
         int best_max = 0; uint32_t best_i = 0, best_j = 0;
         int prev_dir = DIR_GROW, dir = DIR_GROW;
         uint32_t prev_size = 0, block_size = min_size;
-        int off = 0, prev_off, off_max = 0;
+        int off = 0, prev_off = 0, off_max = 0;
         uint32_t y_drop_iter = 0; int x_drop_iter = 0;
         uint32_t i_ckpt = 0, j_ckpt = 0; int off_ckpt = 0;
         int D_corner = 0;
+        int gphase = 0;                 // 0 = first rectangle of this driver step, 1 = second rectangle of a grow
+        Best grow{0, 0, 0};
+        int off_add = 0;
 
         const uint32_t max_steps = 64u * ((qlen + rlen) / STEP + 64u);   // watchdog: far above any legal run
         uint32_t steps = 0;
         for (;;) {
-            if (++steps > max_steps) { status |= ST_WATCHDOG; break; }
-            BA_DBG(1, steps); BA_DBG(2, dir); BA_DBG(3, si); BA_DBG(4, sj); BA_DBG(5, block_size);
-            prev_off = off;
-            Best grow{0, 0, 0}, cur;
-            int right_max, down_max;
+            // ---- set up the next rectangle (one fill call site for all four kinds of rectangle)
+            const uint8_t* seqV; const uint8_t* seqC; uint32_t lenV, lenC, ri, rj, rw, rh;
+            short *Dc, *Cc, *Dr, *Rr; int corner = 0; bool right;
+            if (gphase == 0) {
+                if (++steps > max_steps) { status |= ST_WATCHDOG; break; }
+                prev_off = off;
+                grow = Best{0, 0, 0};
+            }
             if (dir == DIR_RIGHT) {
                 off = off_max;
-                const int off_add = clamp16(prev_off - off);
-                const uint32_t tb = trace_top;
-                if (TRACE) add_block(si, sj + block_size - STEP, STEP, block_size, true);
+                off_add = clamp16(prev_off - off);
+                seqV = q; seqC = r; lenV = qlen; lenC = rlen; ri = si; rj = sj + block_size - STEP; rw = STEP; rh = block_size;
+                Dc = L.D_col; Cc = L.C_col; Dr = temp1; Rr = temp2; right = true;
+                corner = prev_dir == DIR_DOWN ? (int)as_s(adds(splat(D_corner), splat(off_add))).x : 0;
+            } else if (dir == DIR_DOWN) {
+                off = off_max;
+                off_add = clamp16(prev_off - off);
+                seqV = r; seqC = q; lenV = rlen; lenC = qlen; ri = sj; rj = si + block_size - STEP; rw = STEP; rh = block_size;
+                Dc = L.D_row; Cc = L.R_row; Dr = temp1; Rr = temp2; right = false;
+                corner = prev_dir == DIR_RIGHT ? (int)as_s(adds(splat(D_corner), splat(off_add))).x : 0;
+            } else if (gphase == 0) {   // grow, rectangle below the old block (scan_block.rs:260-278)
+                D_corner = 0; off_add = 0;
+                seqV = r; seqC = q; lenV = rlen; lenC = qlen; ri = sj; rj = si + prev_size; rw = block_size - prev_size; rh = prev_size;
+                Dc = L.D_row; Cc = L.R_row; Dr = L.D_col + prev_size; Rr = L.C_col + prev_size; right = false;
+            } else {                    // grow, rectangle right of the old block, full new height (scan_block.rs:287-305)
+                off_add = 0;
+                seqV = q; seqC = r; lenV = qlen; lenC = rlen; ri = si; rj = sj + prev_size; rw = block_size - prev_size; rh = block_size;
+                Dc = L.D_col; Cc = L.C_col; Dr = L.D_row + prev_size; Rr = L.R_row + prev_size; right = true;
+            }
+            const uint32_t tb = trace_top;
+            if (TRACE) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
+                if (right) add_block(ri, rj, rw, rh, true);
+                else add_block(rj, ri, rh, rw, false);
                 if (status) break;
-                cur = place(q, r, qlen, rlen, si, sj + block_size - STEP, STEP, block_size, L.D_col, L.C_col, temp1, temp2,
-                            prev_dir == DIR_DOWN ? (int)adds(splat(D_corner), splat(off_add)).x : 0, clamp16(-off + ZERO), off_add, tb);
+            }
+            uint32_t* tout = TRACE ? trace + tb : nullptr;
+            const int rz = clamp16(-off + ZERO);
+            Best cur{0, 0, 0};
+#define BA_PLACE(N) cur = place_rect<N, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells)
+            if (rh <= 128) BA_PLACE(1);
+            else if (PMAX >= 2 && rh == 256) BA_PLACE(2);
+            else if (PMAX >= 4 && rh == 512) BA_PLACE(4);
+            else if (PMAX >= 8 && rh == 1024) BA_PLACE(8);
+            else if (PMAX >= 16 && rh == 2048) BA_PLACE(16);
+#undef BA_PLACE
+            if (dir == DIR_GROW && gphase == 0) { grow = cur; gphase = 1; continue; }
+            gphase = 0;
+
+            // ---- the rest of the driver step
+            int right_max, down_max;
+            if (dir == DIR_RIGHT) {
                 right_max = lds_prefix_max8(L.D_col);
                 D_corner = lds_shift_and_offset(block_size, L.D_row, L.R_row, temp1, temp2, off_add);
                 down_max = lds_prefix_max8(L.D_row);
             } else if (dir == DIR_DOWN) {
-                off = off_max;
-                const int off_add = clamp16(prev_off - off);
-                const uint32_t tb = trace_top;
-                if (TRACE) add_block(si + block_size - STEP, sj, block_size, STEP, false);
-                if (status) break;
-                cur = place(r, q, rlen, qlen, sj, si + block_size - STEP, STEP, block_size, L.D_row, L.R_row, temp1, temp2,
-                            prev_dir == DIR_RIGHT ? (int)adds(splat(D_corner), splat(off_add)).x : 0, clamp16(-off + ZERO), off_add, tb);
                 down_max = lds_prefix_max8(L.D_row);
                 D_corner = lds_shift_and_offset(block_size, L.D_col, L.C_col, temp1, temp2, off_add);
                 right_max = lds_prefix_max8(L.D_col);
             } else {
-                D_corner = 0;
-                const uint32_t grow_step = block_size - prev_size;
-                const int rz = clamp16(-off + ZERO);
-                uint32_t tb = trace_top;
-                if (TRACE) add_block(si + prev_size, sj, prev_size, grow_step, false);
-                if (status) break;
-                grow = place(r, q, rlen, qlen, sj, si + prev_size, grow_step, prev_size, L.D_row, L.R_row,
-                             L.D_col + prev_size, L.C_col + prev_size, 0, rz, 0, tb);
-                tb = trace_top;
-                if (TRACE) add_block(si, sj + prev_size, grow_step, block_size, true);
-                if (status) break;
-                cur = place(q, r, qlen, rlen, si, sj + prev_size, grow_step, block_size, L.D_col, L.C_col,
-                            L.D_row + prev_size, L.R_row + prev_size, 0, rz, 0, tb);
                 right_max = lds_prefix_max8(L.D_col);
                 down_max = lds_prefix_max8(L.D_row);
                 save_ckpt_borders(block_size);
                 if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
             }
 
-            BA_DBG(6, steps);
             const int this_dir = dir;
             prev_dir = dir;
             const int D_max_max = cur.mx, grow_max = grow.mx;
@@ -295,8 +320,7 @@ struct Aligner {
             if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
                 prev_size = block_size; block_size = next_size; dir = DIR_GROW;
                 si = i_ckpt; sj = j_ckpt; off = off_ckpt;
-                lds_copy(L.D_col, L.D_col_ck, prev_size); lds_copy(L.C_col, L.C_col_ck, prev_size);
-                lds_copy(L.D_row, L.D_row_ck, prev_size); lds_copy(L.R_row, L.R_row_ck, prev_size);
+                restore_ckpt_borders(prev_size);
                 if (TRACE) { trace_top = ck_trace_top; nblocks = ck_nblocks; }
                 y_drop_iter = 0;
                 continue;
@@ -321,7 +345,6 @@ struct Aligner {
             else { sj += STEP; dir = DIR_RIGHT; }
         }
 
-        BA_DBG(7, steps);
         int score; uint32_t ri, rj;
         if (XDROP) { score = best_max; ri = best_i; rj = best_j; }
         else {
@@ -330,7 +353,6 @@ struct Aligner {
             else score = off + uni((int)L.D_col[qlen - si]) - ZERO;
             ri = qlen; rj = rlen;
         }
-        BA_DBG(8, score);
         uint32_t ncig = 0;
         if (TRACE && bp.cig_ops && !status) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
@@ -350,54 +372,68 @@ struct Aligner {
             if (bp.status) bp.status[pair] = status;
             if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
         }
-        BA_DBG(9, 77);
     }
 };
 
-__device__ __forceinline__ WaveLds carve_lds(char* base, uint32_t max_size) {
-    const uint32_t ab = lds_array_bytes(max_size);
+// Persistent kernel: WAVES_PER_WG independent waves per workgroup (they share only the read-only score table in LDS);
+// every wave pulls pair indices from a global counter until the batch is exhausted.
+template <int PMAX, int KIND, bool TRACE, bool XDROP>
+__global__ void __launch_bounds__(WAVES_PER_WG * 64) k_align(const BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id();
+    const int wave = (int)threadIdx.x >> 6;
+    // ---- workgroup-shared scoring table
+    {
+        char* tab = smem;
+        if (KIND == KIND_NUC) {
+            // T[crow][a][b] = packed {score(crow, a), score(crow, b)}: one 4-byte read yields both cells of a lane
+            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
+                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
+                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
+            }
+        } else {
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t ab = lds_array_bytes_h(bp.max_size);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(bp.max_size);
     WaveLds L;
     L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
     L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
-    L.D_col_ck = (short*)(base + 4 * ab); L.C_col_ck = (short*)(base + 5 * ab);
-    L.D_row_ck = (short*)(base + 6 * ab); L.R_row_ck = (short*)(base + 7 * ab);
-    L.vtab = (short*)(base + 8 * ab);                  // 16 consts + temp1[16] + temp2[16] = 96 B
-    L.mat = (const int8_t*)(base + 8 * ab + 128);      // up to 864 B
-    return L;
-}
-
-// Persistent kernel: one wave per workgroup; waves pull pair indices from a global counter.
-template <int PMAX, int KIND, bool TRACE, bool XDROP>
-__global__ void __launch_bounds__(64) k_align(const BatchParams bp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const WaveLds L = carve_lds(smem, bp.max_size);
-    const int lane = lane_id();
-    {   // scoring table and scan artefact constants into LDS
-        int8_t* m = (int8_t*)L.mat;
-        const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_NUC ? 8 * 16 : 2);
-        for (int k = lane; k < nbytes; k += 64) m[k] = bp.matrix[k];
-        if (lane < 16) {
-            // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 see
-            // a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
-            const int mult = lane == 15 ? 0 : (lane == 7 ? 12 : (lane & 7) + 1);
-            L.vtab[lane] = (short)(mult ? max(-32768, mult * bp.gap_extend) : -32768);
+    L.misc = (short*)(base + 4 * ab);
+    L.table = smem;
+    FillConsts fc;
+    {
+        const int g = bp.gap_extend;
+        fc.gap_extend = g;
+        fc.go2 = splat(bp.gap_open); fc.ge2 = splat(g); fc.ome2 = subs(splat(bp.gap_open), splat(g));
+        fc.g12 = pk(g, 2 * g);
+        fc.ones = 0x00010001;
+        fc.laneKG = lane * 2 * g; fc.lanem1KG = (lane - 1) * 2 * g;
+        // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 of each
+        // 16-cell vector see a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
+        int v[2];
+        for (int h = 0; h < 2; h++) {
+            const int k = (2 * lane + h) & 15;
+            const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
+            v[h] = mult ? max(-32768, mult * g) : -32768;
         }
+        fc.vconst = pk(v[0], v[1]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const uint32_t slot = blockIdx.x;
+    const uint32_t slot = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
     for (;;) {
         uint32_t pair = 0;
         if (is_lane(0)) pair = atomicAdd(bp.work_counter, 1u);
         pair = (uint32_t)uni((int)pair);
-        BA_DBG(10, pair);
         if (pair >= bp.n) break;
-        Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L);
+        Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L, fc);
         al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
         al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
+        al.ckpt = bp.ckpt + (uint64_t)slot * 4 * bp.max_size;
         al.run(pair);
-        BA_DBG(11, 88);
     }
-    BA_DBG(12, 99);
 }
 
 }  // namespace ba

@@ -157,9 +157,9 @@ struct BaBatch {
     int kind = 0; uint32_t mode = 0;
     uint32_t n = 0, min_size = 0, max_size = 0, pclass = 0;
     int gap_open = 0, gap_extend = 0, x_drop = 0;
-    uint32_t grid = 0, lds = 0;
+    uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
-    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, trace, blocks, counter;
+    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, trace, blocks, ckpt, counter;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false;
     BatchParams params() const {
@@ -171,11 +171,12 @@ struct BaBatch {
         bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode;
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
-        bp.cig_ops = (mode & BA_TRACE) ? cig_ops.as<uint32_t>() : nullptr;
+        bp.cig_ops = ((mode & BA_TRACE) && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
         bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
         bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
+        bp.ckpt = ckpt.as<short>();
         bp.work_counter = counter.as<uint32_t>();
         return bp;
     }
@@ -273,16 +274,22 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return nullptr; }
-    b->lds = ba::lds_wave_bytes_h((uint32_t)max_size);
+    b->lds = ba::lds_wg_bytes_h(kind, (uint32_t)max_size);
+    if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return nullptr; }
+    if (b->lds > 64 * 1024) {
+        // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
+    }
     int per_cu = 0;
     if (g_occ[kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return nullptr;
     }
-    if (per_cu > 32) per_cu = 32;
+    if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
+    if (const char* env = getenv("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
     uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
-    if (const char* env = getenv("BA_WAVES_PER_CU")) { int v = atoi(env); if (v > 0) grid = (uint64_t)prop.multiProcessorCount * v; }
-    if (grid > n) grid = n;
+    const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
+    if (grid > need) grid = need;
     b->grid = (uint32_t)grid;
+    b->slots = b->grid * ba::WAVES_PER_WG;
     // trace stack capacity per resident wave: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
     b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 : 0;
     b->blocks_stride = trace ? maxlen2 : 0;
@@ -296,8 +303,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(counter, 64);
     BA_ALLOC(cig_off, (n + 1) * 8);
     BA_ALLOC(cig_ops, b->cig_total * 4);
-    BA_ALLOC(trace, b->trace_stride * 4 * b->grid);
-    BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->grid);
+    BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
+    BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
+    BA_ALLOC(ckpt, (size_t)b->slots * 4 * max_size * sizeof(short));
 #undef BA_ALLOC
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -396,7 +404,7 @@ int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
 }
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {
     if (!b) return fail("null batch");
-    out[0] = b->grid; out[1] = b->lds; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
+    out[0] = b->slots; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
     return 0;
 }
 void ba_batch_destroy(BaBatch* b) { delete b; }

@@ -17,12 +17,20 @@
 
 template <bool TRACE, bool XDROP>
 static hipError_t launch1(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
-    ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(64), lds, s>>>(bp);
+    if (lds > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
     return hipGetLastError();
 }
 template <bool TRACE, bool XDROP>
 static hipError_t occ1(int* blocks_per_cu, unsigned lds) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, 64, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, ba::WAVES_PER_WG * 64, lds);
 }
 
 extern "C" hipError_t BA_LAUNCH(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {

@@ -40,13 +40,24 @@ struct BatchParams {
     // scratch, one region per resident wave
     uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot
+    short* ckpt;                 // per slot: 4 x max_size i16 (best-so-far borders, scan_block.rs:406-427)
     uint32_t* work_counter;
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_trace_top;
 };
 
 
-inline uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
-inline uint32_t lds_wave_bytes_h(uint32_t max_size) { return 8 * lds_array_bytes_h(max_size) + 128 + 896; }
+constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
+
+// LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
+#if defined(__HIPCC__)
+#define BA_HD __host__ __device__
+#else
+#define BA_HD
+#endif
+BA_HD inline uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
+BA_HD inline uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_array_bytes_h(max_size) + 128; }
+BA_HD inline uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }
+BA_HD inline uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
 
 }  // namespace ba
