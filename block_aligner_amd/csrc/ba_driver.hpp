@@ -139,6 +139,108 @@ __device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32
     return (uint32_t)(out_hi - wp);
 }
 
+// ------------------------------------------------------------------ traceback lanes (batch path)
+// In a TRACE batch the fill waves do not walk their own tracebacks: a walk is ~(|q|+|r|) dependent global loads and
+// would idle 63 lanes for as long as the fill itself takes. Finished trace stacks are handed to dedicated traceback
+// workgroups of the same persistent launch through a global ring (agent-scope release / acquire, MI355X guide G16);
+// there every LANE walks one alignment, one cell per loop iteration, so 64 latency-bound walks overlap per wave.
+#define BA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+struct TbLane {
+    uint32_t slot, pair, i, j, table, bidx, run_op, run_len, status;
+    uint64_t wp, lo;
+    const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
+    uint32_t bi, bj, tbase, nch, nl; bool right, in_rect;
+};
+
+__device__ __forceinline__ void tb_emit(TbLane& t, uint32_t* __restrict__ out) {
+    if (t.run_len) {
+        if (t.wp == t.lo) { t.status |= ST_CIGAR_OVERFLOW; t.i = t.j = 0; return; }
+        out[--t.wp] = (t.run_len << 4) | t.run_op;
+    }
+}
+// one iteration of scan_block.rs:1576-1670 for one lane: either step to the next rectangle or walk one cell
+__device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict__ out) {
+    if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
+        if (t.bidx == 0) { t.status |= ST_TRACEBACK_LOST; t.i = t.j = 0; t.run_len = 0; return; }
+        t.bidx--;
+        const BlockRec br = t.blocks[t.bidx];
+        t.bi = br.i; t.bj = br.j;
+        t.in_rect = t.i >= br.i && t.j >= br.j;
+        t.right = br.trace_base >> 31;
+        t.tbase = br.trace_base & 0x7fffffffu;
+        const uint32_t Hv = t.right ? br.h : br.w;
+        t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
+        return;
+    }
+    const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
+    const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
+    const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + ((v & 127) >> 1)];
+    const uint32_t same = eq ? (uint32_t)(t.q[t.i] == t.r[t.j]) : 0u;
+    const uint32_t nib = ~(word >> ((v & 1) * 16 + (w & 3) * 4)) & 15u;
+    const Move m = tb_lut(t.right, nib & 3, nib >> 2, t.table);
+    uint32_t op = m.op;
+    if (eq && op == 1) op = same ? 2 : 3;
+    if (m.di > t.i || m.dj > t.j) { t.status |= ST_TRACEBACK_LOST; t.i = t.j = 0; t.run_len = 0; return; }
+    t.i -= m.di; t.j -= m.dj; t.table = m.next;
+    if (op == t.run_op) t.run_len++;
+    else { tb_emit(t, out); t.run_op = op; t.run_len = 1; }
+}
+
+__device__ void traceback_consumer(const BatchParams& bp) {
+    enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
+    int phase = IDLE;
+    uint32_t claimed = 0;
+    TbLane t{};
+    const bool eq = bp.flags & F_CIGAR_EQ;
+    uint32_t* head = bp.tb_ctrl + 32;
+    for (;;) {
+        if (phase == IDLE) {
+            claimed = __hip_atomic_fetch_add(head, 1u, BA_RLX_AGENT);
+            phase = claimed >= bp.n ? RETIRED : WAIT;     // every pair yields exactly one task
+        }
+        bool got = false;
+        uint32_t entry = 0;
+        if (phase == WAIT) {
+            entry = __hip_atomic_load(bp.tb_queue + (claimed & bp.tb_qmask), BA_RLX_AGENT);
+            got = entry != 0;
+        }
+        if (__any(got)) {
+            // ONE acquire per poll round that found work, then plain loads (guide G16): drops stale L1 lines of
+            // arenas this CU read during earlier walks
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (got) __hip_atomic_store(bp.tb_queue + (claimed & bp.tb_qmask), 0u, BA_RLX_AGENT);
+            if (got && (entry & 0x80000000u)) {           // a pair that produced no trace stack (slot time-out)
+                bp.cig_len[entry & 0x7fffffffu] = 0;
+                phase = IDLE;
+            } else if (got) {
+                t = TbLane{};
+                t.slot = entry - 1;
+                const SlotInfo si = bp.slot_info[t.slot];
+                t.pair = si.pair; t.i = si.end_i; t.j = si.end_j; t.bidx = si.nblocks;
+                t.blocks = bp.blocks + (uint64_t)t.slot * bp.blocks_stride;
+                t.trace = bp.trace_arena + (uint64_t)t.slot * bp.trace_stride;
+                t.q = bp.pool + bp.q_off[t.pair]; t.r = bp.pool + bp.r_off[t.pair];
+                t.lo = bp.cig_off[t.pair]; t.wp = bp.cig_off[t.pair + 1];
+                t.status = bp.status[t.pair];
+                if (t.status) t.i = t.j = 0;          // the fill failed: nothing to walk
+                phase = WALK;
+            }
+        } else if (phase == WALK) {
+            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops);
+            if (!(t.i > 0 || t.j > 0)) {
+                tb_emit(t, bp.cig_ops);
+                bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
+                if (t.status) bp.status[t.pair] = t.status;
+                __hip_atomic_store(bp.slot_free + t.slot, 1u, BA_RLX_AGENT);   // the arena may be reused
+                phase = IDLE;
+            }
+        }
+        if (__all(phase == RETIRED)) break;
+        if (!__any(phase == WALK)) __builtin_amdgcn_s_sleep(32);               // nothing to walk: poll gently
+    }
+}
+
 // ------------------------------------------------------------------ driver
 template <int PMAX, int KIND, bool TRACE, bool XDROP>
 struct Aligner {
@@ -192,7 +294,35 @@ struct Aligner {
         lds_sync();
     }
 
-    __device__ void run(uint32_t pair) {
+    // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done).
+    __device__ __forceinline__ bool acquire_slot(uint32_t slot) {
+        for (uint32_t spins = 0; spins < (1u << 21); spins++) {   // ~4 s
+            uint32_t f = 0;
+            if (is_lane(0)) f = __hip_atomic_load(bp.slot_free + slot, BA_RLX_AGENT);
+            if (uni((int)f)) {
+                if (is_lane(0)) __hip_atomic_store(bp.slot_free + slot, 0u, BA_RLX_AGENT);
+                return true;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+        return false;
+    }
+    // Publish a finished trace stack: plain stores -> release fence -> drained -> queue entry (guide G16 flag form).
+    __device__ __forceinline__ void hand_off(uint32_t slot, uint32_t pair, uint32_t end_i, uint32_t end_j, bool null_task = false) {
+        if (is_lane(0)) {
+            if (!null_task) bp.slot_info[slot] = SlotInfo{pair, nblocks, end_i, end_j};
+            bp.status[pair] = status;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (is_lane(0)) {
+            const uint32_t tpos = __hip_atomic_fetch_add(bp.tb_ctrl, 1u, BA_RLX_AGENT) & bp.tb_qmask;
+            while (__hip_atomic_load(bp.tb_queue + tpos, BA_RLX_AGENT) != 0) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(bp.tb_queue + tpos, null_task ? (0x80000000u | pair) : slot + 1, BA_RLX_AGENT);
+        }
+    }
+
+    __device__ void run(uint32_t pair, uint32_t slot, bool batch_traceback) {
         q = bp.pool + bp.q_off[pair]; r = bp.pool + bp.r_off[pair];
         qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
         const uint32_t min_size = bp.min_size, max_size = bp.max_size;
@@ -354,6 +484,15 @@ struct Aligner {
             ri = qlen; rj = rlen;
         }
         uint32_t ncig = 0;
+        if (TRACE && batch_traceback) {
+            if (is_lane(0)) {
+                bp.score[pair] = score; bp.query_idx[pair] = ri; bp.reference_idx[pair] = rj;
+                if (bp.cells) bp.cells[pair] = cells;
+                if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
+            }
+            hand_off(slot, pair, ri, rj);
+            return;
+        }
         if (TRACE && bp.cig_ops && !status) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
@@ -378,7 +517,7 @@ struct Aligner {
 // Persistent kernel: WAVES_PER_WG independent waves per workgroup (they share only the read-only score table in LDS);
 // every wave pulls pair indices from a global counter until the batch is exhausted.
 template <int PMAX, int KIND, bool TRACE, bool XDROP>
-__global__ void __launch_bounds__(WAVES_PER_WG * 64) k_align(const BatchParams bp) {
+__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_align(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
     const int wave = (int)threadIdx.x >> 6;
@@ -422,17 +561,36 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) k_align(const BatchParams b
         }
         fc.vconst = pk(v[0], v[1]);
     }
-    const uint32_t slot = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
+    // Traceback workgroups take the LOWEST block ids: blocks are dispatched in id order, so they are resident before
+    // any fill workgroup can wait on them even if the grid turns out to be larger than what fits at once.
+    const uint32_t n_tb_wgs = gridDim.x - bp.n_fill_wgs;
+    const bool batch_traceback = TRACE && n_tb_wgs > 0;
+    if (TRACE && blockIdx.x < n_tb_wgs) {
+        traceback_consumer(bp);
+        return;
+    }
+    const uint32_t fill_wave = (blockIdx.x - n_tb_wgs) * WAVES_PER_WG + (uint32_t)wave;
+    uint32_t turn = 0;
     for (;;) {
         uint32_t pair = 0;
         if (is_lane(0)) pair = atomicAdd(bp.work_counter, 1u);
         pair = (uint32_t)uni((int)pair);
         if (pair >= bp.n) break;
+        const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
+        if (++turn == bp.slots_per_wave) turn = 0;
         Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L, fc);
+        if (batch_traceback && !al.acquire_slot(slot)) {
+            // the traceback workgroups are not making progress: report instead of hanging. The pair still has to
+            // produce its queue entry so the consumers' task count stays exact.
+            al.status = ST_SLOT_TIMEOUT;
+            if (is_lane(0)) { bp.score[pair] = 0; bp.query_idx[pair] = 0; bp.reference_idx[pair] = 0; }
+            al.hand_off(slot, pair, 0, 0, true);
+            continue;
+        }
         al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
         al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
-        al.ckpt = bp.ckpt + (uint64_t)slot * 4 * bp.max_size;
-        al.run(pair);
+        al.ckpt = bp.ckpt + (uint64_t)fill_wave * 4 * bp.max_size;
+        al.run(pair, slot, batch_traceback);
     }
 }
 

@@ -159,7 +159,9 @@ struct BaBatch {
     int gap_open = 0, gap_extend = 0, x_drop = 0;
     uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
-    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, trace, blocks, ckpt, counter;
+    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, trace, blocks, ckpt, counter,
+           tb_queue, tb_ctrl, slot_free, slot_info;
+    uint32_t n_fill_wgs = 0, slots_per_wave = 1, tb_qsize = 1;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false;
     BatchParams params() const {
@@ -177,6 +179,10 @@ struct BaBatch {
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
         bp.ckpt = ckpt.as<short>();
+        bp.n_fill_wgs = n_fill_wgs; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots;
+        bp.tb_qmask = tb_qsize - 1;
+        bp.tb_queue = tb_queue.as<uint32_t>(); bp.tb_ctrl = tb_ctrl.as<uint32_t>();
+        bp.slot_free = slot_free.as<uint32_t>(); bp.slot_info = slot_info.as<ba::SlotInfo>();
         bp.work_counter = counter.as<uint32_t>();
         return bp;
     }
@@ -289,11 +295,34 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
     if (grid > need) grid = need;
     b->grid = (uint32_t)grid;
-    b->slots = b->grid * ba::WAVES_PER_WG;
-    // trace stack capacity per resident wave: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
+    // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
     b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 : 0;
     b->blocks_stride = trace ? maxlen2 : 0;
     if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
+    // TRACE batches big enough to keep them busy get dedicated traceback workgroups (ba_driver.hpp traceback_consumer)
+    // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
+    b->n_fill_wgs = b->grid; b->slots_per_wave = 1;
+    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
+        uint32_t cons = b->grid >= 32 ? b->grid / 16 : 1;
+        if (const char* env = getenv("BA_TB_WGS")) { int v = atoi(env); if (v > 0 && (uint32_t)v < b->grid) cons = (uint32_t)v; }
+        b->n_fill_wgs = b->grid - cons;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
+        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
+        uint32_t spw = 3;
+        if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
+        while (spw > 1 && fixed + per_slot * spw * b->n_fill_wgs * ba::WAVES_PER_WG > free_b * 9 / 10) spw--;
+        b->slots_per_wave = spw;
+    }
+    b->slots = b->n_fill_wgs * ba::WAVES_PER_WG * b->slots_per_wave;
+    {
+        const uint64_t lanes = (uint64_t)(b->grid - b->n_fill_wgs) * ba::WAVES_PER_WG * 64;
+        uint64_t need_q = std::max<uint64_t>(lanes, b->slots);
+        uint32_t qs = 1;
+        while (qs < need_q) qs <<= 1;
+        b->tb_qsize = qs;
+    }
     b->cig_total = trace ? cig_total : 0;
 
 #define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return nullptr
@@ -305,7 +334,8 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(cig_ops, b->cig_total * 4);
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
-    BA_ALLOC(ckpt, (size_t)b->slots * 4 * max_size * sizeof(short));
+    BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * max_size * sizeof(short));
+    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
 #undef BA_ALLOC
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -324,6 +354,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
 static int batch_run(BaBatch* b, float* kernel_ms) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+    HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
+    HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
+    HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     HIP_TRY(g_launch[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));

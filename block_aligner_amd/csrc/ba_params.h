@@ -12,13 +12,15 @@ constexpr int DIR_RIGHT = 0, DIR_DOWN = 1, DIR_GROW = 2;
 enum : uint32_t {
     F_TRACE = 1u << 0, F_XDROP = 1u << 1, F_LOCAL = 1u << 2, F_FQS = 1u << 3, F_FQE = 1u << 4, F_CIGAR_EQ = 1u << 5
 };
-enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8, ST_WATCHDOG = 16 };
+enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8, ST_WATCHDOG = 16, ST_SLOT_TIMEOUT = 32 };
 
 struct BlockRec {   // one computed rectangle (scan_block.rs:1428-1443), 16 bytes
     uint32_t i, j;
     uint16_t h, w;        // h = rows, w = columns of the rectangle
     uint32_t trace_base;  // dword index into this slot's trace arena; bit 31 = "right" (vectors along rows)
 };
+
+struct SlotInfo { uint32_t pair, nblocks, end_i, end_j; };
 
 struct BatchParams {
     // inputs: pool holds PaddedBytes images: [NULL] + converted bytes + NULL x pad (scan_block.rs:1790-1812)
@@ -40,8 +42,17 @@ struct BatchParams {
     // scratch, one region per resident wave
     uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot
-    short* ckpt;                 // per slot: 4 x max_size i16 (best-so-far borders, scan_block.rs:406-427)
+    short* ckpt;                 // per fill wave: 4 x max_size i16 (best-so-far borders, scan_block.rs:406-427)
     uint32_t* work_counter;
+    // in-launch hand-off of finished trace stacks from fill waves to traceback lanes (TRACE batches)
+    uint32_t n_fill_wgs;         // workgroups [0, n_fill_wgs) fill, the rest walk tracebacks
+    uint32_t slots_per_wave;     // trace arena slots owned by each fill wave (a slot is busy until its traceback is done)
+    uint32_t n_slots;
+    uint32_t tb_qmask;           // ring size - 1 (power of two >= max(traceback lanes, n_slots): live claims never share a position)
+    uint32_t* tb_queue;          // ring entries: slot + 1, or 0x80000000 | pair for a pair without a trace stack; 0 = empty
+    uint32_t* tb_ctrl;           // [0] tail (next entry to produce), [32] head (next entry to claim); separate cache lines
+    uint32_t* slot_free;         // per slot: 1 = free, 0 = owned by a fill wave or a pending traceback
+    SlotInfo* slot_info;         // per slot: what the traceback lane needs
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_trace_top;
 };

@@ -93,3 +93,15 @@ def test_config3_shape(hip, oracle):
     pairs = synth.make_pairs(96, 10000, 1000, 500, synth.DNA, seed=1234)
     res = compare(hip, oracle, pairs, NUC, (-5, -1), (128, 1024), 100, ("trace", "x_drop"))
     assert (res["query_idx"] > 9000).all()
+
+
+def test_traceback_consumer_path(hip, oracle, monkeypatch):
+    """Large TRACE batches hand finished trace stacks to dedicated traceback workgroups inside the launch
+    (agent-scope release/acquire queue, slot reuse). Force that path on a batch small enough for the oracle and big
+    enough that every fill wave recycles its trace slots several times."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_SLOTS_PER_WAVE", "2")
+    monkeypatch.setenv("BA_WGS_PER_CU", "1")
+    pairs = synth.make_pairs(6000, (200, 1500), (10, 150), 40, synth.DNA, seed=77, indels=1, indel_len=(10, 80))
+    compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 60, ("trace", "x_drop"))
+    compare(hip, oracle, pairs, NUC, (-5, -1), (32, 128), 0, ("trace",))
