@@ -510,6 +510,7 @@ struct Aligner {
             if (bp.cells) bp.cells[pair] = cells;
             if (bp.status) bp.status[pair] = status;
             if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
+            if (bp.slot_out) bp.slot_out[pair] = slot;
         }
     }
 };

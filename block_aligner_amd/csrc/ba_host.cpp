@@ -159,7 +159,7 @@ struct BaBatch {
     int gap_open = 0, gap_extend = 0, x_drop = 0;
     uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
-    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, trace, blocks, ckpt, counter,
+    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace, blocks, ckpt, counter,
            tb_queue, tb_ctrl, slot_free, slot_info;
     uint32_t n_fill_wgs = 0, slots_per_wave = 1, tb_qsize = 1;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
@@ -175,7 +175,7 @@ struct BaBatch {
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
         bp.cig_ops = ((mode & BA_TRACE) && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
         bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
-        bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>();
+        bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
         bp.ckpt = ckpt.as<short>();
@@ -329,7 +329,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(pool, total); BA_ALLOC(q_off, n * 8); BA_ALLOC(q_len, n * 4); BA_ALLOC(r_off, n * 8); BA_ALLOC(r_len, n * 4);
     BA_ALLOC(matrix, 1024);
     BA_ALLOC(score, n * 4); BA_ALLOC(qidx, n * 4); BA_ALLOC(ridx, n * 4); BA_ALLOC(cig_len, n * 4); BA_ALLOC(cells, n * 8);
-    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(counter, 64);
+    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(pair_slot, n * 4); BA_ALLOC(counter, 64);
     BA_ALLOC(cig_off, (n + 1) * 8);
     BA_ALLOC(cig_ops, b->cig_total * 4);
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
@@ -631,14 +631,14 @@ static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const 
     if (!(b->mode & BA_TRACE)) die("trace() requires a Block created with TRACE");   // scan_block.rs:1241-1243
     BaBatch* d = b->last.get();
     if (!d) die("cigar requested before any alignment");
-    uint32_t ql, rl, nb;
-    if (d2h(d->q_len, &ql, 1) || d2h(d->r_len, &rl, 1) || d2h(d->nblocks, &nb, 1)) die("%s", g_err.c_str());
+    uint32_t ql, rl, nb, slot;
+    if (d2h(d->q_len, &ql, 1) || d2h(d->r_len, &rl, 1) || d2h(d->nblocks, &nb, 1) || d2h(d->pair_slot, &slot, 1)) die("%s", g_err.c_str());
     if (!(i <= ql && j <= rl)) die("Traceback cigar end position must be in bounds!");   // scan_block.rs:1483
     if (i + j + 5 > cigar->capacity) die("Cigar was created for shorter sequences than this traceback needs");   // cigar.rs:58-60 slice bound
     (void)q; (void)r;   // the padded images of the aligned pair are already resident on the device
     BatchParams bp = d->params();
     bp.flags = eq ? (bp.flags | ba::F_CIGAR_EQ) : (bp.flags & ~ba::F_CIGAR_EQ);
-    bp.tb_i = (uint32_t)i; bp.tb_j = (uint32_t)j; bp.tb_nblocks = nb;
+    bp.tb_i = (uint32_t)i; bp.tb_j = (uint32_t)j; bp.tb_nblocks = nb; bp.tb_slot = slot;
     if (hipSetDevice(d->device) != hipSuccess || ba_launch_traceback(d->stream, &bp) != hipSuccess ||
         hipStreamSynchronize(d->stream) != hipSuccess) die("traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
     uint32_t n, st;

@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {
     using namespace ba;
     if (lane_id() != 0) return;
     uint32_t st = 0;
-    const uint32_t n = traceback(bp.blocks, bp.tb_nblocks, bp.trace_arena, bp.tb_i, bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0],
+    const uint32_t n = traceback(bp.blocks + (uint64_t)bp.tb_slot * bp.blocks_stride, bp.tb_nblocks,
+                                 bp.trace_arena + (uint64_t)bp.tb_slot * bp.trace_stride, bp.tb_i, bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0],
                                  bp.flags & F_CIGAR_EQ, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
     bp.cig_len[0] = n;
     bp.status[0] = st;

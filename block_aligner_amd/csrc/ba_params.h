@@ -39,6 +39,7 @@ struct BatchParams {
     unsigned long long* cells;   // per pair: computed DP cells, may be null
     uint32_t* status;            // per pair error bits
     uint32_t* nblocks_out;       // per pair: rectangles on the trace stack at the end (may be null)
+    uint32_t* slot_out;          // per pair: trace slot that holds its stack (for a later k_traceback; may be null)
     // scratch, one region per resident wave
     uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot
@@ -54,7 +55,7 @@ struct BatchParams {
     uint32_t* slot_free;         // per slot: 1 = free, 0 = owned by a fill wave or a pending traceback
     SlotInfo* slot_info;         // per slot: what the traceback lane needs
     // single-pair traceback request (k_traceback): end position
-    uint32_t tb_i, tb_j, tb_nblocks, tb_trace_top;
+    uint32_t tb_i, tb_j, tb_nblocks, tb_slot;
 };
 
 
