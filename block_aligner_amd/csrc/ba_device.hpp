@@ -40,6 +40,19 @@ __device__ __forceinline__ int dpp_keep(int old, int src) {
 }
 // lane l <- lane l-1; lane 0 <- fill
 __device__ __forceinline__ int wave_shr1(int src, int fill) { return dpp_keep<0x138, 0xf>(fill, src); }
+// lane l <- lane l-1; lane 0 <- 0 (bound_ctrl:0): a single v_mov_b32_dpp, no "old value" set-up move
+__device__ __forceinline__ int wave_shr1_z(int src) { return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true); }
+// write a wave-uniform value into lane 0 of v
+__device__ __forceinline__ int set_lane0(int v, int uniform_val) {
+    asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(uniform_val)));
+    return v;
+}
+// a[l-1] + b[l] in one instruction (lane 0: 0 + b[0])
+__device__ __forceinline__ int add_shr1(int a, int b) {
+    int t;
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
 
 // inclusive prefix max over the 64 lanes: row_shr 1/2/4/8 inside rows of 16, then row_bcast:15 / row_bcast:31.
 // The DPP control is fused into v_max_i32 (lanes without a valid source keep their value); a DPP read needs two wait
@@ -76,6 +89,17 @@ __device__ __forceinline__ int neq01(int a, int b, int ones) {
     asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(t) : "v"(a), "v"(b), "s"(ones));
     return t;
 }
+// per 16-bit half: 1 where a == b, else 0 (sub, then saturating 1 - diff)
+__device__ __forceinline__ int eq01(int a, int b, int ones) {
+    int t;
+    asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, %3, %0 clamp" : "=&v"(t) : "v"(a), "v"(b), "s"(ones));
+    return t;
+}
+__device__ __forceinline__ int pk_mul(int a, int m) {
+    int t;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(a), "s"(m));
+    return t;
+}
 // per half: a * m + c (mod 2^16), m wave-uniform
 __device__ __forceinline__ int pk_mad(int a, int m, int c) {
     int t;
@@ -90,14 +114,31 @@ struct WaveLds {
     short* misc;          // per wave: 16 scan artefact constants, temp1[16], temp2[16]
     const char* table;    // per workgroup: NUC packed-pair score table (8 KB) / AA 27x32 bytes / BYTES {match, mismatch}
 };
-struct Best { int mx; int row; int col; };   // rect max (i16 value) and, for X-drop, its resolved location
+struct Best { int mx; int row; int col; };
+
+// Extra inputs / outputs of the shift-step fast path (block <= 128 cells: one chunk, everything in registers).
+struct FastIO {
+    int vec_a, vec_b;         // in: this lane's two vector-axis bytes (already waited for by the caller)
+    int col_chars;            // in: lanes 0..7 hold the 8 column bytes of the step
+    short* Pd; short* Pr;     // in: the orthogonal ("passive") border pair in LDS: shifted by 8 and re-based here
+    int act_max8, pas_max8;   // out: max of the first 8 entries of the active / passive D border (scan_block.rs:1020-1022)
+    int corner_new;           // out: D_corner for a following orthogonal step (scan_block.rs:1042)
+    int rAd, rAc, rPd, rPr;   // out: register images of the four borders after the step (checkpoint source)
+};
+// max over lanes 0..3 of max(lo, hi) of a packed register (quad-permute DPP reduce), wave-uniform result
+__device__ __forceinline__ int first8_max(int v) {
+    int m = max((int)as_s(v).x, (int)as_s(v).y);
+    m = max(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+    m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+    return __builtin_amdgcn_readlane(m, 0);
+}   // rect max (i16 value) and, for X-drop, its resolved location
 
 // loop-invariant per-lane / per-kernel values
 struct FillConsts {
     int go2, ge2, ome2;       // splat(gap_open), splat(gap_extend), splat(open (-) extend)
     int g12;                  // {g, 2g}
     int ones;                 // 0x00010001
-    int laneKG, lanem1KG;     // lane * 2g, (lane - 1) * 2g
+    int laneKG, lanem1KG;     // lane * 2g; (lane - 1) * 2g, except lane 0 which holds a large negative (no lane above)
     int vconst;               // scan artefact constants of this lane's two cells (avx2.rs:315-338)
     int gap_extend;
 };
@@ -133,12 +174,13 @@ __device__ __forceinline__ int fetch_score(const char* table, const ScoreKey<KIN
 // Fills a width x height rectangle column by column (scan_block.rs:1083-1228; for a down shift the caller swaps the
 // sequences exactly as the reference does). NCH = chunks of 128 cells per column; below 128 cells NCH = 1 and only
 // height / 2 lanes are active. width is a multiple of 8.
-template <int NCH, int KIND, bool TRACE, bool XDROP>
+template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false>
 __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
                                            short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out,
-                                           unsigned long long& cells) {
+                                           unsigned long long& cells, FastIO* fs = nullptr) {
+    static_assert(!FAST || NCH == 1, "the fast path handles single-chunk steps");
     const int lane = lane_id();
     const int nl = NCH > 1 ? 64 : (int)(height >> 1);   // active lanes
     const bool active = lane < nl;
@@ -150,13 +192,26 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     int d[NCH], c[NCH], dmax[NCH], jlast[NCH], tacc[NCH];
     ScoreKey<KIND> key[NCH];
     const int offa = splat(off_add);
+    int pasD = 0, pasR = 0;          // FAST: passive border entries [2l+8, 2l+9], re-based
+    const bool pas_in = FAST && lane + 4 < nl;   // this lane's shifted passive pair comes from the old border (else: the 8 new cells)
+    int ca[NCH], cb_[NCH];           // the chunk's two vector-axis bytes: all loads issued before any is used
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        ca[ch] = 0; cb_[ch] = 0;
+        if (!FAST && active) { ca[ch] = seqV[start_i + ch * 128 + 2 * lane]; cb_[ch] = seqV[start_i + ch * 128 + 2 * lane + 1]; }
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const int r0 = ch * 128 + 2 * lane;
-        int dv = 0, cv = 0, a = 0, b = 0;
-        if (active) {
-            dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0);
-            a = seqV[start_i + r0]; b = seqV[start_i + r0 + 1];
+        int dv = 0, cv = 0, a = ca[ch], b = cb_[ch];
+        if (active) { dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0); }
+        if (FAST) {
+            // every LDS read of the step is issued here, in one batch
+            if (pas_in) { pasD = *(const int*)(fs->Pd + r0 + STEP); pasR = *(const int*)(fs->Pr + r0 + STEP); }
+            const int c7 = (int)fs->Pd[STEP - 1];
+            fs->corner_new = uni((int)as_s(adds(splat(c7), offa)).x);
+            pasD = adds(pasD, offa); pasR = adds(pasR, offa);
+            a = fs->vec_a; b = fs->vec_b;
         }
         d[ch] = adds(dv, offa);                 // just_offset folded into the load (scan_block.rs:1003-1012)
         c[ch] = adds(cv, offa);
@@ -164,9 +219,8 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         key[ch] = make_key<KIND>(a, b);
     }
     const bool break_armed = !XDROP && (start_i + height > lenV);
-    const int NEG = -(1 << 29);
     int corner_cur = corner;
-    int cvec = (int)seqC[start_j + (lane & 7)];       // 8 column bytes at a time, one per lane (lanes 0..7)
+    int cvec = FAST ? fs->col_chars : (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
     int sc_next[NCH];
     {
         const int cb0 = __builtin_amdgcn_readlane(cvec, 0);
@@ -179,7 +233,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sc[ch] = sc_next[ch];
         // scores of the next column are fetched while this one is computed
-        if (((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
+        if (!FAST && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
         {
             const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
 #pragma unroll
@@ -189,17 +243,21 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
-        int up_nr = 1 << 16;                             // "R not opened" above the chunk
-        const int jj = splat((int)j), njj = splat(-(int)j);
+        int up_ro = 0;                                   // "R opened" flag of the cell above the chunk (0 at the top)
+        const int jp1 = splat((int)j + 1);
         int r_last = 0;
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
-            // D00: previous column shifted down one cell (scan_block.rs:1125)
-            const int prev = wave_shr1(d[ch], up_d);
+            // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
+            int prev = wave_shr1_z(d[ch]);
+            if (up_d != 0) prev = set_lane0(prev, up_d);
             if (NCH > 1) up_d = __builtin_amdgcn_readlane(d[ch], 63);
             const int d00 = __builtin_amdgcn_alignbit(d[ch], prev, 16);
             int d11 = adds(d00, sc[ch]);
-            if (ch == 0 && first_cell && lane == 0) d11 = pk(rel_zero, d11 >> 16);   // cell (0,0), scan_block.rs:1130-1132
+            if (ch == 0 && first_cell) {                 // cell (0,0), scan_block.rs:1130-1132: lane 0, low half
+                const int v0 = __builtin_amdgcn_readlane(d11, 0);
+                d11 = set_lane0(d11, (v0 & (int)0xffff0000) | (rel_zero & 0xffff));
+            }
             const int copen = adds(d[ch], fc.go2);
             const int cn = vmax(adds(c[ch], fc.ge2), copen);
             d11 = vmax(d11, cn);
@@ -207,31 +265,31 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             // R11: in-lane step, then the 64-lane scan on values re-based by lane * 2g
             const s16x2 t2 = as_s(adds(x, fc.ge2));
             int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
-            const int A = (int)as_s(r).y - fc.laneKG;
-            const int pm = wave_prefix_max(A);
-            const int pmx = wave_shr1(pm, NEG);
-            // lane*2g (+ carry) = what the cell above the chunk contributes: MIN = 0 at the top of the column
-            int cin = max(max(pmx + fc.lanem1KG, fc.laneKG + carry_r), -32768);
+            const int pm = wave_prefix_max((int)as_s(r).y - fc.laneKG);
+            // what the cells above this lane contribute: lanes above in this chunk, or (lane*2g + carry) from above the
+            // chunk, which is MIN = 0 at the top of the column
+            int cin = add_shr1(pm, fc.lanem1KG);
+            cin = max(max(cin, NCH > 1 ? fc.laneKG + carry_r : fc.laneKG), -32768);
             const s16x2 cs = as_s(cin);
             r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst);
             if (NCH > 1) carry_r = (int)(short)(__builtin_amdgcn_readlane(r, 63) >> 16);
             const int dn = vmax(d11, r);
             if (TRACE) {
                 const int nC = neq01(dn, cn, fc.ones), nR = neq01(dn, r, fc.ones);
-                const int nCo = neq01(cn, copen, fc.ones), nRo = neq01(r, x, fc.ones);
-                // "R opened" belongs to the cell below it (scan_block.rs:1179-1182)
-                const int pn = wave_shr1(nRo, up_nr);
-                if (NCH > 1) up_nr = __builtin_amdgcn_readlane(nRo, 63);
-                const int nRs = __builtin_amdgcn_alignbit(nRo, pn, 16);
+                const int nCo = neq01(cn, copen, fc.ones), eRo = eq01(r, x, fc.ones);
+                // "R opened" belongs to the cell below it (scan_block.rs:1179-1182): stored as an "equal" bit so the
+                // column top needs no fill value
+                int pn = wave_shr1_z(eRo);
+                if (NCH > 1) { if (up_ro != 0) pn = set_lane0(pn, up_ro); up_ro = __builtin_amdgcn_readlane(eRo, 63); }
+                const int eRs = __builtin_amdgcn_alignbit(eRo, pn, 16);
                 int nib = pk_mad(nR, 0x00020002, nC);
                 nib = pk_mad(nCo, 0x00040004, nib);
-                nib = pk_mad(nRs, 0x00080008, nib);
+                nib = pk_mad(eRs, 0x00080008, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
             }
             dmax[ch] = vmax(dmax[ch], dn);
-            if (XDROP) {
-                const int ne = neq01(dmax[ch], dn, fc.ones);
-                jlast[ch] = vmaxu(jlast[ch], pk_mad(ne, njj, jj));   // j where this cell ties or raises its row's max, else 0
+            if (XDROP) {   // jlast = 1 + last column whose cell ties or raises its row's running max
+                jlast[ch] = vmaxu(jlast[ch], pk_mul(eq01(dmax[ch], dn, fc.ones), jp1));
             }
             d[ch] = dn; c[ch] = cn;
             if (ch == NCH - 1) r_last = r;
@@ -262,6 +320,18 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (FAST) {
+        // shift_and_offset (scan_block.rs:1040-1061) on registers: the last 4 lanes take the 8 cells this step appended
+        if (active && !pas_in) { pasD = *(const int*)(Dr + 2 * (lane + 4 - nl)); pasR = *(const int*)(Rr + 2 * (lane + 4 - nl)); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active) { *(int*)(fs->Pd + 2 * lane) = pasD; *(int*)(fs->Pr + 2 * lane) = pasR; }
+        fs->act_max8 = first8_max(d[0]);
+        fs->pas_max8 = first8_max(pasD);
+        fs->rAd = d[0]; fs->rAc = c[0]; fs->rPd = pasD; fs->rPr = pasR;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     // ---- rectangle max and (X-drop) its location: among cells equal to the max, smallest (row % 16), then
     // largest column, then largest row (avx2.rs:271-274 + scan_block.rs:1198-1200 last-writer-wins per lane)
     int lm = -32768;
@@ -277,7 +347,8 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int v = h ? (int)as_s(dmax[ch]).y : (int)as_s(dmax[ch]).x;
-                const int jl = h ? (jlast[ch] >> 16) & 0xffff : jlast[ch] & 0xffff;
+                const int jl1 = h ? (jlast[ch] >> 16) & 0xffff : jlast[ch] & 0xffff;
+                const int jl = jl1 ? jl1 - 1 : 0;
                 const int row = ch * 128 + 2 * lane + h;
                 const int k = ((row & 15) << 24) | ((4095 - jl) << 12) | (4095 - row);
                 if (active && v == M) kmin = min(kmin, k);

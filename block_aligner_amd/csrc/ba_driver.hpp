@@ -116,7 +116,7 @@ __device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32
             const uint32_t v = right_blk ? ci : cj, w = right_blk ? cj : ci;
             const uint32_t chunk = v >> 7, lane = (v & 127) >> 1;
             const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
-            const uint32_t nib = ~(word >> ((v & 1) * 16 + (w & 3) * 4)) & 15u;   // stored as "differs" bits
+            const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 stored as "differs", bit 3 as "equal"
             const Move m = tb_lut(right_blk, nib & 3, nib >> 2, table);
             uint32_t op = m.op;
             if (eq && op == 1) op = q[i] == r[j] ? 2 : 3;
@@ -177,7 +177,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict
     const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
     const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + ((v & 127) >> 1)];
     const uint32_t same = eq ? (uint32_t)(t.q[t.i] == t.r[t.j]) : 0u;
-    const uint32_t nib = ~(word >> ((v & 1) * 16 + (w & 3) * 4)) & 15u;
+    const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 "differs", bit 3 "equal"
     const Move m = tb_lut(t.right, nib & 3, nib >> 2, t.table);
     uint32_t op = m.op;
     if (eq && op == 1) op = same ? 2 : 3;
@@ -253,6 +253,28 @@ struct Aligner {
     uint32_t trace_top = 0, nblocks = 0, ck_trace_top = 0, ck_nblocks = 0;
     uint32_t status = 0;
     unsigned long long cells = 0;
+    // sequence bytes for the next shift step, fetched one step ahead for both possible directions
+    int pf_qv = 0, pf_rv = 0, pf_qc = 0, pf_rc = 0;
+    uint32_t pf_si = 0, pf_sj = 0, pf_B = 0;   // pf_B = 0: nothing prefetched
+    FastIO fs;
+
+    __device__ __forceinline__ void prefetch_seq(uint32_t si, uint32_t sj, uint32_t B) {
+        const int lane = lane_id();
+        pf_qv = *(const unsigned short*)(q + si + 2 * lane);
+        pf_rv = *(const unsigned short*)(r + sj + 2 * lane);
+        pf_qc = q[si + B + (lane & 7)];
+        pf_rc = r[sj + B + (lane & 7)];
+        pf_si = si; pf_sj = sj; pf_B = B;
+    }
+    // While the block is a single chunk (<= 128 cells) the whole checkpoint is four VGPRs: a fast step parks its
+    // register images here instead of storing to memory (D_col, C_col, D_row, R_row order).
+    int ck_reg[4] = {0, 0, 0, 0};
+    bool ck_in_regs = false;
+    __device__ __forceinline__ void save_ckpt_regs(bool right) {
+        ck_reg[0] = right ? fs.rAd : fs.rPd; ck_reg[1] = right ? fs.rAc : fs.rPr;
+        ck_reg[2] = right ? fs.rPd : fs.rAd; ck_reg[3] = right ? fs.rPr : fs.rAc;
+        ck_in_regs = true;
+    }
 
     __device__ Aligner(const BatchParams& bp_, const WaveLds& L_, const FillConsts& fc_) : bp(bp_), L(L_), fc(fc_) {}
 
@@ -272,6 +294,7 @@ struct Aligner {
     // scratch arena (L2-resident, 8 * max_size bytes): they are written on every improving step but read back only
     // when the block grows, and keeping them out of LDS doubles the number of resident waves per CU.
     __device__ __forceinline__ void save_ckpt_borders(uint32_t n) {
+        ck_in_regs = false;
         lds_sync();
         const uint32_t ms = bp.max_size;
         for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
@@ -282,6 +305,16 @@ struct Aligner {
         }
     }
     __device__ __forceinline__ void restore_ckpt_borders(uint32_t n) {
+        if (ck_in_regs) {   // checkpoint of a single-chunk block: registers -> LDS
+            const uint32_t k = 2 * lane_id();
+            lds_sync();
+            if (k < n) {
+                *(int*)(L.D_col + k) = ck_reg[0]; *(int*)(L.C_col + k) = ck_reg[1];
+                *(int*)(L.D_row + k) = ck_reg[2]; *(int*)(L.R_row + k) = ck_reg[3];
+            }
+            lds_sync();
+            return;
+        }
         // drain this wave's checkpoint stores and drop stale L1 lines before reading them back
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         const uint32_t ms = bp.max_size;
@@ -385,8 +418,29 @@ struct Aligner {
             uint32_t* tout = TRACE ? trace + tb : nullptr;
             const int rz = clamp16(-off + ZERO);
             Best cur{0, 0, 0};
+            const bool fast = dir != DIR_GROW && rh <= 128 && !(bp.flags & 0x100u);   // bit 8: development switch, generic path only
+            if (fast) {
+                // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
+                const int lane = lane_id();
+                const bool hit = pf_B == block_size && ((dir == DIR_RIGHT && pf_si == si && pf_sj + STEP == sj) ||
+                                                        (dir == DIR_DOWN && pf_si + STEP == si && pf_sj == sj));
+                int vc;
+                if (hit) { vc = right ? pf_qv : pf_rv; fs.col_chars = right ? pf_rc : pf_qc; }
+                else {
+                    vc = 2 * lane < (int)rh ? (int)*(const unsigned short*)(seqV + ri + 2 * lane) : 0;
+                    fs.col_chars = seqC[rj + (lane & 7)];
+                }
+                fs.vec_a = vc & 0xff; fs.vec_b = (vc >> 8) & 0xff;
+                // pin the consumption of the old prefetch here: the memory counter is in-order, so the next prefetch
+                // must be issued only after the wait for the previous one
+                asm volatile("" : "+v"(fs.vec_a), "+v"(fs.vec_b), "+v"(fs.col_chars));
+                prefetch_seq(si, sj, block_size);
+                fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
+                cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
+                                                              off_add, tout, cells, &fs);
+            }
 #define BA_PLACE(N) cur = place_rect<N, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells)
-            if (rh <= 128) BA_PLACE(1);
+            else if (rh <= 128) BA_PLACE(1);
             else if (PMAX >= 2 && rh == 256) BA_PLACE(2);
             else if (PMAX >= 4 && rh == 512) BA_PLACE(4);
             else if (PMAX >= 8 && rh == 1024) BA_PLACE(8);
@@ -397,7 +451,11 @@ struct Aligner {
 
             // ---- the rest of the driver step
             int right_max, down_max;
-            if (dir == DIR_RIGHT) {
+            if (fast) {
+                right_max = right ? fs.act_max8 : fs.pas_max8;
+                down_max = right ? fs.pas_max8 : fs.act_max8;
+                D_corner = fs.corner_new;
+            } else if (dir == DIR_RIGHT) {
                 right_max = lds_prefix_max8(L.D_col);
                 D_corner = lds_shift_and_offset(block_size, L.D_row, L.R_row, temp1, temp2, off_add);
                 down_max = lds_prefix_max8(L.D_row);
@@ -429,7 +487,8 @@ struct Aligner {
                 }
                 if (block_size < max_size) {
                     i_ckpt = si; j_ckpt = sj; off_ckpt = off;
-                    save_ckpt_borders(block_size);
+                    if (fast) save_ckpt_regs(this_dir == DIR_RIGHT);
+                    else save_ckpt_borders(block_size);
                     if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
                     grow_no_max = false;
                 }
@@ -551,7 +610,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         fc.go2 = splat(bp.gap_open); fc.ge2 = splat(g); fc.ome2 = subs(splat(bp.gap_open), splat(g));
         fc.g12 = pk(g, 2 * g);
         fc.ones = 0x00010001;
-        fc.laneKG = lane * 2 * g; fc.lanem1KG = (lane - 1) * 2 * g;
+        fc.laneKG = lane * 2 * g; fc.lanem1KG = lane ? (lane - 1) * 2 * g : -(1 << 29);
         // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 of each
         // 16-cell vector see a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
         int v[2];

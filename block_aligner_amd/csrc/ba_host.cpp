@@ -170,7 +170,7 @@ struct BaBatch {
         bp.q_off = q_off.as<uint64_t>(); bp.q_len = q_len.as<uint32_t>();
         bp.r_off = r_off.as<uint64_t>(); bp.r_len = r_len.as<uint32_t>();
         bp.n = n; bp.gap_open = gap_open; bp.gap_extend = gap_extend;
-        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode;
+        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (getenv("BA_NO_FAST") ? 0x100u : 0u);
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
         bp.cig_ops = ((mode & BA_TRACE) && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
@@ -248,10 +248,10 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         const uint8_t* ptr; size_t len;
         get(p, 0, &ptr, &len);
         if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
-        ql[p] = (uint32_t)len; qo[p] = total; total += 1 + len + pad;
+        ql[p] = (uint32_t)len; qo[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;   // images start 4-byte aligned
         get(p, 1, &ptr, &len);
         if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
-        rl[p] = (uint32_t)len; ro[p] = total; total += 1 + len + pad;
+        rl[p] = (uint32_t)len; ro[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;
         maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
         cig_off[p] = cig_total;
         cig_total += (uint64_t)ql[p] + rl[p] + 1;
