@@ -18,6 +18,15 @@
 
 namespace ba {
 
+// development aid: -DBA_TIMING builds accumulate s_memtime deltas per phase (slots documented in tools/gpu_timing.py)
+#ifdef BA_TIMING
+#define BA_TSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define BA_TADD(acc, slot, a, b) (acc)[slot] += (b) - (a)
+#else
+#define BA_TSTAMP(var) do { } while (0)
+#define BA_TADD(acc, slot, a, b) do { } while (0)
+#endif
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -179,7 +188,8 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
                                            short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out,
-                                           unsigned long long& cells, FastIO* fs = nullptr) {
+                                           unsigned long long& cells, FastIO* fs = nullptr, unsigned long long* tacc_prof = nullptr) {
+    BA_TSTAMP(tp0);
     static_assert(!FAST || NCH == 1, "the fast path handles single-chunk steps");
     const int lane = lane_id();
     const int nl = NCH > 1 ? 64 : (int)(height >> 1);   // active lanes
@@ -227,19 +237,20 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sc_next[ch] = fetch_score<KIND>(L.table, key[ch], cb0);
     }
-    uint32_t j = 0;
-    for (; j < width; j++) {
+    BA_TSTAMP(tp1);
+    const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
+    auto column = [&](const uint32_t j) -> bool {   // returns false when the fill stops early (scan_block.rs:1216-1224)
         int sc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sc[ch] = sc_next[ch];
         // scores of the next column are fetched while this one is computed
         if (!FAST && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
-        {
+        if (!(FAST && j == 7)) {   // (last column of a shift step: nothing left to fetch)
             const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) sc_next[ch] = fetch_score<KIND>(L.table, key[ch], cbn);
         }
-        const bool first_cell = start_i == 0 && start_j + j == 0;
+        const bool first_cell = j == 0 && start_i == 0 && start_j == 0;
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
@@ -303,16 +314,26 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             for (int ch = 0; ch < NCH; ch++) tacc[ch] = 0;
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-        if (is_lane(nl - 1)) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
+        if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
         cells += height;
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCH + ch) * nl + lane] = (uint32_t)tacc[ch];
             }
-            break;
+            return false;
         }
+        return true;
+    };
+    if constexpr (FAST) {
+        // a shift step is exactly 8 columns: fully unrolled, so column indices, trace shifts and border offsets are
+        // immediates and only column 0 carries the corner / first-cell handling
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)STEP; j++) { if (!column(j)) break; }
+    } else {
+        for (uint32_t j = 0; j < width; j++) { if (!column(j)) break; }
     }
+    BA_TSTAMP(tp2);
     // ---- write the vector-axis border back
     if (active) {
 #pragma unroll
@@ -334,6 +355,28 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     }
     // ---- rectangle max and (X-drop) its location: among cells equal to the max, smallest (row % 16), then
     // largest column, then largest row (avx2.rs:271-274 + scan_block.rs:1198-1200 last-writer-wins per lane)
+    if (FAST && XDROP) {
+        // one reduction for both: value (16 bits, >= 0 because D_max starts at MIN = 0) | 15 - row%16 | last column + 1 | row
+        int best = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int v = h ? (int)as_s(dmax[0]).y : (int)as_s(dmax[0]).x;
+            const int jl1 = h ? (jlast[0] >> 16) & 0xffff : jlast[0] & 0xffff;
+            const int row = 2 * lane + h;
+            best = max(best, (v << 15) | ((15 - (row & 15)) << 11) | (jl1 << 7) | row);
+        }
+        if (!active) best = 0;
+        best = wave_max(best);
+        res.mx = best >> 15;
+        const int jl1 = (best >> 7) & 15;
+        res.col = jl1 ? jl1 - 1 : 0;
+        res.row = best & 127;
+        // no cell equalled the max (it is the initial MIN): the reference reports lane 0 / column 0 / vector 0
+        if (res.mx == 0 && jl1 == 0) res.row = 0;
+        BA_TSTAMP(tp3f);
+        BA_TADD(tacc_prof, 0, tp0, tp1); BA_TADD(tacc_prof, 1, tp1, tp2); BA_TADD(tacc_prof, 2, tp2, tp3f);
+        return res;
+    }
     int lm = -32768;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) lm = max(lm, max((int)as_s(dmax[ch]).x, (int)as_s(dmax[ch]).y));
@@ -358,6 +401,10 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         res.col = 4095 - ((kmin >> 12) & 4095);
         res.row = 4095 - (kmin & 4095);
     }
+    BA_TSTAMP(tp3);
+    BA_TADD(tacc_prof, FAST ? 0 : (NCH == 1 ? 4 : 8), tp0, tp1);
+    BA_TADD(tacc_prof, FAST ? 1 : (NCH == 1 ? 5 : 9), tp1, tp2);
+    BA_TADD(tacc_prof, FAST ? 2 : (NCH == 1 ? 6 : 10), tp2, tp3);
     return res;
 }
 

@@ -257,6 +257,11 @@ struct Aligner {
     int pf_qv = 0, pf_rv = 0, pf_qc = 0, pf_rc = 0;
     uint32_t pf_si = 0, pf_sj = 0, pf_B = 0;   // pf_B = 0: nothing prefetched
     FastIO fs;
+#ifdef BA_TIMING
+    unsigned long long prof[32] = {};
+#else
+    unsigned long long* prof = nullptr;
+#endif
 
     __device__ __forceinline__ void prefetch_seq(uint32_t si, uint32_t sj, uint32_t B) {
         const int lane = lane_id();
@@ -379,7 +384,9 @@ struct Aligner {
 
         const uint32_t max_steps = 64u * ((qlen + rlen) / STEP + 64u);   // watchdog: far above any legal run
         uint32_t steps = 0;
+        BA_TSTAMP(tr0);
         for (;;) {
+            BA_TSTAMP(ts0);
             // ---- set up the next rectangle (one fill call site for all four kinds of rectangle)
             const uint8_t* seqV; const uint8_t* seqC; uint32_t lenV, lenC, ri, rj, rw, rh;
             short *Dc, *Cc, *Dr, *Rr; int corner = 0; bool right;
@@ -417,6 +424,7 @@ struct Aligner {
             }
             uint32_t* tout = TRACE ? trace + tb : nullptr;
             const int rz = clamp16(-off + ZERO);
+            BA_TSTAMP(ts1);
             Best cur{0, 0, 0};
             const bool fast = dir != DIR_GROW && rh <= 128 && !(bp.flags & 0x100u);   // bit 8: development switch, generic path only
             if (fast) {
@@ -437,15 +445,17 @@ struct Aligner {
                 prefetch_seq(si, sj, block_size);
                 fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
                 cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
-                                                              off_add, tout, cells, &fs);
+                                                              off_add, tout, cells, &fs, prof);
             }
-#define BA_PLACE(N) cur = place_rect<N, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells)
+#define BA_PLACE(N) cur = place_rect<N, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof)
             else if (rh <= 128) BA_PLACE(1);
             else if (PMAX >= 2 && rh == 256) BA_PLACE(2);
             else if (PMAX >= 4 && rh == 512) BA_PLACE(4);
             else if (PMAX >= 8 && rh == 1024) BA_PLACE(8);
             else if (PMAX >= 16 && rh == 2048) BA_PLACE(16);
 #undef BA_PLACE
+            BA_TSTAMP(ts2);
+            BA_TADD(prof, 12, ts0, ts1); BA_TADD(prof, 13, ts1, ts2);
             if (dir == DIR_GROW && gphase == 0) { grow = cur; gphase = 1; continue; }
             gphase = 0;
 
@@ -501,6 +511,8 @@ struct Aligner {
                     else break;
                 } else x_drop_iter = 0;
             }
+            BA_TSTAMP(ts3);
+            BA_TADD(prof, 14, ts2, ts3);
             if (si + block_size > qlen && sj + block_size > rlen) break;
             if (sj + block_size > rlen) { si += STEP; dir = DIR_DOWN; continue; }
             if (si + block_size > qlen) { sj += STEP; dir = DIR_RIGHT; continue; }
@@ -534,6 +546,12 @@ struct Aligner {
             else { sj += STEP; dir = DIR_RIGHT; }
         }
 
+        BA_TSTAMP(tr1);
+        BA_TADD(prof, 15, tr0, tr1);
+#ifdef BA_TIMING
+        prof[16] += steps;
+        if (bp.prof && is_lane(0)) for (int k = 0; k < 17; k++) atomicAdd(bp.prof + k, prof[k]);
+#endif
         int score; uint32_t ri, rj;
         if (XDROP) { score = best_max; ri = best_i; rj = best_j; }
         else {

@@ -160,7 +160,7 @@ struct BaBatch {
     uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace, blocks, ckpt, counter,
-           tb_queue, tb_ctrl, slot_free, slot_info;
+           tb_queue, tb_ctrl, slot_free, slot_info, prof;
     uint32_t n_fill_wgs = 0, slots_per_wave = 1, tb_qsize = 1;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false;
@@ -184,6 +184,7 @@ struct BaBatch {
         bp.tb_queue = tb_queue.as<uint32_t>(); bp.tb_ctrl = tb_ctrl.as<uint32_t>();
         bp.slot_free = slot_free.as<uint32_t>(); bp.slot_info = slot_info.as<ba::SlotInfo>();
         bp.work_counter = counter.as<uint32_t>();
+        bp.prof = prof.as<unsigned long long>();
         return bp;
     }
     ~BaBatch() {
@@ -335,7 +336,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * max_size * sizeof(short));
-    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
+    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 256); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
 #undef BA_ALLOC
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -355,6 +356,7 @@ static int batch_run(BaBatch* b, float* kernel_ms) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
     HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
+    HIP_TRY(hipMemsetAsync(b->prof.p, 0, 256, b->stream));
     HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
     const BatchParams bp = b->params();
@@ -433,6 +435,11 @@ int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
                                      d_off.as<uint64_t>(), d_out.as<uint32_t>(), b->n));
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy(runs, d_out.p, total * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int ba_batch_prof(BaBatch* b, uint64_t out[32]) {   // development: phase timers of a -DBA_TIMING build
+    if (!b) return fail("null batch");
+    HIP_TRY(hipMemcpy(out, b->prof.p, 256, hipMemcpyDeviceToHost));
     return 0;
 }
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {

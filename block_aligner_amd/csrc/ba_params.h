@@ -45,6 +45,7 @@ struct BatchParams {
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot
     short* ckpt;                 // per fill wave: 4 x max_size i16 (best-so-far borders, scan_block.rs:406-427)
     uint32_t* work_counter;
+    unsigned long long* prof;    // development (-DBA_TIMING builds): per-phase cycle sums, 32 slots
     // in-launch hand-off of finished trace stacks from fill waves to traceback lanes (TRACE batches)
     uint32_t n_fill_wgs;         // workgroups [0, n_fill_wgs) fill, the rest walk tracebacks
     uint32_t slots_per_wave;     // trace arena slots owned by each fill wave (a slot is busy until its traceback is done)

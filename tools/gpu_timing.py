@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Phase timers from a -DBA_TIMING build (make -C block_aligner_amd/csrc EXTRA=-DBA_TIMING OBJ=_build_t LIB=../lib/libblock_aligner_hip_timing.so).
+usage: gpu_timing.py <pairs> <trace 0|1>"""
+import sys, os, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from block_aligner_amd import hip as H, scores as S, synth
+H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), "libblock_aligner_hip_timing.so")
+n, trace = int(sys.argv[1]), int(sys.argv[2])
+pairs = synth.make_pairs(n, 10000, 1000, 500, synth.DNA, seed=1234)
+mode = H.X_DROP | ((H.TRACE | H.CIGAR_EQ) if trace else 0)
+b = H.BatchAligner(S.NucMatrix.new_simple(2, -3), (-5, -1), (128, 1024), 100, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+b.run(); ms = b.run()
+prof = np.zeros(32, np.uint64)
+H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
+H.lib().ba_batch_prof(b._h, prof.ctypes.data)
+names = {0: "fast prologue", 1: "fast columns", 2: "fast epilogue", 4: "generic<=128 prologue", 5: "generic<=128 columns", 6: "generic<=128 epilogue",
+         8: "tall prologue", 9: "tall columns", 10: "tall epilogue", 12: "driver: rect setup", 13: "driver: place (all)", 14: "driver: post-step", 15: "pair total"}
+tot = float(prof[15]); steps = float(prof[16])
+print(f"pairs={n} trace={trace} kernel_ms={ms:.2f} steps/pair={steps/n:.0f} cycles/pair={tot/n:.0f} (s_memtime ticks)")
+for k, v in names.items():
+    print(f"  {v:28s} {float(prof[k])/n:12.0f} ticks/pair  {100*float(prof[k])/tot:5.1f}%   {float(prof[k])/max(steps,1):8.1f} ticks/step")
