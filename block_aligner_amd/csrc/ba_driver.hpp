@@ -151,40 +151,100 @@ struct TbLane {
     uint64_t wp, lo;
     const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
     uint32_t bi, bj, tbase, nch, nl; bool right, in_rect;
+    // look-ahead state: the next rectangle record, a 4-lane x 2-column-group window of this rectangle's trace words,
+    // and 16-byte windows of both sequences -- so that most cells are walked from registers
+    uint4 nrec; bool nrec_ok;
+    uint32_t tw[8]; uint32_t tw_lane0; bool tw_ok;
+    uint32_t qw[4], rw[4]; uint32_t qw0, rw0;     // windows cover [qw0, qw0 + 16) and [rw0, rw0 + 16); 0xffffffff = empty
 };
 
+__device__ __forceinline__ uint32_t sel4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t k) {
+    return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
+}
 __device__ __forceinline__ void tb_emit(TbLane& t, uint32_t* __restrict__ out) {
     if (t.run_len) {
         if (t.wp == t.lo) { t.status |= ST_CIGAR_OVERFLOW; t.i = t.j = 0; return; }
         out[--t.wp] = (t.run_len << 4) | t.run_op;
     }
 }
-// one iteration of scan_block.rs:1576-1670 for one lane: either step to the next rectangle or walk one cell
+__device__ __forceinline__ void tb_fail(TbLane& t) { t.status |= ST_TRACEBACK_LOST; t.i = t.j = 0; t.run_len = 0; }
+
+// One iteration of scan_block.rs:1576-1670 for one lane: either move to the next rectangle (and issue the loads that
+// will let it be walked from registers) or walk up to four cells. At most one round of memory latency per call.
 __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict__ out) {
     if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
-        if (t.bidx == 0) { t.status |= ST_TRACEBACK_LOST; t.i = t.j = 0; t.run_len = 0; return; }
+        if (t.bidx == 0) { tb_fail(t); return; }
         t.bidx--;
-        const BlockRec br = t.blocks[t.bidx];
-        t.bi = br.i; t.bj = br.j;
-        t.in_rect = t.i >= br.i && t.j >= br.j;
-        t.right = br.trace_base >> 31;
-        t.tbase = br.trace_base & 0x7fffffffu;
-        const uint32_t Hv = t.right ? br.h : br.w;
+        const uint4 rec = t.nrec_ok ? t.nrec : *(const uint4*)(t.blocks + t.bidx);
+        t.nrec_ok = t.bidx > 0;
+        if (t.nrec_ok) t.nrec = *(const uint4*)(t.blocks + t.bidx - 1);
+        t.bi = rec.x; t.bj = rec.y;
+        const uint32_t h = rec.z & 0xffffu, w = rec.z >> 16;
+        t.in_rect = t.i >= t.bi && t.j >= t.bj;
+        t.right = rec.w >> 31;
+        t.tbase = rec.w & 0x7fffffffu;
+        const uint32_t Hv = t.right ? h : w, ncol = t.right ? w : h;
         t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
+        t.tw_ok = false;
+        if (t.in_rect) {
+            if (t.nch == 1 && ncol == 8) {   // a shift step: both column groups of the 4 lanes ending at the entry cell
+                const uint32_t v = t.right ? t.i - t.bi : t.j - t.bj, lc = v >> 1;
+                t.tw_lane0 = lc >= 3 ? lc - 3 : 0;
+                const uint32_t* base = t.trace + t.tbase;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t l = min(t.tw_lane0 + k, t.nl - 1);
+                    t.tw[k] = base[l]; t.tw[4 + k] = base[t.nl + l];
+                }
+                t.tw_ok = true;
+            }
+            if (eq) {   // refill the sequence windows when fewer than 8 positions are left below the current one
+                if (t.qw0 == 0xffffffffu || t.i < t.qw0 + 8 || t.i >= t.qw0 + 16) {
+                    t.qw0 = t.i >= 12 ? (t.i - 12) & ~3u : 0;
+                    const uint32_t* p = (const uint32_t*)(t.q + t.qw0);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) t.qw[k] = p[k];
+                }
+                if (t.rw0 == 0xffffffffu || t.j < t.rw0 + 8 || t.j >= t.rw0 + 16) {
+                    t.rw0 = t.j >= 12 ? (t.j - 12) & ~3u : 0;
+                    const uint32_t* p = (const uint32_t*)(t.r + t.rw0);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) t.rw[k] = p[k];
+                }
+            }
+        }
         return;
     }
-    const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
-    const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
-    const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + ((v & 127) >> 1)];
-    const uint32_t same = eq ? (uint32_t)(t.q[t.i] == t.r[t.j]) : 0u;
-    const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 "differs", bit 3 "equal"
-    const Move m = tb_lut(t.right, nib & 3, nib >> 2, t.table);
-    uint32_t op = m.op;
-    if (eq && op == 1) op = same ? 2 : 3;
-    if (m.di > t.i || m.dj > t.j) { t.status |= ST_TRACEBACK_LOST; t.i = t.j = 0; t.run_len = 0; return; }
-    t.i -= m.di; t.j -= m.dj; t.table = m.next;
-    if (op == t.run_op) t.run_len++;
-    else { tb_emit(t, out); t.run_op = op; t.run_len = 1; }
+    for (int s = 0; s < 4; s++) {
+        if (!(t.i > 0 || t.j > 0) || !(t.i >= t.bi && t.j >= t.bj)) break;
+        const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
+        const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
+        const uint32_t lc = (v & 127) >> 1;
+        uint32_t word;
+        if (t.tw_ok && lc >= t.tw_lane0 && lc < t.tw_lane0 + 4) {
+            const uint32_t k = lc - t.tw_lane0;
+            word = (w >> 2) ? sel4(t.tw[4], t.tw[5], t.tw[6], t.tw[7], k) : sel4(t.tw[0], t.tw[1], t.tw[2], t.tw[3], k);
+        } else if (s == 0) {
+            word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
+        } else break;
+        const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 "differs", bit 3 "equal"
+        const Move m = tb_lut(t.right, nib & 3, nib >> 2, t.table);
+        uint32_t op = m.op;
+        if (eq && op == 1) {
+            uint32_t qb, rb;
+            const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
+            if (t.qw0 != 0xffffffffu && qo < 16 && t.rw0 != 0xffffffffu && ro < 16) {
+                qb = (sel4(t.qw[0], t.qw[1], t.qw[2], t.qw[3], qo >> 2) >> ((qo & 3) * 8)) & 0xff;
+                rb = (sel4(t.rw[0], t.rw[1], t.rw[2], t.rw[3], ro >> 2) >> ((ro & 3) * 8)) & 0xff;
+            } else if (s == 0) { qb = t.q[t.i]; rb = t.r[t.j]; }
+            else break;
+            op = qb == rb ? 2 : 3;
+        }
+        if (m.di > t.i || m.dj > t.j) { tb_fail(t); return; }   // would leave the matrix: corrupt trace
+        t.i -= m.di; t.j -= m.dj; t.table = m.next;
+        if (op == t.run_op) t.run_len++;
+        else { tb_emit(t, out); t.run_op = op; t.run_len = 1; }
+    }
 }
 
 __device__ void traceback_consumer(const BatchParams& bp) {
@@ -215,6 +275,7 @@ __device__ void traceback_consumer(const BatchParams& bp) {
                 phase = IDLE;
             } else if (got) {
                 t = TbLane{};
+                t.qw0 = t.rw0 = 0xffffffffu;
                 t.slot = entry - 1;
                 const SlotInfo si = bp.slot_info[t.slot];
                 t.pair = si.pair; t.i = si.end_i; t.j = si.end_j; t.bidx = si.nblocks;
@@ -416,18 +477,8 @@ struct Aligner {
                 seqV = q; seqC = r; lenV = qlen; lenC = rlen; ri = si; rj = sj + prev_size; rw = block_size - prev_size; rh = block_size;
                 Dc = L.D_col; Cc = L.C_col; Dr = L.D_row + prev_size; Rr = L.R_row + prev_size; right = true;
             }
-            const uint32_t tb = trace_top;
-            if (TRACE) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
-                if (right) add_block(ri, rj, rw, rh, true);
-                else add_block(rj, ri, rh, rw, false);
-                if (status) break;
-            }
-            uint32_t* tout = TRACE ? trace + tb : nullptr;
-            const int rz = clamp16(-off + ZERO);
-            BA_TSTAMP(ts1);
-            Best cur{0, 0, 0};
             const bool fast = dir != DIR_GROW && rh <= 128 && !(bp.flags & 0x100u);   // bit 8: development switch, generic path only
-            if (fast) {
+            if (fast) {   // before any store of this step: the memory counter is in-order
                 // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
                 const int lane = lane_id();
                 const bool hit = pf_B == block_size && ((dir == DIR_RIGHT && pf_si == si && pf_sj + STEP == sj) ||
@@ -442,10 +493,22 @@ struct Aligner {
                 // pin the consumption of the old prefetch here: the memory counter is in-order, so the next prefetch
                 // must be issued only after the wait for the previous one
                 asm volatile("" : "+v"(fs.vec_a), "+v"(fs.vec_b), "+v"(fs.col_chars));
-                prefetch_seq(si, sj, block_size);
+            }
+            const uint32_t tb = trace_top;
+            if (TRACE) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
+                if (right) add_block(ri, rj, rw, rh, true);
+                else add_block(rj, ri, rh, rw, false);
+                if (status) break;
+            }
+            uint32_t* tout = TRACE ? trace + tb : nullptr;
+            const int rz = clamp16(-off + ZERO);
+            BA_TSTAMP(ts1);
+            Best cur{0, 0, 0};
+            if (fast) {
                 fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
                 cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
                                                               off_add, tout, cells, &fs, prof);
+                prefetch_seq(si, sj, block_size);   // for the next step, behind this step's stores
             }
 #define BA_PLACE(N) cur = place_rect<N, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof)
             else if (rh <= 128) BA_PLACE(1);
@@ -657,7 +720,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
         if (++turn == bp.slots_per_wave) turn = 0;
         Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L, fc);
-        if (batch_traceback && !al.acquire_slot(slot)) {
+        BA_TSTAMP(tw0);
+        const bool got_slot = !batch_traceback || al.acquire_slot(slot);
+        BA_TSTAMP(tw1);
+#ifdef BA_TIMING
+        if (bp.prof && is_lane(0)) atomicAdd(bp.prof + 17, tw1 - tw0);
+#endif
+        if (!got_slot) {
             // the traceback workgroups are not making progress: report instead of hanging. The pair still has to
             // produce its queue entry so the consumers' task count stays exact.
             al.status = ST_SLOT_TIMEOUT;

@@ -193,14 +193,15 @@ int ba_oracle_batch_align(int kind, const int8_t* matrix, const uint8_t* pool,
             if (r_len[p] > max_r) max_r = r_len[p];
         }
         if (n_threads < 1) n_threads = 1;
-        std::vector<std::unique_ptr<Block>> blocks;
-        for (int t = 0; t < n_threads; t++) blocks.emplace_back(new Block(mode_of(flags), max_q, max_r, pad));
+        // one Block per thread, constructed (and so first-touched) by the thread that uses it
+        std::vector<std::unique_ptr<Block>> blocks(n_threads);
         std::atomic<size_t> next{0};
         std::atomic<uint64_t> cells{0};
         std::atomic<bool> failed{false};
         std::string err;
         const Gaps g{gap_open, gap_extend};
         auto worker = [&](int t) {
+            if (!blocks[t]) blocks[t].reset(new Block(mode_of(flags), max_q, max_r, pad));
             Block& blk = *blocks[t];
             Cigar cg((flags & F_TRACE) ? max_q : 0, (flags & F_TRACE) ? max_r : 0);
             uint64_t local_cells = 0;
@@ -231,6 +232,11 @@ int ba_oracle_batch_align(int kind, const int8_t* matrix, const uint8_t* pool,
             }
             cells += local_cells;
         };
+        {   // allocate before the clock starts
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; t++) th.emplace_back([&, t] { blocks[t].reset(new Block(mode_of(flags), max_q, max_r, pad)); });
+            for (auto& x : th) x.join();
+        }
         auto t0 = std::chrono::steady_clock::now();
         if (n_threads == 1) worker(0);
         else {
