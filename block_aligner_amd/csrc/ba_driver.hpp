@@ -305,7 +305,18 @@ __device__ void traceback_consumer(const BatchParams& bp) {
 // ------------------------------------------------------------------ driver
 template <int PMAX, int KIND, bool TRACE, bool XDROP>
 struct Aligner {
-    const BatchParams& bp;
+    // The batch descriptor lives in device memory. Only the scalars the step loop needs are copied into registers;
+    // everything else (a couple of dozen per-pair output pointers) is re-read where it is used, once per pair, so it
+    // does not sit in SGPRs across the whole persistent loop and get spilled to VGPR lanes.
+    uint32_t h_flags, h_min_size, h_max_size, h_blocks_stride, h_trace_stride; int h_x_drop;
+    // cold fields: scalar loads from the kernel-argument segment at the point of use (the empty asm keeps the compiler
+    // from hoisting them out of the persistent loop and pinning ~50 SGPRs)
+    typedef const __attribute__((address_space(4))) BatchParams* ColdPtr;
+    __device__ __forceinline__ static ColdPtr coldp() {
+        ColdPtr p = (ColdPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    }
     const WaveLds& L;
     const FillConsts& fc;
     const uint8_t* q; const uint8_t* r;
@@ -342,11 +353,14 @@ struct Aligner {
         ck_in_regs = true;
     }
 
-    __device__ Aligner(const BatchParams& bp_, const WaveLds& L_, const FillConsts& fc_) : bp(bp_), L(L_), fc(fc_) {}
+    __device__ Aligner(const BatchParams& b, const WaveLds& L_, const FillConsts& fc_) : L(L_), fc(fc_) {
+        h_flags = b.flags; h_min_size = b.min_size; h_max_size = b.max_size; h_x_drop = b.x_drop;
+        h_blocks_stride = (uint32_t)b.blocks_stride; h_trace_stride = (uint32_t)b.trace_stride;
+    }
 
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
-        if (nblocks >= bp.blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
-        if ((uint64_t)trace_top + (uint64_t)w * h / 8 > bp.trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
+        if (nblocks >= h_blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
+        if ((uint64_t)trace_top + (uint64_t)w * h / 8 > h_trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
         if (is_lane(0)) {
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
@@ -362,7 +376,7 @@ struct Aligner {
     __device__ __forceinline__ void save_ckpt_borders(uint32_t n) {
         ck_in_regs = false;
         lds_sync();
-        const uint32_t ms = bp.max_size;
+        const uint32_t ms = h_max_size;
         for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
             *(int*)(ckpt + k) = *(const int*)(L.D_col + k);
             *(int*)(ckpt + ms + k) = *(const int*)(L.C_col + k);
@@ -383,7 +397,7 @@ struct Aligner {
         }
         // drain this wave's checkpoint stores and drop stale L1 lines before reading them back
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-        const uint32_t ms = bp.max_size;
+        const uint32_t ms = h_max_size;
         for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
             *(int*)(L.D_col + k) = *(const int*)(ckpt + k);
             *(int*)(L.C_col + k) = *(const int*)(ckpt + ms + k);
@@ -397,9 +411,9 @@ struct Aligner {
     __device__ __forceinline__ bool acquire_slot(uint32_t slot) {
         for (uint32_t spins = 0; spins < (1u << 21); spins++) {   // ~4 s
             uint32_t f = 0;
-            if (is_lane(0)) f = __hip_atomic_load(bp.slot_free + slot, BA_RLX_AGENT);
+            if (is_lane(0)) f = __hip_atomic_load(coldp()->slot_free + slot, BA_RLX_AGENT);
             if (uni((int)f)) {
-                if (is_lane(0)) __hip_atomic_store(bp.slot_free + slot, 0u, BA_RLX_AGENT);
+                if (is_lane(0)) __hip_atomic_store(coldp()->slot_free + slot, 0u, BA_RLX_AGENT);
                 return true;
             }
             __builtin_amdgcn_s_sleep(64);
@@ -409,22 +423,22 @@ struct Aligner {
     // Publish a finished trace stack: plain stores -> release fence -> drained -> queue entry (guide G16 flag form).
     __device__ __forceinline__ void hand_off(uint32_t slot, uint32_t pair, uint32_t end_i, uint32_t end_j, bool null_task = false) {
         if (is_lane(0)) {
-            if (!null_task) bp.slot_info[slot] = SlotInfo{pair, nblocks, end_i, end_j};
-            bp.status[pair] = status;
+            if (!null_task) coldp()->slot_info[slot] = SlotInfo{pair, nblocks, end_i, end_j};
+            coldp()->status[pair] = status;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (is_lane(0)) {
-            const uint32_t tpos = __hip_atomic_fetch_add(bp.tb_ctrl, 1u, BA_RLX_AGENT) & bp.tb_qmask;
-            while (__hip_atomic_load(bp.tb_queue + tpos, BA_RLX_AGENT) != 0) __builtin_amdgcn_s_sleep(8);
-            __hip_atomic_store(bp.tb_queue + tpos, null_task ? (0x80000000u | pair) : slot + 1, BA_RLX_AGENT);
+            const uint32_t tpos = __hip_atomic_fetch_add(coldp()->tb_ctrl, 1u, BA_RLX_AGENT) & coldp()->tb_qmask;
+            while (__hip_atomic_load(coldp()->tb_queue + tpos, BA_RLX_AGENT) != 0) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(coldp()->tb_queue + tpos, null_task ? (0x80000000u | pair) : slot + 1, BA_RLX_AGENT);
         }
     }
 
     __device__ void run(uint32_t pair, uint32_t slot, bool batch_traceback) {
-        q = bp.pool + bp.q_off[pair]; r = bp.pool + bp.r_off[pair];
-        qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
-        const uint32_t min_size = bp.min_size, max_size = bp.max_size;
+        q = coldp()->pool + coldp()->q_off[pair]; r = coldp()->pool + coldp()->r_off[pair];
+        qlen = coldp()->q_len[pair]; rlen = coldp()->r_len[pair];
+        const uint32_t min_size = h_min_size, max_size = h_max_size;
         // scratch reset (scan_block.rs:1322-1339): borders to MIN = 0. The checkpoint copies need no reset: they are
         // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
         lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size);
@@ -477,7 +491,7 @@ struct Aligner {
                 seqV = q; seqC = r; lenV = qlen; lenC = rlen; ri = si; rj = sj + prev_size; rw = block_size - prev_size; rh = block_size;
                 Dc = L.D_col; Cc = L.C_col; Dr = L.D_row + prev_size; Rr = L.R_row + prev_size; right = true;
             }
-            const bool fast = dir != DIR_GROW && rh <= 128 && !(bp.flags & 0x100u);   // bit 8: development switch, generic path only
+            const bool fast = dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u);   // bit 8: development switch, generic path only
             if (fast) {   // before any store of this step: the memory counter is in-order
                 // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
                 const int lane = lane_id();
@@ -569,7 +583,7 @@ struct Aligner {
                 y_drop_iter = 0;
             }
             if (XDROP) {
-                if (off_max < best_max - bp.x_drop) {
+                if (off_max < best_max - h_x_drop) {
                     if (x_drop_iter < 1) x_drop_iter++;   // X_DROP_ITER = 2
                     else break;
                 } else x_drop_iter = 0;
@@ -613,7 +627,7 @@ struct Aligner {
         BA_TADD(prof, 15, tr0, tr1);
 #ifdef BA_TIMING
         prof[16] += steps;
-        if (bp.prof && is_lane(0)) for (int k = 0; k < 17; k++) atomicAdd(bp.prof + k, prof[k]);
+        if (coldp()->prof && is_lane(0)) for (int k = 0; k < 17; k++) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
         int score; uint32_t ri, rj;
         if (XDROP) { score = best_max; ri = best_i; rj = best_j; }
@@ -626,31 +640,31 @@ struct Aligner {
         uint32_t ncig = 0;
         if (TRACE && batch_traceback) {
             if (is_lane(0)) {
-                bp.score[pair] = score; bp.query_idx[pair] = ri; bp.reference_idx[pair] = rj;
-                if (bp.cells) bp.cells[pair] = cells;
-                if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
+                coldp()->score[pair] = score; coldp()->query_idx[pair] = ri; coldp()->reference_idx[pair] = rj;
+                if (coldp()->cells) coldp()->cells[pair] = cells;
+                if (coldp()->nblocks_out) coldp()->nblocks_out[pair] = nblocks;
             }
             hand_off(slot, pair, ri, rj);
             return;
         }
-        if (TRACE && bp.cig_ops && !status) {
+        if (TRACE && coldp()->cig_ops && !status) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             if (is_lane(0)) {
                 uint32_t st = 0;
-                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, bp.flags & F_CIGAR_EQ, bp.cig_ops,
-                                 bp.cig_off[pair], bp.cig_off[pair + 1], &st);
+                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, h_flags & F_CIGAR_EQ, coldp()->cig_ops,
+                                 coldp()->cig_off[pair], coldp()->cig_off[pair + 1], &st);
                 status |= st;
             }
         }
         if (is_lane(0)) {
-            bp.score[pair] = score; bp.query_idx[pair] = ri; bp.reference_idx[pair] = rj;
-            if (bp.cig_len) bp.cig_len[pair] = ncig;
-            if (bp.cells) bp.cells[pair] = cells;
-            if (bp.status) bp.status[pair] = status;
-            if (bp.nblocks_out) bp.nblocks_out[pair] = nblocks;
-            if (bp.slot_out) bp.slot_out[pair] = slot;
+            coldp()->score[pair] = score; coldp()->query_idx[pair] = ri; coldp()->reference_idx[pair] = rj;
+            if (coldp()->cig_len) coldp()->cig_len[pair] = ncig;
+            if (coldp()->cells) coldp()->cells[pair] = cells;
+            if (coldp()->status) coldp()->status[pair] = status;
+            if (coldp()->nblocks_out) coldp()->nblocks_out[pair] = nblocks;
+            if (coldp()->slot_out) coldp()->slot_out[pair] = slot;
         }
     }
 };
