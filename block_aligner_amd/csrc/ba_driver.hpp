@@ -151,16 +151,17 @@ struct TbLane {
     uint64_t wp, lo;
     const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
     uint32_t bi, bj, tbase, nch, nl; bool right, in_rect;
-    // look-ahead state: the next rectangle record, a 4-lane x 2-column-group window of this rectangle's trace words,
+    // look-ahead state: the next rectangle record, a 5-lane x 2-column-group window of this rectangle's trace words,
     // and 16-byte windows of both sequences -- so that most cells are walked from registers
     uint4 nrec; bool nrec_ok;
-    uint32_t tw[8]; uint32_t tw_lane0; bool tw_ok;
+    uint32_t tw[10]; uint32_t tw_lane0; bool tw_ok;
     uint32_t qw[4], rw[4]; uint32_t qw0, rw0;     // windows cover [qw0, qw0 + 16) and [rw0, rw0 + 16); 0xffffffff = empty
 };
 
 __device__ __forceinline__ uint32_t sel4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t k) {
     return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
 }
+__device__ __forceinline__ uint32_t sel5(const uint32_t* w, uint32_t k) { return k == 4 ? w[4] : sel4(w[0], w[1], w[2], w[3], k); }
 __device__ __forceinline__ void tb_emit(TbLane& t, uint32_t* __restrict__ out) {
     if (t.run_len) {
         if (t.wp == t.lo) { t.status |= ST_CIGAR_OVERFLOW; t.i = t.j = 0; return; }
@@ -171,7 +172,9 @@ __device__ __forceinline__ void tb_fail(TbLane& t) { t.status |= ST_TRACEBACK_LO
 
 // One iteration of scan_block.rs:1576-1670 for one lane: either move to the next rectangle (and issue the loads that
 // will let it be walked from registers) or walk up to four cells. At most one round of memory latency per call.
-__device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict__ out) {
+__device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict__ out, unsigned long long* tacc = nullptr) {
+    BA_TSTAMP(ts0);
+    bool fresh = true;   // may this call still issue a direct (non-window) load?
     if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
         if (t.bidx == 0) { tb_fail(t); return; }
         t.bidx--;
@@ -189,12 +192,12 @@ __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict
         if (t.in_rect) {
             if (t.nch == 1 && ncol == 8) {   // a shift step: both column groups of the 4 lanes ending at the entry cell
                 const uint32_t v = t.right ? t.i - t.bi : t.j - t.bj, lc = v >> 1;
-                t.tw_lane0 = lc >= 3 ? lc - 3 : 0;
+                t.tw_lane0 = lc >= 4 ? lc - 4 : 0;
                 const uint32_t* base = t.trace + t.tbase;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < 5; k++) {
                     const uint32_t l = min(t.tw_lane0 + k, t.nl - 1);
-                    t.tw[k] = base[l]; t.tw[4 + k] = base[t.nl + l];
+                    t.tw[k] = base[l]; t.tw[5 + k] = base[t.nl + l];
                 }
                 t.tw_ok = true;
             }
@@ -213,18 +216,25 @@ __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict
                 }
             }
         }
-        return;
+        if (!t.in_rect) return;
+        fresh = false;    // this call already spent its round of memory latency on the window loads
     }
-    for (int s = 0; s < 4; s++) {
+#ifdef BA_TIMING
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+    if (tacc) { tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; }
+#endif
+    for (int s = 0; s < 12; s++) {
         if (!(t.i > 0 || t.j > 0) || !(t.i >= t.bi && t.j >= t.bj)) break;
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
         const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
         const uint32_t lc = (v & 127) >> 1;
         uint32_t word;
-        if (t.tw_ok && lc >= t.tw_lane0 && lc < t.tw_lane0 + 4) {
+        if (t.tw_ok && lc >= t.tw_lane0 && lc < t.tw_lane0 + 5) {
             const uint32_t k = lc - t.tw_lane0;
-            word = (w >> 2) ? sel4(t.tw[4], t.tw[5], t.tw[6], t.tw[7], k) : sel4(t.tw[0], t.tw[1], t.tw[2], t.tw[3], k);
-        } else if (s == 0) {
+            word = (w >> 2) ? sel5(t.tw + 5, k) : sel5(t.tw, k);
+        } else if (s == 0 && fresh) {
             word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
         } else break;
         const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 "differs", bit 3 "equal"
@@ -236,7 +246,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict
             if (t.qw0 != 0xffffffffu && qo < 16 && t.rw0 != 0xffffffffu && ro < 16) {
                 qb = (sel4(t.qw[0], t.qw[1], t.qw[2], t.qw[3], qo >> 2) >> ((qo & 3) * 8)) & 0xff;
                 rb = (sel4(t.rw[0], t.rw[1], t.rw[2], t.rw[3], ro >> 2) >> ((ro & 3) * 8)) & 0xff;
-            } else if (s == 0) { qb = t.q[t.i]; rb = t.r[t.j]; }
+            } else if (s == 0 && fresh) { qb = t.q[t.i]; rb = t.r[t.j]; }
             else break;
             op = qb == rb ? 2 : 3;
         }
@@ -254,7 +264,19 @@ __device__ void traceback_consumer(const BatchParams& bp) {
     TbLane t{};
     const bool eq = bp.flags & F_CIGAR_EQ;
     uint32_t* head = bp.tb_ctrl + 32;
+    // A walk is a long dependent chain of short instructions sharing its SIMD with VALU-saturating fill waves; without
+    // priority it gets a quarter of the issue slots and every pending walk pins a whole trace slot meanwhile.
+    __builtin_amdgcn_s_setprio(3);
+#ifdef BA_TIMING
+    unsigned long long c_sec[3] = {};
+    unsigned long long c_iters = 0, c_walk_lanes = 0, c_walk_iters = 0, c_poll_iters = 0, c_walk_ticks = 0, c_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+#ifdef BA_TIMING
+        const unsigned long long it0 = __builtin_amdgcn_s_memtime();
+        const bool any_walk = __any(phase == WALK);
+        c_iters++; c_walk_lanes += __popcll(__ballot(phase == WALK)); c_walk_iters += any_walk; c_poll_iters += __any(phase == WAIT);
+#endif
         if (phase == IDLE) {
             claimed = __hip_atomic_fetch_add(head, 1u, BA_RLX_AGENT);
             phase = claimed >= bp.n ? RETIRED : WAIT;     // every pair yields exactly one task
@@ -288,7 +310,13 @@ __device__ void traceback_consumer(const BatchParams& bp) {
                 phase = WALK;
             }
         } else if (phase == WALK) {
+#ifdef BA_TIMING
+            const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, c_sec);
+            c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
+#else
             if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops);
+#endif
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
                 bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
@@ -297,9 +325,20 @@ __device__ void traceback_consumer(const BatchParams& bp) {
                 phase = IDLE;
             }
         }
+#ifdef BA_TIMING
+        if (any_walk) c_walk_ticks += __builtin_amdgcn_s_memtime() - it0;
+#endif
         if (__all(phase == RETIRED)) break;
         if (!__any(phase == WALK)) __builtin_amdgcn_s_sleep(32);               // nothing to walk: poll gently
     }
+#ifdef BA_TIMING
+    if (bp.prof && is_lane(0)) {
+        atomicAdd(bp.prof + 20, c_iters); atomicAdd(bp.prof + 21, c_walk_lanes); atomicAdd(bp.prof + 22, c_walk_iters);
+        atomicAdd(bp.prof + 23, c_poll_iters); atomicAdd(bp.prof + 24, c_walk_ticks);
+        atomicAdd(bp.prof + 25, __builtin_amdgcn_s_memtime() - c_t0); atomicAdd(bp.prof + 26, 1ull);
+        atomicAdd(bp.prof + 27, c_sec[0]); atomicAdd(bp.prof + 28, c_sec[1]); atomicAdd(bp.prof + 29, c_sec[2]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ driver
@@ -716,15 +755,17 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         }
         fc.vconst = pk(v[0], v[1]);
     }
-    // Traceback workgroups take the LOWEST block ids: blocks are dispatched in id order, so they are resident before
-    // any fill workgroup can wait on them even if the grid turns out to be larger than what fits at once.
-    const uint32_t n_tb_wgs = gridDim.x - bp.n_fill_wgs;
-    const bool batch_traceback = TRACE && n_tb_wgs > 0;
-    if (TRACE && blockIdx.x < n_tb_wgs) {
+    // Traceback waves are spread over the chip (wave 0 of every tb_stride-th workgroup): a walk is all divergent
+    // loads, and eight of them on one CU would queue behind that CU's single memory pipeline.
+    const uint32_t stride = bp.tb_stride;
+    const bool batch_traceback = TRACE && stride > 0;
+    if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         traceback_consumer(bp);
         return;
     }
-    const uint32_t fill_wave = (blockIdx.x - n_tb_wgs) * WAVES_PER_WG + (uint32_t)wave;
+    // dense index among the fill waves (consumer waves of this and earlier workgroups skipped)
+    const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
+    const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
     uint32_t turn = 0;
     for (;;) {
         uint32_t pair = 0;

@@ -161,7 +161,7 @@ struct BaBatch {
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace, blocks, ckpt, counter,
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
-    uint32_t n_fill_wgs = 0, slots_per_wave = 1, tb_qsize = 1;
+    uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false;
     BatchParams params() const {
@@ -179,7 +179,7 @@ struct BaBatch {
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
         bp.ckpt = ckpt.as<short>();
-        bp.n_fill_wgs = n_fill_wgs; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots;
+        bp.tb_stride = tb_stride; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots;
         bp.tb_qmask = tb_qsize - 1;
         bp.tb_queue = tb_queue.as<uint32_t>(); bp.tb_ctrl = tb_ctrl.as<uint32_t>();
         bp.slot_free = slot_free.as<uint32_t>(); bp.slot_info = slot_info.as<ba::SlotInfo>();
@@ -302,23 +302,26 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
     // TRACE batches big enough to keep them busy get dedicated traceback workgroups (ba_driver.hpp traceback_consumer)
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
-    b->n_fill_wgs = b->grid; b->slots_per_wave = 1;
+    b->tb_stride = 0; b->slots_per_wave = 1;
+    b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
     if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
-        uint32_t cons = b->grid >= 32 ? b->grid / 16 : 1;
-        if (const char* env = getenv("BA_TB_WGS")) { int v = atoi(env); if (v > 0 && (uint32_t)v < b->grid) cons = (uint32_t)v; }
-        b->n_fill_wgs = b->grid - cons;
+        // 3 is coprime with the 8 XCDs the workgroups are dealt over, so the traceback waves land on every XCD
+        uint32_t stride = b->grid >= 32 ? 3 : 2;
+        if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
+        b->tb_stride = stride;
+        b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
-        uint32_t spw = 3;
+        uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (186 GB at config 3)
         if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
-        while (spw > 1 && fixed + per_slot * spw * b->n_fill_wgs * ba::WAVES_PER_WG > free_b * 9 / 10) spw--;
+        while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         b->slots_per_wave = spw;
     }
-    b->slots = b->n_fill_wgs * ba::WAVES_PER_WG * b->slots_per_wave;
+    b->slots = b->n_fill_waves * b->slots_per_wave;
     {
-        const uint64_t lanes = (uint64_t)(b->grid - b->n_fill_wgs) * ba::WAVES_PER_WG * 64;
+        const uint64_t lanes = b->tb_stride ? (uint64_t)((b->grid + b->tb_stride - 1) / b->tb_stride) * 64 : 0;
         uint64_t need_q = std::max<uint64_t>(lanes, b->slots);
         uint32_t qs = 1;
         while (qs < need_q) qs <<= 1;

@@ -47,7 +47,7 @@ struct BatchParams {
     uint32_t* work_counter;
     unsigned long long* prof;    // development (-DBA_TIMING builds): per-phase cycle sums, 32 slots
     // in-launch hand-off of finished trace stacks from fill waves to traceback lanes (TRACE batches)
-    uint32_t n_fill_wgs;         // workgroups [0, n_fill_wgs) fill, the rest walk tracebacks
+    uint32_t tb_stride;          // 0: fill waves walk their own tracebacks. s > 0: wave 0 of every s-th workgroup walks tracebacks
     uint32_t slots_per_wave;     // trace arena slots owned by each fill wave (a slot is busy until its traceback is done)
     uint32_t n_slots;
     uint32_t tb_qmask;           // ring size - 1 (power of two >= max(traceback lanes, n_slots): live claims never share a position)

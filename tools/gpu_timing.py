@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Phase timers from a -DBA_TIMING build (make -C block_aligner_amd/csrc EXTRA=-DBA_TIMING OBJ=_build_t LIB=../lib/libblock_aligner_hip_timing.so).
-usage: gpu_timing.py <pairs> <trace 0|1>"""
+usage: gpu_timing.py <pairs> <trace 0|1> [max_block]"""
 import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from block_aligner_amd import hip as H, scores as S, synth
 H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), "libblock_aligner_hip_timing.so")
 n, trace = int(sys.argv[1]), int(sys.argv[2])
+maxb = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 pairs = synth.make_pairs(n, 10000, 1000, 500, synth.DNA, seed=1234)
 mode = H.X_DROP | ((H.TRACE | H.CIGAR_EQ) if trace else 0)
-b = H.BatchAligner(S.NucMatrix.new_simple(2, -3), (-5, -1), (128, 1024), 100, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+b = H.BatchAligner(S.NucMatrix.new_simple(2, -3), (-5, -1), (128, maxb), 100, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
 b.run(); ms = b.run()
 prof = np.zeros(32, np.uint64)
 H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
@@ -20,3 +21,10 @@ tot = float(prof[15]); steps = float(prof[16])
 print(f"pairs={n} trace={trace} kernel_ms={ms:.2f} steps/pair={steps/n:.0f} cycles/pair={tot/n:.0f} (s_memtime ticks)")
 for k, v in names.items():
     print(f"  {v:28s} {float(prof[k])/n:12.0f} ticks/pair  {100*float(prof[k])/tot:5.1f}%   {float(prof[k])/max(steps,1):8.1f} ticks/step")
+if prof[26]:
+    w = float(prof[26])
+    print(f"traceback waves={w:.0f}: iterations/wave={prof[20]/w:.0f} walking iterations/wave={prof[22]/w:.0f} polling iterations/wave={prof[23]/w:.0f}")
+    print(f"  mean walking lanes per walking iteration={float(prof[21])/max(float(prof[22]),1):.1f}  ticks per walking iteration={float(prof[24])/max(float(prof[22]),1):.0f}  wave lifetime ticks={prof[25]/w:.0f}")
+    print(f"  lane-iterations per walk={float(prof[21])/n:.0f}")
+    wi = max(float(prof[22]), 1)
+    print(f"  per walking iteration: rect entry + load issue={float(prof[27])/wi:.0f}  wait for loads={float(prof[28])/wi:.0f}  whole tb_step={float(prof[29])/wi:.0f} ticks")
