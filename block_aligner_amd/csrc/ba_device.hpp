@@ -152,17 +152,27 @@ struct FillConsts {
     int gap_extend;
 };
 
+// one pair's AAProfile image (layout in ba_params.h)
+struct ProfileView {
+    const signed char* pos_aa; const short* aa_pos; const short* goC; const short* clC; const short* goR;
+    uint32_t P;
+};
+// special alignment modes of a rectangle (scan_block.rs:89): handled on the generic path only
+enum : uint32_t { SP_LOCAL = 1, SP_FQS_ROW0 = 2, SP_FQE = 4 };
+struct FqeOut { int M; int j; };   // FREE_QUERY_END_GAPS: D_max / argmax_j of vector lane (query length % 16)
+
 // per-chunk substitution-score lookup state, set up once per rectangle from the chunk's two vector-axis bytes
 template <int KIND> struct ScoreKey;
 template <> struct ScoreKey<KIND_NUC> { int off; };          // byte offset of the (a, b) pair inside one 1 KB table row
 template <> struct ScoreKey<KIND_AA> { int a, b; };          // column indices (0..31)
 template <> struct ScoreKey<KIND_BYTES> { int a, b; };       // raw bytes
+template <> struct ScoreKey<KIND_PROFILE> { int a, b; };     // query residues (0..31), used by right rectangles only
 
 template <int KIND>
 __device__ __forceinline__ ScoreKey<KIND> make_key(int a, int b) {
     ScoreKey<KIND> k;
     if constexpr (KIND == KIND_NUC) k.off = (((a & 15) << 4) | (b & 15)) << 2;
-    else if constexpr (KIND == KIND_AA) { k.a = a & 31; k.b = b & 31; }
+    else if constexpr (KIND == KIND_AA || KIND == KIND_PROFILE) { k.a = a & 31; k.b = b & 31; }
     else { k.a = a; k.b = b; }
     return k;
 }
@@ -173,24 +183,30 @@ __device__ __forceinline__ int fetch_score(const char* table, const ScoreKey<KIN
     else if constexpr (KIND == KIND_AA) {
         const signed char* row = (const signed char*)table + cb * 32;
         return pk(row[k.a], row[k.b]);
-    } else {
+    } else if constexpr (KIND == KIND_BYTES) {
         const signed char* t = (const signed char*)table;
         return pk(k.a == cb ? t[0] : t[1], k.b == cb ? t[0] : t[1]);
-    }
+    } else return 0;   // PROFILE: scores come from the profile image, see profile_score
 }
+// unaligned (2-byte aligned) load of two consecutive i16
+__device__ __forceinline__ int load_pair_i16(const short* p) { int v; __builtin_memcpy(&v, p, 4); return v; }
 
 // ------------------------------------------------------------------ block fill
 // Fills a width x height rectangle column by column (scan_block.rs:1083-1228; for a down shift the caller swaps the
 // sequences exactly as the reference does). NCH = chunks of 128 cells per column; below 128 cells NCH = 1 and only
 // height / 2 lanes are active. width is a multiple of 8.
-template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false>
+// PDIR (KIND_PROFILE only): 1 = vectors along the query, one profile position per column (place_block_profile_right,
+// scan_block.rs:612-783 with $right = true); 2 = vectors along the profile, one query residue per column.
+template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false, int PDIR = 0>
 __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
                                            short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out,
-                                           unsigned long long& cells, FastIO* fs = nullptr, unsigned long long* tacc_prof = nullptr) {
+                                           unsigned long long& cells, FastIO* fs = nullptr, unsigned long long* tacc_prof = nullptr,
+                                           uint32_t sp = 0, FqeOut* fq = nullptr, const ProfileView* pv = nullptr) {
     BA_TSTAMP(tp0);
     static_assert(!FAST || NCH == 1, "the fast path handles single-chunk steps");
+    static_assert((KIND == KIND_PROFILE) == (PDIR != 0) && !(FAST && PDIR), "profile rectangles take the generic path with a direction");
     const int lane = lane_id();
     const int nl = NCH > 1 ? 64 : (int)(height >> 1);   // active lanes
     const bool active = lane < nl;
@@ -201,6 +217,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     __builtin_amdgcn_wave_barrier();
     int d[NCH], c[NCH], dmax[NCH], jlast[NCH], tacc[NCH];
     ScoreKey<KIND> key[NCH];
+    int fqM = 0, fqJ = 0;            // SP_FQE: running max / last column of the tracked vector lane
     const int offa = splat(off_add);
     int pasD = 0, pasR = 0;          // FAST: passive border entries [2l+8, 2l+9], re-based
     const bool pas_in = FAST && lane + 4 < nl;   // this lane's shifted passive pair comes from the old border (else: the 8 new cells)
@@ -208,8 +225,37 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         ca[ch] = 0; cb_[ch] = 0;
-        if (!FAST && active) { ca[ch] = seqV[start_i + ch * 128 + 2 * lane]; cb_[ch] = seqV[start_i + ch * 128 + 2 * lane + 1]; }
+        if (!FAST && PDIR != 2 && active) { ca[ch] = seqV[start_i + ch * 128 + 2 * lane]; cb_[ch] = seqV[start_i + ch * 128 + 2 * lane + 1]; }
     }
+    // profile, vectors along the profile: per-position gap costs of this lane's two cells, swapped as the reference
+    // swaps them for its "down" orientation (scan_block.rs:671-682)
+    int goCv[PDIR == 2 ? NCH : 1], goRv[PDIR == 2 ? NCH : 1], clRv[PDIR == 2 ? NCH : 1];
+    if constexpr (PDIR == 2) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const uint32_t row = start_i + ch * 128 + 2 * lane;
+            goCv[ch] = goRv[ch] = clRv[ch] = 0;
+            if (active) {
+                goCv[ch] = adds(load_pair_i16(pv->goR + row), fc.ge2);
+                goRv[ch] = load_pair_i16(pv->goC + row);
+                clRv[ch] = load_pair_i16(pv->clC + row);
+            }
+        }
+    }
+    // profile, vectors along the query: this column's (and the next one's) per-position gap costs, wave-uniform
+    int col_goC = 0, col_clC = 0, col_goR = 0, nxt_goC = 0, nxt_clC = 0, nxt_goR = 0;
+    auto profile_col_gaps = [&](uint32_t idx, int& goC, int& clC, int& goR) {
+        goC = splat(clamp16((int)pv->goC[idx] + fc.gap_extend)); clC = splat((int)pv->clC[idx]); goR = splat((int)pv->goR[idx]);
+    };
+    // packed scores of this lane's two cells in every chunk for one column of a profile rectangle
+    auto profile_score = [&](uint32_t col, int cbyte, int ch) -> int {
+        if constexpr (PDIR == 1) {
+            const signed char* row = pv->pos_aa + (uint64_t)col * 32;
+            return active ? pk(row[key[ch].a], row[key[ch].b]) : 0;
+        } else {
+            return active ? load_pair_i16(pv->aa_pos + (uint64_t)(cbyte & 31) * pv->P + start_i + ch * 128 + 2 * lane) : 0;
+        }
+    };
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         const int r0 = ch * 128 + 2 * lane;
@@ -228,14 +274,17 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         dmax[ch] = 0; jlast[ch] = 0; tacc[ch] = 0;
         key[ch] = make_key<KIND>(a, b);
     }
-    const bool break_armed = !XDROP && (start_i + height > lenV);
+    const bool break_armed = !XDROP && !(sp & SP_FQE) && (start_i + height > lenV);
+    const int rz2 = splat(rel_zero);
+    const uint32_t zwords = (width >> 2) * (uint32_t)(NCH * nl);   // SP_LOCAL: the zero mask follows the rectangle's trace words
     int corner_cur = corner;
-    int cvec = FAST ? fs->col_chars : (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
+    int cvec = FAST ? fs->col_chars : (PDIR == 1 ? 0 : (int)seqC[start_j + (lane & 7)]);   // 8 column bytes at a time, one per lane (lanes 0..7)
     int sc_next[NCH];
     {
         const int cb0 = __builtin_amdgcn_readlane(cvec, 0);
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) sc_next[ch] = fetch_score<KIND>(L.table, key[ch], cb0);
+        for (int ch = 0; ch < NCH; ch++) sc_next[ch] = PDIR ? profile_score(start_j, cb0, ch) : fetch_score<KIND>(L.table, key[ch], cb0);
+        if constexpr (PDIR == 1) profile_col_gaps(start_j, nxt_goC, nxt_clC, nxt_goR);
     }
     BA_TSTAMP(tp1);
     const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
@@ -244,13 +293,17 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sc[ch] = sc_next[ch];
         // scores of the next column are fetched while this one is computed
-        if (!FAST && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
+        if (!FAST && PDIR != 1 && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
+        if constexpr (PDIR == 1) { col_goC = nxt_goC; col_clC = nxt_clC; col_goR = nxt_goR; }
         if (!(FAST && j == 7)) {   // (last column of a shift step: nothing left to fetch)
             const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
 #pragma unroll
-            for (int ch = 0; ch < NCH; ch++) sc_next[ch] = fetch_score<KIND>(L.table, key[ch], cbn);
+            for (int ch = 0; ch < NCH; ch++) sc_next[ch] = PDIR ? profile_score(start_j + j + 1, cbn, ch) : fetch_score<KIND>(L.table, key[ch], cbn);
+            if constexpr (PDIR == 1) profile_col_gaps(start_j + j + 1, nxt_goC, nxt_clC, nxt_goR);
         }
-        const bool first_cell = j == 0 && start_i == 0 && start_j == 0;
+        // cell (0,0) -- or, with free query start gaps, every cell of row 0 -- starts from the relative zero
+        // (scan_block.rs:1130-1136)
+        const bool first_cell = (j == 0 && start_i == 0 && start_j == 0 && !(sp & SP_LOCAL)) || ((sp & SP_FQS_ROW0) && start_i == 0);
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
@@ -269,10 +322,12 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 const int v0 = __builtin_amdgcn_readlane(d11, 0);
                 d11 = set_lane0(d11, (v0 & (int)0xffff0000) | (rel_zero & 0xffff));
             }
-            const int copen = adds(d[ch], fc.go2);
+            if (!FAST && (sp & SP_LOCAL)) d11 = vmax(d11, rz2);   // a local alignment may start anywhere (scan_block.rs:1134-1136)
+            const int copen = adds(d[ch], PDIR == 0 ? fc.go2 : (PDIR == 1 ? col_goC : goCv[ch]));
             const int cn = vmax(adds(c[ch], fc.ge2), copen);
-            d11 = vmax(d11, cn);
-            const int x = adds(d11, fc.ome2);                                         // D11_open
+            const int cend = PDIR == 1 ? adds(cn, col_clC) : cn;                       // C11_end (scan_block.rs:697-701)
+            d11 = vmax(d11, cend);
+            const int x = adds(d11, PDIR == 0 ? fc.ome2 : (PDIR == 1 ? col_goR : goRv[ch]));   // D11_open
             // R11: in-lane step, then the 64-lane scan on values re-based by lane * 2g
             const s16x2 t2 = as_s(adds(x, fc.ge2));
             int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
@@ -284,9 +339,10 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             const s16x2 cs = as_s(cin);
             r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst);
             if (NCH > 1) carry_r = (int)(short)(__builtin_amdgcn_readlane(r, 63) >> 16);
-            const int dn = vmax(d11, r);
+            const int rend = PDIR == 2 ? adds(r, clRv[ch]) : r;                        // R11_end (scan_block.rs:712-716)
+            const int dn = vmax(d11, rend);
             if (TRACE) {
-                const int nC = neq01(dn, cn, fc.ones), nR = neq01(dn, r, fc.ones);
+                const int nC = neq01(dn, cend, fc.ones), nR = neq01(dn, rend, fc.ones);
                 const int nCo = neq01(cn, copen, fc.ones), eRo = eq01(r, x, fc.ones);
                 // "R opened" belongs to the cell below it (scan_block.rs:1179-1182): stored as an "equal" bit so the
                 // column top needs no fill value
@@ -297,6 +353,21 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 nib = pk_mad(nCo, 0x00040004, nib);
                 nib = pk_mad(eRs, 0x00080008, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
+                if (!FAST && (sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
+                    trace_out[zwords + (j * NCH + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);
+            }
+            if (!FAST && (sp & SP_FQE)) {
+                // D_max / argmax_j of vector lane k = len % 16 in the reference's visiting order (columns outer, vectors
+                // inner; scan_block.rs:1189-1201): a running max over that lane's cells of this column, seeded with the
+                // max of all earlier columns; a tracked vector records the column when it ties or raises it
+                const int k = (int)(lenV & 15);
+                const bool mine = active && (lane & 7) == (k >> 1);
+                const int v = mine ? ((k & 1) ? (int)as_s(dn).y : (int)as_s(dn).x) : -32768;
+                const int pm = wave_prefix_max(v);
+                const uint32_t vec_base = start_i + ch * 128 + ((2 * lane) & ~15);
+                const bool hit = mine && vec_base + 16 > lenV && v == max(pm, fqM);
+                if (__any(hit)) fqJ = (int)j;
+                fqM = max(fqM, __builtin_amdgcn_readlane(pm, 63));
             }
             dmax[ch] = vmax(dmax[ch], dn);
             if (XDROP) {   // jlast = 1 + last column whose cell ties or raises its row's running max
@@ -334,6 +405,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         for (uint32_t j = 0; j < width; j++) { if (!column(j)) break; }
     }
     BA_TSTAMP(tp2);
+    if (!FAST && fq) { fq->M = fqM; fq->j = fqJ; }
     // ---- write the vector-axis border back
     if (active) {
 #pragma unroll

@@ -93,13 +93,15 @@ __device__ __forceinline__ Move tb_lut(bool right_blk, uint32_t t, uint32_t t2, 
 // Walk back from (i, j); emit run-length ops right-aligned into [out_lo, out_hi). Returns run count, or
 // sets *status on failure. Executed by lane 0 only. (scan_block.rs:1482-1672)
 __device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32_t nblocks, const uint32_t* __restrict__ trace,
-                                     uint32_t i, uint32_t j, const uint8_t* __restrict__ q, const uint8_t* __restrict__ r, bool eq,
+                                     uint32_t i, uint32_t j, const uint8_t* __restrict__ q, const uint8_t* __restrict__ r, uint32_t flags,
                                      uint32_t* __restrict__ out, uint64_t out_lo, uint64_t out_hi, uint32_t* status) {
+    const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
+    bool stop = false;               // LOCAL_START / FREE_QUERY_START_GAPS end the walk before (0, 0)
     uint64_t wp = out_hi;          // next free slot is wp - 1
     uint32_t run_op = 0, run_len = 0;
     uint32_t table = 0;
     uint32_t bidx = nblocks;
-    while (i > 0 || j > 0) {
+    while ((i > 0 || j > 0) && !stop) {
         BlockRec br;
         for (;;) {
             if (bidx == 0) { *status |= ST_TRACEBACK_LOST; return 0; }
@@ -115,6 +117,11 @@ __device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32
             const uint32_t ci = i - br.i, cj = j - br.j;
             const uint32_t v = right_blk ? ci : cj, w = right_blk ? cj : ci;
             const uint32_t chunk = v >> 7, lane = (v & 127) >> 1;
+            if (right_blk && fqs && i == 0) { stop = true; break; }                     // scan_block.rs:1597-1599
+            if (local && table == 0) {                                                   // scan_block.rs:1604-1611
+                const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
+                if ((z >> ((v & 1) * 16)) & 1) { stop = true; break; }
+            }
             const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
             const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 stored as "differs", bit 3 as "equal"
             const Move m = tb_lut(right_blk, nib & 3, nib >> 2, table);
@@ -150,7 +157,7 @@ struct TbLane {
     uint32_t slot, pair, i, j, table, bidx, run_op, run_len, status;
     uint64_t wp, lo;
     const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
-    uint32_t bi, bj, tbase, nch, nl; bool right, in_rect;
+    uint32_t bi, bj, tbase, zoff, nch, nl; bool right, in_rect;
     // look-ahead state: the next rectangle record, a 5-lane x 2-column-group window of this rectangle's trace words,
     // and 16-byte windows of both sequences -- so that most cells are walked from registers
     uint4 nrec; bool nrec_ok;
@@ -172,7 +179,8 @@ __device__ __forceinline__ void tb_fail(TbLane& t) { t.status |= ST_TRACEBACK_LO
 
 // One iteration of scan_block.rs:1576-1670 for one lane: either move to the next rectangle (and issue the loads that
 // will let it be walked from registers) or walk up to four cells. At most one round of memory latency per call.
-__device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict__ out, unsigned long long* tacc = nullptr) {
+__device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned long long* tacc = nullptr) {
+    const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
     BA_TSTAMP(ts0);
     bool fresh = true;   // may this call still issue a direct (non-window) load?
     if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
@@ -184,13 +192,14 @@ __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict
         t.bi = rec.x; t.bj = rec.y;
         const uint32_t h = rec.z & 0xffffu, w = rec.z >> 16;
         t.in_rect = t.i >= t.bi && t.j >= t.bj;
+        t.zoff = h * w / 8;
         t.right = rec.w >> 31;
         t.tbase = rec.w & 0x7fffffffu;
         const uint32_t Hv = t.right ? h : w, ncol = t.right ? w : h;
         t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
         t.tw_ok = false;
         if (t.in_rect) {
-            if (t.nch == 1 && ncol == 8) {   // a shift step: both column groups of the 4 lanes ending at the entry cell
+            if (t.nch == 1 && ncol == 8 && !local) {   // a shift step: both column groups of the 4 lanes ending at the entry cell
                 const uint32_t v = t.right ? t.i - t.bi : t.j - t.bj, lc = v >> 1;
                 t.tw_lane0 = lc >= 4 ? lc - 4 : 0;
                 const uint32_t* base = t.trace + t.tbase;
@@ -230,8 +239,17 @@ __device__ __forceinline__ void tb_step(TbLane& t, bool eq, uint32_t* __restrict
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
         const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
         const uint32_t lc = (v & 127) >> 1;
+        if (t.right && fqs && t.i == 0) { t.i = t.j = 0; break; }                       // scan_block.rs:1597-1599
         uint32_t word;
-        if (t.tw_ok && lc >= t.tw_lane0 && lc < t.tw_lane0 + 5) {
+        if (local) {   // zero mask first (scan_block.rs:1604-1611); no register window in this mode: one cell per call
+            if (!(s == 0 && fresh)) break;
+            const uint32_t widx = t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc;
+            word = t.trace[widx];
+            if (t.table == 0) {
+                const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
+                if ((z >> ((v & 1) * 16)) & 1) { t.i = t.j = 0; break; }
+            }
+        } else if (t.tw_ok && lc >= t.tw_lane0 && lc < t.tw_lane0 + 5) {
             const uint32_t k = lc - t.tw_lane0;
             word = (w >> 2) ? sel5(t.tw + 5, k) : sel5(t.tw, k);
         } else if (s == 0 && fresh) {
@@ -262,7 +280,7 @@ __device__ void traceback_consumer(const BatchParams& bp) {
     int phase = IDLE;
     uint32_t claimed = 0;
     TbLane t{};
-    const bool eq = bp.flags & F_CIGAR_EQ;
+    const uint32_t eq = bp.flags;   // mode bits the walk looks at: CIGAR_EQ, LOCAL_START, FREE_QUERY_START_GAPS
     uint32_t* head = bp.tb_ctrl + 32;
     // A walk is a long dependent chain of short instructions sharing its SIMD with VALU-saturating fill waves; without
     // priority it gets a quarter of the issue slots and every pending walk pins a whole trace slot meanwhile.
@@ -399,14 +417,16 @@ struct Aligner {
 
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
         if (nblocks >= h_blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
-        if ((uint64_t)trace_top + (uint64_t)w * h / 8 > h_trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
+        // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
+        const uint32_t words = (w * h / 8) * ((h_flags & F_LOCAL) ? 5u : 1u);
+        if ((uint64_t)trace_top + words > h_trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
         if (is_lane(0)) {
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
             blocks[nblocks] = br;
         }
         nblocks++;
-        trace_top += w * h / 8;
+        trace_top += words;
     }
 
     // The block borders of the best-so-far position (scan_block.rs:406-427) are parked in this wave's slot of a global
@@ -478,6 +498,16 @@ struct Aligner {
         q = coldp()->pool + coldp()->q_off[pair]; r = coldp()->pool + coldp()->r_off[pair];
         qlen = coldp()->q_len[pair]; rlen = coldp()->r_len[pair];
         const uint32_t min_size = h_min_size, max_size = h_max_size;
+        ProfileView pv{};
+        if constexpr (KIND == KIND_PROFILE) {   // r points at the pair's AAProfile image (ba_params.h)
+            pv.P = profile_positions(rlen, max_size);
+            pv.pos_aa = (const signed char*)r;
+            pv.aa_pos = (const short*)(r + (uint64_t)pv.P * 32);
+            pv.goC = pv.aa_pos + (uint64_t)pv.P * 32; pv.clC = pv.goC + pv.P; pv.goR = pv.clC + pv.P;
+        }
+        const uint32_t special = h_flags & (F_LOCAL | F_FQS | F_FQE);
+        const bool FQE = h_flags & F_FQE;
+        FqeOut fq{0, 0};
         // scratch reset (scan_block.rs:1322-1339): borders to MIN = 0. The checkpoint copies need no reset: they are
         // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
         lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size);
@@ -530,7 +560,8 @@ struct Aligner {
                 seqV = q; seqC = r; lenV = qlen; lenC = rlen; ri = si; rj = sj + prev_size; rw = block_size - prev_size; rh = block_size;
                 Dc = L.D_col; Cc = L.C_col; Dr = L.D_row + prev_size; Rr = L.R_row + prev_size; right = true;
             }
-            const bool fast = dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u);   // bit 8: development switch, generic path only
+            // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
+            const bool fast = KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special;
             if (fast) {   // before any store of this step: the memory counter is in-order
                 // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
                 const int lane = lane_id();
@@ -557,19 +588,25 @@ struct Aligner {
             const int rz = clamp16(-off + ZERO);
             BA_TSTAMP(ts1);
             Best cur{0, 0, 0};
-            if (fast) {
-                fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
-                cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
-                                                              off_add, tout, cells, &fs, prof);
-                prefetch_seq(si, sj, block_size);   // for the next step, behind this step's stores
+            const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
+            if constexpr (KIND != KIND_PROFILE) {
+                if (fast) {
+                    fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
+                    cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
+                                                                  off_add, tout, cells, &fs, prof);
+                    prefetch_seq(si, sj, block_size);   // for the next step, behind this step's stores
+                }
             }
-#define BA_PLACE(N) cur = place_rect<N, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof)
+#define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
+#define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
+            if (fast) { }
             else if (rh <= 128) BA_PLACE(1);
             else if (PMAX >= 2 && rh == 256) BA_PLACE(2);
             else if (PMAX >= 4 && rh == 512) BA_PLACE(4);
             else if (PMAX >= 8 && rh == 1024) BA_PLACE(8);
             else if (PMAX >= 16 && rh == 2048) BA_PLACE(16);
 #undef BA_PLACE
+#undef BA_PLACE1
             BA_TSTAMP(ts2);
             BA_TADD(prof, 12, ts0, ts1); BA_TADD(prof, 13, ts1, ts2);
             if (dir == DIR_GROW && gphase == 0) { grow = cur; gphase = 1; continue; }
@@ -598,13 +635,20 @@ struct Aligner {
 
             const int this_dir = dir;
             prev_dir = dir;
-            const int D_max_max = cur.mx, grow_max = grow.mx;
+            // FREE_QUERY_END_GAPS: only the vector lane that holds the last query row counts (scan_block.rs:333-339)
+            const int D_max_max = FQE ? fq.M : cur.mx, grow_max = grow.mx;
             const int mx = max(D_max_max, grow_max);
             off_max = off + mx - ZERO;
             y_drop_iter++;
             bool grow_no_max = this_dir == DIR_GROW;
 
             if (off_max > best_max) {
+                if (FQE) {     // scan_block.rs:354-368
+                    best_i = qlen;
+                    if (this_dir == DIR_RIGHT) best_j = sj + (block_size - STEP) + (uint32_t)fq.j;
+                    else if (this_dir == DIR_GROW) best_j = sj + prev_size + (uint32_t)fq.j;
+                    else status |= ST_MODE;   // the reference panics: min block size > query length rules out down steps
+                }
                 if (XDROP) {   // scan_block.rs:370-404
                     if (this_dir == DIR_RIGHT) { best_i = si + cur.row; best_j = sj + (block_size - STEP) + cur.col; }
                     else if (this_dir == DIR_DOWN) { best_i = si + (block_size - STEP) + cur.col; best_j = sj + cur.row; }
@@ -669,7 +713,7 @@ struct Aligner {
         if (coldp()->prof && is_lane(0)) for (int k = 0; k < 17; k++) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
         int score; uint32_t ri, rj;
-        if (XDROP) { score = best_max; ri = best_i; rj = best_j; }
+        if (XDROP || FQE) { score = best_max; ri = best_i; rj = best_j; }
         else {
             lds_sync();
             if (dir == DIR_DOWN) score = off + uni((int)L.D_row[rlen - sj]) - ZERO;
@@ -692,7 +736,7 @@ struct Aligner {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             if (is_lane(0)) {
                 uint32_t st = 0;
-                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, h_flags & F_CIGAR_EQ, coldp()->cig_ops,
+                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, h_flags, coldp()->cig_ops,
                                  coldp()->cig_off[pair], coldp()->cig_off[pair + 1], &st);
                 status |= st;
             }
@@ -725,7 +769,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
                 ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
             }
         } else {
-            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_BYTES ? 2 : 0);   // PROFILE: scores live in the pair's image
             for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
         }
     }

@@ -26,7 +26,7 @@ using ba::BlockRec;
     extern "C" hipError_t ba_launch_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);       \
     extern "C" hipError_t ba_occupancy_k##K##_p##P(int, int, unsigned, int*);
 #define BA_DECL_KIND(K) BA_DECL(K, 1) BA_DECL(K, 2) BA_DECL(K, 4) BA_DECL(K, 8) BA_DECL(K, 16)
-BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2)
+BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
 
@@ -34,8 +34,9 @@ typedef hipError_t (*LaunchFn)(int, int, unsigned, unsigned, hipStream_t, const 
 typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 #define BA_ROW(K) {ba_launch_k##K##_p1, ba_launch_k##K##_p2, ba_launch_k##K##_p4, ba_launch_k##K##_p8, ba_launch_k##K##_p16}
 #define BA_OROW(K) {ba_occupancy_k##K##_p1, ba_occupancy_k##K##_p2, ba_occupancy_k##K##_p4, ba_occupancy_k##K##_p8, ba_occupancy_k##K##_p16}
-static const LaunchFn g_launch[3][5] = {BA_ROW(0), BA_ROW(1), BA_ROW(2)};
-static const OccFn g_occ[3][5] = {BA_OROW(0), BA_OROW(1), BA_OROW(2)};
+static const LaunchFn g_launch[4][5] = {BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)};
+static const OccFn g_occ[4][5] = {BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)};
+constexpr int BA_KIND_PROFILE_ = ba::KIND_PROFILE;   // batches whose "reference" is an AAProfile (sequence bytes: AA alphabet)
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -105,9 +106,11 @@ extern const ByteMatrix BYTES1 = {1, -1};
 }
 
 static inline uint8_t upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
-static inline uint8_t null_byte(int kind) { return kind == BA_KIND_AA ? 26 : (kind == BA_KIND_NUC ? 'Z' : 0); }
+static inline int seq_kind(int kind) { return kind == BA_KIND_PROFILE_ ? BA_KIND_AA : kind; }
+static inline uint8_t null_byte(int kind) { kind = seq_kind(kind); return kind == BA_KIND_AA ? 26 : (kind == BA_KIND_NUC ? 'Z' : 0); }
 // convert_char of scores.rs:130-134 / 212-216 / 270-272; returns false on a byte the reference would assert on
 static inline bool convert_char(int kind, uint8_t c, uint8_t* out) {
+    kind = seq_kind(kind);
     if (kind == BA_KIND_BYTES) { *out = c; return true; }
     c = upper(c);
     if (kind == BA_KIND_AA) { if (c < 'A' || c > 'A' + 26) return false; *out = (uint8_t)(c - 'A'); return true; }
@@ -194,10 +197,13 @@ struct BaBatch {
     }
 };
 
-static int check_align_params(Gaps g, size_t min_size, size_t max_size, int32_t x_drop, uint32_t mode, std::string* why) {
-    // scan_block.rs:847-862
-    if (!(g.open < 0 && g.extend < 0)) { *why = "Gap costs must be negative!"; return 1; }
-    if (!(g.open < g.extend)) { *why = "Gap open must cost more than gap extend!"; return 1; }
+static int check_align_params(bool profile, Gaps g, size_t min_size, size_t max_size, int32_t x_drop, uint32_t mode, std::string* why) {
+    // scan_block.rs:847-862 (align) / 942-956 (align_profile: only the extend cost, which lives in the profile)
+    if (profile) { if (!(g.extend < 0)) { *why = "Gap extend cost must be negative!"; return 1; } }
+    else {
+        if (!(g.open < 0 && g.extend < 0)) { *why = "Gap costs must be negative!"; return 1; }
+        if (!(g.open < g.extend)) { *why = "Gap open must cost more than gap extend!"; return 1; }
+    }
     if (!(min_size < 65535 && max_size < 65535)) { *why = "Block sizes must be smaller than 2^16 - 1!"; return 1; }
     if ((min_size & (min_size - 1)) || (max_size & (max_size - 1))) { *why = "Block sizes must be powers of two!"; return 1; }
     if ((mode & BA_X_DROP) && x_drop < 0) { *why = "X-drop threshold amount must be nonnegative!"; return 1; }
@@ -216,18 +222,37 @@ static int pclass_of(size_t max_size) {   // index into {1,2,4,8,16} packed regi
 }
 
 // Build a batch from already-converted byte ranges. `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1).
-template <class GetSeq>
+// AAProfile -> device image (layout in ba_params.h). `P` positions, defaults (-128) beyond the profile's own length.
+static void profile_image(const AAProfile* pr, uint32_t P, uint8_t* dst) {
+    int8_t* pos_aa = (int8_t*)dst;
+    int16_t* aa_pos = (int16_t*)(dst + (size_t)P * 32);
+    int16_t* goC = aa_pos + (size_t)P * 32; int16_t* clC = goC + P; int16_t* goR = clC + P;
+    const size_t have = std::min<size_t>(P, pr->curr_len);
+    memset(pos_aa, 0x80, (size_t)P * 32);
+    memcpy(pos_aa, pr->pos_aa.data(), have * 32);
+    for (size_t c = 0; c < 32; c++)
+        for (size_t i = 0; i < P; i++) aa_pos[c * P + i] = (int16_t)pos_aa[i * 32 + c];    // scores.rs:552-553 keeps both orders in sync
+    for (size_t i = 0; i < P; i++) {
+        goC[i] = i < have ? pr->gap_open_C[i] : (int16_t)-128;
+        clC[i] = i < have ? pr->gap_close_C[i] : (int16_t)-128;
+        goR[i] = i < have ? pr->gap_open_R[i] : (int16_t)-128;
+    }
+}
+struct NoProfiles { const AAProfile* operator()(size_t) const { return nullptr; } };
+
+// `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1); for kind PROFILE the reference comes from
+// `getp(p)` instead.
+template <class GetSeq, class GetProfile = NoProfiles>
 static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, size_t n,
-                            bool already_converted, GetSeq get) {
+                            bool already_converted, GetSeq get, GetProfile getp = GetProfile()) {
     if (ensure_device()) return nullptr;
-    if (kind < 0 || kind > 2) { fail("unknown matrix kind %d", kind); return nullptr; }
+    if (kind < 0 || kind > 3) { fail("unknown matrix kind %d", kind); return nullptr; }
+    const bool profile = kind == BA_KIND_PROFILE_;
     const size_t min_size = size.min < 16 ? 16 : size.min, max_size = size.max < 16 ? 16 : size.max;   // clamp to L (scan_block.rs:853-854)
     std::string why;
-    if (check_align_params(gaps, min_size, max_size, x_drop, mode, &why)) { fail("%s", why.c_str()); return nullptr; }
+    if (check_align_params(profile, gaps, min_size, max_size, x_drop, mode, &why)) { fail("%s", why.c_str()); return nullptr; }
     if (min_size > max_size) { fail("min block size exceeds max block size"); return nullptr; }
-    if (mode & (BA_LOCAL_START | BA_FREE_QUERY_START_GAPS | BA_FREE_QUERY_END_GAPS)) {
-        fail("LOCAL_START / FREE_QUERY_*_GAPS are not implemented in the HIP backend yet"); return nullptr;
-    }
+    if (profile && (mode & BA_CIGAR_EQ)) { fail("=/X CIGARs need two sequences; a profile alignment has none to compare"); return nullptr; }
     if (kind == BA_KIND_BYTES && (mode & BA_X_DROP)) { /* allowed by the reference, documented as inaccurate (scores.rs:235-239) */ }
     const int pc = pclass_of(max_size);
     if (pc < 0) { fail("max block size %zu not supported by the HIP backend (16..2048)", max_size); return nullptr; }
@@ -250,9 +275,21 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         get(p, 0, &ptr, &len);
         if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
         ql[p] = (uint32_t)len; qo[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;   // images start 4-byte aligned
-        get(p, 1, &ptr, &len);
-        if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
-        rl[p] = (uint32_t)len; ro[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;
+        if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > len)) {   // scan_block.rs:860-862
+            fail("pair %zu: Min block size must be larger than the query length for FREE_QUERY_END_GAPS!", p); return nullptr;
+        }
+        if (profile) {
+            const AAProfile* pr = getp(p);
+            if (!pr) { fail("pair %zu: null profile", p); return nullptr; }
+            if (pr->gap_extend != gaps.extend) { fail("pair %zu: profile gap_extend %d differs from the batch's %d", p, pr->gap_extend, gaps.extend); return nullptr; }
+            len = pr->str_len;
+            if (len > 0x3fffffffu) { fail("profile too long"); return nullptr; }
+            rl[p] = (uint32_t)len; ro[p] = total; total += ba::profile_image_bytes((uint32_t)len, (uint32_t)max_size);
+        } else {
+            get(p, 1, &ptr, &len);
+            if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
+            rl[p] = (uint32_t)len; ro[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;
+        }
         maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
         cig_off[p] = cig_total;
         cig_total += (uint64_t)ql[p] + rl[p] + 1;
@@ -261,7 +298,8 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     total += 64;
     std::vector<uint8_t> image(total, null_byte(kind));
     for (size_t p = 0; p < n; p++) {
-        for (int w = 0; w < 2; w++) {
+        if (profile) profile_image(getp(p), ba::profile_positions(rl[p], (uint32_t)max_size), image.data() + ro[p]);
+        for (int w = 0; w < (profile ? 1 : 2); w++) {
             const uint8_t* ptr; size_t len;
             get(p, w, &ptr, &len);
             uint8_t* dst = image.data() + (w ? ro[p] : qo[p]) + 1;
@@ -277,7 +315,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { fail("hipEventCreate failed"); return nullptr; }
 
     const bool trace = mode & BA_TRACE;
-    const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : 2);
+    const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : (profile ? 0 : 2));
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return nullptr; }
@@ -297,7 +335,8 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (grid > need) grid = need;
     b->grid = (uint32_t)grid;
     // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
-    b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 : 0;
+    // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
+    b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) : 0;
     b->blocks_stride = trace ? maxlen2 : 0;
     if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
     // TRACE batches big enough to keep them busy get dedicated traceback workgroups (ba_driver.hpp traceback_consumer)
@@ -347,7 +386,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     {
         int8_t tmp[1024] = {0};
         if (kind == BA_KIND_BYTES) { const ByteMatrix* bm = (const ByteMatrix*)matrix; tmp[0] = bm->match_score; tmp[1] = bm->mismatch_score; }
-        else memcpy(tmp, matrix, mat_bytes);
+        else if (mat_bytes) memcpy(tmp, matrix, mat_bytes);
         BA_H2D(matrix, tmp, 1024);
     }
 #undef BA_H2D
@@ -406,9 +445,18 @@ uintptr_t block_percent_len(uintptr_t len, float p) {   // lib.rs:109-111
 BaBatch* ba_batch_create(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, const uint8_t* pool,
                          const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n) {
     if (!matrix || !pool || !q_off || !q_len || !r_off || !r_len) { fail("null argument"); return nullptr; }
+    if (kind == BA_KIND_PROFILE_) { fail("profile batches are created with ba_batch_create_profile"); return nullptr; }
     return batch_build(kind, matrix, gaps, size, x_drop, mode, n, false, [&](size_t p, int w, const uint8_t** ptr, size_t* len) {
         if (w == 0) { *ptr = pool + q_off[p]; *len = q_len[p]; } else { *ptr = pool + r_off[p]; *len = r_len[p]; }
     });
+}
+BaBatch* ba_batch_create_profile(const AAProfile* const* profiles, SizeRange size, int32_t x_drop, uint32_t mode, const uint8_t* pool,
+                                 const uint64_t* q_off, const uint32_t* q_len, uintptr_t n) {
+    if (!profiles || !pool || !q_off || !q_len || n == 0 || !profiles[0]) { fail("null argument"); return nullptr; }
+    const Gaps g{0, profiles[0]->gap_extend};   // the open costs are per position, inside the profiles
+    return batch_build(BA_KIND_PROFILE_, nullptr, g, size, x_drop, mode, n, false,
+                       [&](size_t p, int, const uint8_t** ptr, size_t* len) { *ptr = pool + q_off[p]; *len = q_len[p]; },
+                       [&](size_t p) { return profiles[p]; });
 }
 int ba_batch_run(BaBatch* b, float* kernel_ms) { return b ? batch_run(b, kernel_ms) : fail("null batch"); }
 int ba_batch_results(BaBatch* b, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {
@@ -597,6 +645,16 @@ int8_t block_get_aaprofile(const AAProfile* p, uintptr_t i, uint8_t b) {
     return p->pos_aa.at(i * 32 + (b - 'A'));
 }
 int8_t block_get_gap_extend_aaprofile(const AAProfile* p) { return p->gap_extend; }
+// Part 2: bulk form of set / set_gap_* for bindings that already hold the profile as arrays. Copies the first
+// `positions` rows of pos_aa ([position][32]) and entries of the three gap arrays; no range checks beyond the length.
+int ba_aaprofile_set_raw(AAProfile* p, const int8_t* pos_aa, const int8_t* gap_open_C, const int8_t* gap_close_C,
+                         const int8_t* gap_open_R, uintptr_t positions) {
+    if (!p || !pos_aa || !gap_open_C || !gap_close_C || !gap_open_R) return fail("null argument");
+    if (positions > p->curr_len) return fail("%zu positions exceed the profile's %zu", (size_t)positions, p->curr_len);
+    memcpy(p->pos_aa.data(), pos_aa, (size_t)positions * 32);
+    for (size_t i = 0; i < positions; i++) { p->gap_open_C[i] = gap_open_C[i]; p->gap_close_C[i] = gap_close_C[i]; p->gap_open_R[i] = gap_open_R[i]; }
+    return 0;
+}
 void block_free_aaprofile(AAProfile* p) { delete p; }
 
 }  // extern "C"
@@ -620,7 +678,7 @@ static void block_align_impl(BlockImpl* b, int kind, const PaddedBytes* q, const
     if (q->kind != kind || r->kind != kind) die("PaddedBytes were built for a different matrix kind");
     const size_t min_size = s.min < 16 ? 16 : s.min, max_size = s.max < 16 ? 16 : s.max;
     std::string why;
-    if (check_align_params(g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    if (check_align_params(false, g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
     // Allocated::clear (scan_block.rs:1324-1326)
     if (q->len + r->len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
     if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
@@ -637,10 +695,30 @@ static void block_align_impl(BlockImpl* b, int kind, const PaddedBytes* q, const
     b->res = AlignResult{sc, qi, ri};
 }
 
+static void block_align_profile_impl(BlockImpl* b, const PaddedBytes* q, const AAProfile* pr, SizeRange s, int32_t x) {   // scan_block.rs:942-968
+    if (q->kind != BA_KIND_AA) die("PaddedBytes were built for a different matrix kind");
+    const size_t min_size = s.min < 16 ? 16 : s.min, max_size = s.max < 16 ? 16 : s.max;
+    const Gaps g{0, pr->gap_extend};
+    std::string why;
+    if (check_align_params(true, g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    if (q->len + pr->str_len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
+    if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
+    b->last.reset(batch_build(BA_KIND_PROFILE_, nullptr, g, SizeRange{min_size, max_size}, x, b->mode & ~(uint32_t)BA_CIGAR_EQ, 1, true,
+                              [&](size_t, int, const uint8_t** ptr, size_t* len) { *ptr = q->s.data() + 1; *len = q->len; },
+                              [&](size_t) { return pr; }));
+    if (!b->last) die("%s", g_err.c_str());
+    if (batch_run(b->last.get(), nullptr)) die("%s", g_err.c_str());
+    int32_t sc; uint32_t qi, ri, st;
+    if (ba_batch_results(b->last.get(), &sc, &qi, &ri, nullptr, nullptr, &st)) die("%s", g_err.c_str());
+    if (st) die("device alignment failed (status 0x%x)", st);
+    b->res = AlignResult{sc, qi, ri};
+}
+
 static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const PaddedBytes* r, size_t i, size_t j, Cigar* cigar) {
     if (!(b->mode & BA_TRACE)) die("trace() requires a Block created with TRACE");   // scan_block.rs:1241-1243
     BaBatch* d = b->last.get();
     if (!d) die("cigar requested before any alignment");
+    if (eq && d->kind == BA_KIND_PROFILE_) die("cigar_eq needs two sequences; the last alignment was against a profile");
     uint32_t ql, rl, nb, slot;
     if (d2h(d->q_len, &ql, 1) || d2h(d->r_len, &rl, 1) || d2h(d->nblocks, &nb, 1) || d2h(d->pair_slot, &slot, 1)) die("%s", g_err.c_str());
     if (!(i <= ql && j <= rl)) die("Traceback cigar end position must be in bounds!");   // scan_block.rs:1483
@@ -667,6 +745,9 @@ BlockHandle block_new_generic(uint32_t mode, uintptr_t ql, uintptr_t rl, uintptr
 void block_align_generic(BlockHandle b, int kind, const PaddedBytes* q, const PaddedBytes* r, const void* matrix, Gaps g, SizeRange s, int32_t x) {
     block_align_impl((BlockImpl*)b, kind, q, r, matrix, g, s, x);
 }
+void block_align_profile_generic(BlockHandle b, const PaddedBytes* q, const AAProfile* p, SizeRange s, int32_t x) {
+    block_align_profile_impl((BlockImpl*)b, q, p, s, x);
+}
 AlignResult block_res_generic(BlockHandle b) { return ((BlockImpl*)b)->res; }
 void block_cigar_generic(BlockHandle b, uintptr_t i, uintptr_t j, Cigar* c) { block_cigar_impl((BlockImpl*)b, false, nullptr, nullptr, i, j, c); }
 void block_cigar_eq_generic(BlockHandle b, const PaddedBytes* q, const PaddedBytes* r, uintptr_t i, uintptr_t j, Cigar* c) {
@@ -679,8 +760,8 @@ void block_free_generic(BlockHandle b) { delete (BlockImpl*)b; }
     void block_align_##S(BlockHandle b, const PaddedBytes* q, const PaddedBytes* r, const AAMatrix* m, Gaps g, SizeRange s, int32_t x) { \
         block_align_impl((BlockImpl*)b, BA_KIND_AA, q, r, m, g, s, x);                                                            \
     }                                                                                                                             \
-    void block_align_profile_##S(BlockHandle, const PaddedBytes*, const AAProfile*, SizeRange, int32_t) {                         \
-        die("sequence-to-profile alignment is not implemented in the HIP backend yet");                                           \
+    void block_align_profile_##S(BlockHandle b, const PaddedBytes* q, const AAProfile* p, SizeRange s, int32_t x) {                \
+        block_align_profile_impl((BlockImpl*)b, q, p, s, x);                                                                      \
     }                                                                                                                             \
     AlignResult block_res_##S(BlockHandle b) { return ((BlockImpl*)b)->res; }                                                      \
     void CIG(BlockHandle b, uintptr_t i, uintptr_t j, Cigar* c) { block_cigar_impl((BlockImpl*)b, false, nullptr, nullptr, i, j, c); } \

@@ -1,4 +1,4 @@
-// One translation unit per (matrix kind, max-block class): compiled with -DBA_KIND=<0|1|2> -DBA_PMAX=<1|2|4|8|16>.
+// One translation unit per (matrix kind, max-block class): compiled with -DBA_KIND=<0|1|2|3> -DBA_PMAX=<1|2|4|8|16>.
 // BA_PMAX = max block size / 128 (packed VGPRs per border array per lane); a smaller class keeps the kernel's VGPR
 // budget (and so its occupancy) matched to the batch's max block size.
 #include "ba_driver.hpp"
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {
     uint32_t st = 0;
     const uint32_t n = traceback(bp.blocks + (uint64_t)bp.tb_slot * bp.blocks_stride, bp.tb_nblocks,
                                  bp.trace_arena + (uint64_t)bp.tb_slot * bp.trace_stride, bp.tb_i, bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0],
-                                 bp.flags & F_CIGAR_EQ, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
+                                 bp.flags, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
     bp.cig_len[0] = n;
     bp.status[0] = st;
 }

@@ -6,13 +6,13 @@ namespace ba {
 
 constexpr int ZERO = 1 << 14;     // avx2.rs:15
 constexpr int STEP = 8;           // scan_block.rs:787
-constexpr int KIND_AA = 0, KIND_NUC = 1, KIND_BYTES = 2;
+constexpr int KIND_AA = 0, KIND_NUC = 1, KIND_BYTES = 2, KIND_PROFILE = 3;   // PROFILE: the "reference" is a position-specific AAProfile
 constexpr int DIR_RIGHT = 0, DIR_DOWN = 1, DIR_GROW = 2;
 
 enum : uint32_t {
     F_TRACE = 1u << 0, F_XDROP = 1u << 1, F_LOCAL = 1u << 2, F_FQS = 1u << 3, F_FQE = 1u << 4, F_CIGAR_EQ = 1u << 5
 };
-enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8, ST_WATCHDOG = 16, ST_SLOT_TIMEOUT = 32 };
+enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8, ST_WATCHDOG = 16, ST_SLOT_TIMEOUT = 32, ST_MODE = 64 };
 
 struct BlockRec {   // one computed rectangle (scan_block.rs:1428-1443), 16 bytes
     uint32_t i, j;
@@ -21,6 +21,17 @@ struct BlockRec {   // one computed rectangle (scan_block.rs:1428-1443), 16 byte
 };
 
 struct SlotInfo { uint32_t pair, nblocks, end_i, end_j; };
+
+// Device image of one AAProfile (scores.rs:452-468) inside the sequence pool, P = profile_positions(len, max_size):
+//   int8  pos_aa[P][32]   | int16 aa_pos[32][P] | int16 gap_open_C[P] | gap_close_C[P] | gap_open_R[P]
+// positions beyond the profile hold the reference's defaults (-128), so block reads past the end need no bounds checks
+#if defined(__HIPCC__)
+#define BA_HD __host__ __device__
+#else
+#define BA_HD
+#endif
+BA_HD inline uint32_t profile_positions(uint32_t len, uint32_t max_size) { return (len + max_size + 17u) & ~1u; }
+BA_HD inline uint64_t profile_image_bytes(uint32_t len, uint32_t max_size) { return (uint64_t)profile_positions(len, max_size) * (32 + 64 + 6); }
 
 struct BatchParams {
     // inputs: pool holds PaddedBytes images: [NULL] + converted bytes + NULL x pad (scan_block.rs:1790-1812)
@@ -63,11 +74,6 @@ struct BatchParams {
 constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
-#if defined(__HIPCC__)
-#define BA_HD __host__ __device__
-#else
-#define BA_HD
-#endif
 BA_HD inline uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
 BA_HD inline uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_array_bytes_h(max_size) + 128; }
 BA_HD inline uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }

@@ -83,6 +83,13 @@ def lib() -> C.CDLL:
         L.block_cigar_generic.argtypes = [vp, sz, sz, vp]
         L.block_cigar_eq_generic.argtypes = [vp, vp, vp, sz, sz, vp]
         L.block_free_generic.argtypes = [vp]
+        L.block_align_profile_generic.argtypes = [vp, vp, vp, SizeRangeC, i32]
+        L.block_new_aaprofile.restype = vp
+        L.block_new_aaprofile.argtypes = [sz, sz, i8]
+        L.block_free_aaprofile.argtypes = [vp]
+        L.ba_aaprofile_set_raw.argtypes = [vp, vp, vp, vp, vp, sz]
+        L.ba_batch_create_profile.restype = vp
+        L.ba_batch_create_profile.argtypes = [vp, SizeRangeC, i32, u32, vp, vp, vp, sz]
         L.ba_batch_create.restype = vp
         L.ba_batch_create.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, u32, vp, vp, vp, vp, vp, sz]
         L.ba_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
@@ -204,6 +211,23 @@ class Cigar:
             self._h = None
 
 
+class _NativeProfile:
+    """The library's AAProfile object (ffi.rs:60-195) filled from the numpy mirror in scores.AAProfile."""
+
+    def __init__(self, p: S.AAProfile):
+        L = lib()
+        self._h = L.block_new_aaprofile(p.str_len, p.curr_len - p.str_len - 1, p.gap_extend)
+        pos = np.ascontiguousarray(p.pos_aa[: p.curr_len], dtype=np.int8)
+        g = [np.ascontiguousarray(a[: p.curr_len], dtype=np.int8) for a in (p.pos_gap_open_C, p.pos_gap_close_C, p.pos_gap_open_R)]
+        if L.ba_aaprofile_set_raw(self._h, pos.ctypes.data, g[0].ctypes.data, g[1].ctypes.data, g[2].ctypes.data, p.curr_len):
+            raise RuntimeError(last_error())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.block_free_aaprofile(self._h)
+            self._h = None
+
+
 class _Trace:
     def __init__(self, block: "Block"):
         self._b = block
@@ -237,6 +261,22 @@ class Block:
         mn, mx = max(s.min, 16), max(s.max, 16)
         while mn <= mx:
             self.align(query, reference, matrix, gaps, (mn, mx), x_drop)
+            if self.res().score >= target_score:
+                return mn
+            mn *= 2
+        return None
+
+    def align_profile(self, query: PaddedBytes, profile: S.AAProfile, size, x_drop: int = 0) -> None:
+        """scan_block.rs:942-968"""
+        native = _NativeProfile(profile)
+        lib().block_align_profile_generic(self._h, query._h, native._h, _size(size), x_drop)
+
+    def align_profile_exp(self, query, profile, size, x_drop: int, target_score: int):
+        """scan_block.rs:974-992"""
+        s = _size(size)
+        mn, mx = max(s.min, 16), max(s.max, 16)
+        while mn <= mx:
+            self.align_profile(query, profile, (mn, mx), x_drop)
             if self.res().score >= target_score:
                 return mn
             mn *= 2
@@ -313,6 +353,24 @@ class BatchAligner:
             self._h = None
 
     __del__ = close
+
+
+class ProfileBatchAligner(BatchAligner):
+    """Sequence-to-profile batch: pair p aligns the amino-acid query pool[q_off[p]:+q_len[p]] to profiles[p]
+    (Block::align_profile over many pairs, examples/pssm_bench.rs:86-103)."""
+
+    def __init__(self, profiles, size, x_drop: int, mode: int, pool, q_off, q_len):
+        L = lib()
+        self.n = len(q_len)
+        self.mode = mode
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+        natives = [_NativeProfile(p) for p in profiles]
+        arr = (C.c_void_p * self.n)(*[x._h for x in natives])
+        self._h = L.ba_batch_create_profile(arr, _size(size), x_drop, mode, pool.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, self.n)
+        if not self._h:
+            raise RuntimeError(last_error())
 
 
 def runs_to_string(runs) -> str:

@@ -150,6 +150,9 @@ BlockHandle block_new_generic(uint32_t mode, uintptr_t query_len, uintptr_t refe
 void block_align_generic(BlockHandle b, int kind, const struct PaddedBytes* q, const struct PaddedBytes* r, const void* matrix,
                          struct Gaps g, struct SizeRange s, int32_t x);
 struct AlignResult block_res_generic(BlockHandle b);
+/* Block::<mode>::align_profile (scan_block.rs:942-968): q must be an AA PaddedBytes; the gap costs come from the profile. */
+void block_align_profile_generic(BlockHandle b, const struct PaddedBytes* q, const struct AAProfile* profile, struct SizeRange s,
+                                 int32_t x);
 void block_cigar_generic(BlockHandle b, uintptr_t query_idx, uintptr_t reference_idx, struct Cigar* cigar);
 void block_cigar_eq_generic(BlockHandle b, const struct PaddedBytes* q, const struct PaddedBytes* r, uintptr_t query_idx,
                             uintptr_t reference_idx, struct Cigar* cigar);
@@ -170,6 +173,17 @@ typedef struct BaBatch BaBatch;
 BaBatch* ba_batch_create(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,
                          const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
                          const uint32_t* r_len, uintptr_t n_pairs);
+/* Bulk form of block_set_aaprofile / block_set_gap_*_aaprofile for callers that hold the profile as arrays: copies the
+ * first `positions` rows of pos_aa ([position][32], column = byte - 'A') and entries of the three gap arrays. */
+int ba_aaprofile_set_raw(struct AAProfile* profile, const int8_t* pos_aa, const int8_t* gap_open_C, const int8_t* gap_close_C,
+                         const int8_t* gap_open_R, uintptr_t positions);
+
+/* Sequence-to-profile batch (Block::align_profile over many pairs; examples/pssm_bench.rs:86-103): pair p aligns the
+ * amino-acid query pool[q_off[p] .. +q_len[p]) to *profiles[p]. Every profile must have been created with a block size
+ * >= size.max and share one gap_extend. The profiles are copied to the device; the caller keeps ownership.
+ * BA_CIGAR_EQ is rejected (there is no second sequence to compare with). */
+BaBatch* ba_batch_create_profile(const struct AAProfile* const* profiles, struct SizeRange size, int32_t x_drop, uint32_t mode,
+                                 const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, uintptr_t n_pairs);
 /* Launch on the batch's stream and wait. kernel_ms (optional) = HIP-event time of the alignment kernel alone. */
 int ba_batch_run(BaBatch* batch, float* kernel_ms);
 /* Copy results to host arrays of n_pairs elements; any pointer may be NULL. status: 0 = ok, else BA_ST_* bits. */
@@ -182,7 +196,8 @@ int ba_batch_cigars(BaBatch* batch, uint32_t* runs, uint64_t capacity);
 int ba_batch_info(BaBatch* batch, uint64_t out[4]);
 void ba_batch_destroy(BaBatch* batch);
 
-enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16 };
+enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16,
+       BA_ST_SLOT_TIMEOUT = 32, BA_ST_MODE = 64 /* FREE_QUERY_END_GAPS reached a down step: the reference panics there */ };
 
 /* One-shot convenience over create/run/results/cigars/destroy. */
 int block_batch_align(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,

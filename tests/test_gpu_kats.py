@@ -3,22 +3,25 @@ Rust API (Block::new / align / res / trace().cigar[_eq]); scan_block.rs:1908-212
 import pytest
 
 from block_aligner_amd import scores as S
-from tests.common import check_expect, kat_matrix
+from tests.common import check_expect, kat_matrix, kat_profile
 
 pytestmark = pytest.mark.gpu
 
-MCLS = {"aa": S.AAMatrix, "nuc": S.NucMatrix, "bytes": S.ByteMatrix}
-SUPPORTED = {"trace", "x_drop"}
+MCLS = {"aa": S.AAMatrix, "nuc": S.NucMatrix, "bytes": S.ByteMatrix, "profile": S.AAMatrix}
 
 
 def run_kat(H, k):
     cls = MCLS[k["kind"]]
     pad = k["size"][1]
     q = H.PaddedBytes.from_bytes(k["q"].encode(), pad, cls)
-    r = H.PaddedBytes.from_bytes(k["r"].encode(), pad, cls)
     mode = set(k["mode"])
-    a = H.Block(k["alloc"][0], k["alloc"][1], k["alloc"][2], trace="trace" in mode, x_drop="x_drop" in mode)
-    a.align(q, r, kat_matrix(k), S.Gaps(*k["gaps"]), tuple(k["size"]), k["x_drop"])
+    a = H.Block(k["alloc"][0], k["alloc"][1], k["alloc"][2], **{m: True for m in mode})
+    if k["kind"] == "profile":   # scan_block.rs:2122-2168
+        r = None
+        a.align_profile(q, kat_profile(k), tuple(k["size"]), k["x_drop"])
+    else:
+        r = H.PaddedBytes.from_bytes(k["r"].encode(), pad, cls)
+        a.align(q, r, kat_matrix(k), S.Gaps(*k["gaps"]), tuple(k["size"]), k["x_drop"])
     res = a.res()
     out = dict(score=res.score, query_idx=res.query_idx, reference_idx=res.reference_idx)
     cig = cig_eq = None
@@ -37,11 +40,27 @@ def run_kat(H, k):
 def test_reference_kats_seq_seq(hip, kats):
     n = 0
     for k in kats["align"] + kats["inferred"]:
-        if k["kind"] == "profile" or not set(k["mode"]) <= SUPPORTED:
+        if k["kind"] == "profile" or not set(k["mode"]) <= {"trace", "x_drop"}:
             continue
         run_kat(hip, k)
         n += 1
     assert n >= 34
+
+
+def test_reference_kats_profile(hip, kats):
+    """scan_block.rs:2122-2168 (test_profile): sequence-to-profile alignment, with and without traceback."""
+    ks = [k for k in kats["align"] if k["kind"] == "profile"]
+    assert len(ks) == 6
+    for k in ks:
+        run_kat(hip, k)
+
+
+def test_reference_kats_special_modes(hip, kats):
+    """scan_block.rs:2171-2230: LOCAL_START, FREE_QUERY_START_GAPS and FREE_QUERY_END_GAPS."""
+    ks = [k for k in kats["align"] if set(k["mode"]) & {"local_start", "free_query_start_gaps", "free_query_end_gaps"}]
+    assert len(ks) == 6
+    for k in ks:
+        run_kat(hip, k)
 
 
 def test_c_example_flow(hip):

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 def compare(H, oracle, pairs, matrix, gaps, size, x_drop, mode_names, cigar_eq=True, threads=8):
     mode = 0
     for m in mode_names:
-        mode |= {"trace": H.TRACE, "x_drop": H.X_DROP}[m]
+        mode |= {"trace": H.TRACE, "x_drop": H.X_DROP, "local_start": H.LOCAL_START, "free_query_start_gaps": H.FREE_QUERY_START_GAPS,
+                 "free_query_end_gaps": H.FREE_QUERY_END_GAPS}[m]
     if cigar_eq and "trace" in mode_names:
         mode |= H.CIGAR_EQ
     b = H.BatchAligner(matrix, gaps, size, x_drop, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
@@ -105,3 +106,88 @@ def test_traceback_consumer_path(hip, oracle, monkeypatch):
     pairs = synth.make_pairs(6000, (200, 1500), (10, 150), 40, synth.DNA, seed=77, indels=1, indel_len=(10, 80))
     compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 60, ("trace", "x_drop"))
     compare(hip, oracle, pairs, NUC, (-5, -1), (32, 128), 0, ("trace",))
+    # the traceback lanes also implement the early stops of LOCAL_START / FREE_QUERY_START_GAPS
+    sub = pairs.subset(np.arange(1500))
+    compare(hip, oracle, sub, NUC, (-5, -1), (32, 128), 60, ("trace", "local_start", "x_drop"))
+    compare(hip, oracle, sub, NUC, (-5, -1), (32, 128), 0, ("trace", "free_query_start_gaps"))
+
+
+def _substring_pairs(n, seed, qlen=(40, 120), rlen=(150, 700), edits=(0, 12)):
+    """Queries that are mutated slices of a longer reference (+ unrelated flanks on the query for the local tests)."""
+    rng = np.random.default_rng(seed)
+    lists = []
+    for _ in range(n):
+        r = synth.rand_str(rng, int(rng.integers(rlen[0], rlen[1] + 1)), synth.DNA)
+        ql = int(rng.integers(qlen[0], qlen[1] + 1))
+        st = int(rng.integers(0, max(1, len(r) - ql)))
+        q = synth.mutate(rng, r[st: st + ql], int(rng.integers(edits[0], edits[1] + 1)), synth.DNA)
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    return synth.PairSet.from_lists(lists)
+
+
+@pytest.mark.parametrize("mode", [("trace", "local_start"), ("trace", "local_start", "x_drop"), ("x_drop", "local_start"),
+                                  ("local_start",), ("trace", "free_query_start_gaps"), ("free_query_start_gaps", "x_drop")])
+@pytest.mark.parametrize("size", [(32, 32), (32, 256), (128, 512)])
+def test_local_and_free_start_modes(hip, oracle, mode, size):
+    """LOCAL_START / FREE_QUERY_START_GAPS (scan_block.rs:1130-1136, 1597-1611) on random related pairs."""
+    pairs = synth.make_pairs(150, (50, 900), (0, 90), 30, synth.DNA, seed=900 + size[1], indels=1, indel_len=(10, 60))
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 40, mode)
+    compare(hip, oracle, _substring_pairs(100, 17 + size[0]), S.NW1, (-2, -1), size, 30, mode)
+
+
+@pytest.mark.parametrize("mode", [("free_query_end_gaps",), ("trace", "free_query_end_gaps"),
+                                  ("trace", "free_query_end_gaps", "free_query_start_gaps"), ("free_query_end_gaps", "local_start")])
+@pytest.mark.parametrize("size", [(128, 128), (128, 512), (256, 1024)])
+def test_free_query_end_gaps(hip, oracle, mode, size):
+    """FREE_QUERY_END_GAPS needs min block size > query length (scan_block.rs:860-862); the result is the best cell of
+    the last query row, found through the reference's per-lane bookkeeping (scan_block.rs:333-368, 1189-1201)."""
+    pairs = _substring_pairs(200, 5 + size[1], qlen=(1, 110), rlen=(100, 900), edits=(0, 15))
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 0, mode)
+    compare(hip, oracle, pairs, S.NW1, (-2, -1), size, 0, mode)
+
+
+AA20 = b"ACDEFGHIKLMNPQRSTVWY"
+
+
+def _pssm_case(rng, length, block_max):
+    """examples/pssm_bench.rs:43-98 shaped: PSSM rows = BLOSUM62 rows of a random consensus, per-position gap costs."""
+    cons = bytes(AA20[i] for i in rng.integers(0, 20, length))
+    p = S.AAProfile(length, block_max, -1)
+    for i, c in enumerate(cons):
+        for b in AA20:
+            p.set(i + 1, b, S.BLOSUM62.get(c, b))
+    for i in range(length + 1):
+        p.set_gap_open_C(i, int(rng.integers(-14, -7)))
+        p.set_gap_open_R(i, int(rng.integers(-14, -7)))
+        if i >= 1:
+            p.set_gap_close_C(i, int(rng.integers(-3, 1)))
+    q = synth.mutate(rng, np.frombuffer(cons, np.uint8), int(0.3 * length), np.frombuffer(AA20, np.uint8)).astype(np.uint8).tobytes()
+    return q, p
+
+
+@pytest.mark.parametrize("mode", [(), ("x_drop",), ("trace",), ("trace", "x_drop")])
+@pytest.mark.parametrize("size", [(16, 16), (32, 128), (32, 256), (128, 1024)])
+def test_profile_batch(hip, oracle, mode, size):
+    """Sequence-to-profile alignment (place_block_profile_*, scan_block.rs:612-783) as a batch: every pair has its own
+    PSSM and per-position gap open / close costs; compared with the oracle pair by pair."""
+    rng = np.random.default_rng(41 + size[1] + len(mode))
+    cases = [_pssm_case(rng, int(rng.integers(1, 500)), size[1]) for _ in range(120)]
+    cases.append((b"", cases[0][1]))
+    pool = np.frombuffer(b"".join(q for q, _ in cases) + b"\0" * 8, np.uint8)
+    q_len = np.array([len(q) for q, _ in cases], np.uint32)
+    q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.uint64)
+    m = 0
+    for name in mode:
+        m |= {"trace": hip.TRACE, "x_drop": hip.X_DROP}[name]
+    b = hip.ProfileBatchAligner([p for _, p in cases], size, 30, m, pool, q_off, q_len)
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"]) if "trace" in mode else (None, None)
+    for k, (q, p) in enumerate(cases):
+        ref = oracle.align_profile(q, p, size, 30, mode)
+        got = (int(res["score"][k]), int(res["query_idx"][k]), int(res["reference_idx"][k]), int(res["cells"][k]))
+        assert got == (ref["score"], ref["query_idx"], ref["reference_idx"], ref["cells"]), (k, len(q), p.str_len, got, ref)
+        if "trace" in mode:
+            assert hip.runs_to_string(runs[int(off[k]): int(off[k + 1])]) == ref["cigar"], k
+    b.close()
