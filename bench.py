@@ -21,9 +21,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# roofline constants (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz, HBM3E 8 TB/s)
+# roofline constants (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz, HBM3E 8 TB/s). A wave64 VALU instruction
+# occupies its SIMD for 4 cycles (measured for v_pk_add_i16 / v_pk_max_i16 / v_max_i32_dpp, tools/dev/valu_rate.hip),
+# i.e. 64 lanes per CU per clock; packed i16 doubles that: 256 x 64 x 2 x 2.4e9 = 78.6 T int16-op/s.
 HBM_PEAK_GBS = 8000.0
-VALU_PEAK_INT16_TOPS = 256 * 4 * 32 * 2 * 2.4e9 / 1e12   # packed 2 x i16 per lane per clock = 157.3 T int16-op/s
+VALU_PEAK_INT16_TOPS = 256 * 64 * 2 * 2.4e9 / 1e12
 OPS_PER_CELL = {"xdrop": 14, "xdrop+trace": 20, "global": 11}      # algorithmic int16 ops per DP cell
 BYTES_PER_CELL = {"xdrop": 0.008, "xdrop+trace": 0.52, "global": 0.008}   # algorithmic HBM bytes per cell
 

@@ -275,12 +275,12 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
     }
 }
 
-__device__ void traceback_consumer(const BatchParams& bp) {
+__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
     int phase = IDLE;
     uint32_t claimed = 0;
     TbLane t{};
-    const uint32_t eq = bp.flags;   // mode bits the walk looks at: CIGAR_EQ, LOCAL_START, FREE_QUERY_START_GAPS
+    const uint32_t eq = bp.flags & flag_mask;   // mode bits the walk looks at: CIGAR_EQ, LOCAL_START, FREE_QUERY_START_GAPS
     uint32_t* head = bp.tb_ctrl + 32;
     // A walk is a long dependent chain of short instructions sharing its SIMD with VALU-saturating fill waves; without
     // priority it gets a quarter of the issue slots and every pending walk pins a whole trace slot meanwhile.
@@ -360,7 +360,9 @@ __device__ void traceback_consumer(const BatchParams& bp) {
 }
 
 // ------------------------------------------------------------------ driver
-template <int PMAX, int KIND, bool TRACE, bool XDROP>
+// SPECIAL: the batch uses LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS. A separate instantiation, so the
+// common kernels carry none of that state (it costs registers: +30 % spills when folded into one kernel).
+template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL>
 struct Aligner {
     // The batch descriptor lives in device memory. Only the scalars the step loop needs are copied into registers;
     // everything else (a couple of dozen per-pair output pointers) is re-read where it is used, once per pair, so it
@@ -418,7 +420,7 @@ struct Aligner {
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
         if (nblocks >= h_blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
         // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
-        const uint32_t words = (w * h / 8) * ((h_flags & F_LOCAL) ? 5u : 1u);
+        const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 5u : 1u);
         if ((uint64_t)trace_top + words > h_trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
         if (is_lane(0)) {
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
@@ -505,8 +507,8 @@ struct Aligner {
             pv.aa_pos = (const short*)(r + (uint64_t)pv.P * 32);
             pv.goC = pv.aa_pos + (uint64_t)pv.P * 32; pv.clC = pv.goC + pv.P; pv.goR = pv.clC + pv.P;
         }
-        const uint32_t special = h_flags & (F_LOCAL | F_FQS | F_FQE);
-        const bool FQE = h_flags & F_FQE;
+        const uint32_t special = SPECIAL ? h_flags & (F_LOCAL | F_FQS | F_FQE) : 0u;
+        const bool FQE = SPECIAL && (h_flags & F_FQE);
         FqeOut fq{0, 0};
         // scratch reset (scan_block.rs:1322-1339): borders to MIN = 0. The checkpoint copies need no reset: they are
         // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
@@ -589,17 +591,16 @@ struct Aligner {
             BA_TSTAMP(ts1);
             Best cur{0, 0, 0};
             const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
-            if constexpr (KIND != KIND_PROFILE) {
-                if (fast) {
+#define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
+#define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
+            if (fast) {
+                if constexpr (KIND != KIND_PROFILE) {
                     fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
                     cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
                                                                   off_add, tout, cells, &fs, prof);
                     prefetch_seq(si, sj, block_size);   // for the next step, behind this step's stores
                 }
             }
-#define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
-#define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
-            if (fast) { }
             else if (rh <= 128) BA_PLACE(1);
             else if (PMAX >= 2 && rh == 256) BA_PLACE(2);
             else if (PMAX >= 4 && rh == 512) BA_PLACE(4);
@@ -736,7 +737,7 @@ struct Aligner {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             if (is_lane(0)) {
                 uint32_t st = 0;
-                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, h_flags, coldp()->cig_ops,
+                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, SPECIAL ? h_flags : (h_flags & F_CIGAR_EQ), coldp()->cig_ops,
                                  coldp()->cig_off[pair], coldp()->cig_off[pair + 1], &st);
                 status |= st;
             }
@@ -754,7 +755,7 @@ struct Aligner {
 
 // Persistent kernel: WAVES_PER_WG independent waves per workgroup (they share only the read-only score table in LDS);
 // every wave pulls pair indices from a global counter until the batch is exhausted.
-template <int PMAX, int KIND, bool TRACE, bool XDROP>
+template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL>
 __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_align(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
@@ -804,7 +805,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
-        traceback_consumer(bp);
+        traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ);
         return;
     }
     // dense index among the fill waves (consumer waves of this and earlier workgroups skipped)
@@ -818,7 +819,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         if (pair >= bp.n) break;
         const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
         if (++turn == bp.slots_per_wave) turn = 0;
-        Aligner<PMAX, KIND, TRACE, XDROP> al(bp, L, fc);
+        Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
         BA_TSTAMP(tw0);
         const bool got_slot = !batch_traceback || al.acquire_slot(slot);
         BA_TSTAMP(tw1);

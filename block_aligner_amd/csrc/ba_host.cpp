@@ -24,7 +24,9 @@ using ba::BlockRec;
 // ------------------------------------------------------------------ kernel entry points (one TU per kind x class)
 #define BA_DECL(K, P)                                                                                                 \
     extern "C" hipError_t ba_launch_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);       \
-    extern "C" hipError_t ba_occupancy_k##K##_p##P(int, int, unsigned, int*);
+    extern "C" hipError_t ba_occupancy_k##K##_p##P(int, int, unsigned, int*);                                         \
+    extern "C" hipError_t ba_launch_s_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);     \
+    extern "C" hipError_t ba_occupancy_s_k##K##_p##P(int, int, unsigned, int*);
 #define BA_DECL_KIND(K) BA_DECL(K, 1) BA_DECL(K, 2) BA_DECL(K, 4) BA_DECL(K, 8) BA_DECL(K, 16)
 BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
@@ -34,8 +36,12 @@ typedef hipError_t (*LaunchFn)(int, int, unsigned, unsigned, hipStream_t, const 
 typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 #define BA_ROW(K) {ba_launch_k##K##_p1, ba_launch_k##K##_p2, ba_launch_k##K##_p4, ba_launch_k##K##_p8, ba_launch_k##K##_p16}
 #define BA_OROW(K) {ba_occupancy_k##K##_p1, ba_occupancy_k##K##_p2, ba_occupancy_k##K##_p4, ba_occupancy_k##K##_p8, ba_occupancy_k##K##_p16}
-static const LaunchFn g_launch[4][5] = {BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)};
-static const OccFn g_occ[4][5] = {BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)};
+#define BA_SROW(K) {ba_launch_s_k##K##_p1, ba_launch_s_k##K##_p2, ba_launch_s_k##K##_p4, ba_launch_s_k##K##_p8, ba_launch_s_k##K##_p16}
+#define BA_SOROW(K) {ba_occupancy_s_k##K##_p1, ba_occupancy_s_k##K##_p2, ba_occupancy_s_k##K##_p4, ba_occupancy_s_k##K##_p8, ba_occupancy_s_k##K##_p16}
+// [special modes?][kind][block class]
+static const LaunchFn g_launch[2][4][5] = {{BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)}, {BA_SROW(0), BA_SROW(1), BA_SROW(2), BA_SROW(3)}};
+static const OccFn g_occ[2][4][5] = {{BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)}, {BA_SOROW(0), BA_SOROW(1), BA_SOROW(2), BA_SOROW(3)}};
+static inline int special_of(uint32_t mode) { return (mode & (BA_LOCAL_START | BA_FREE_QUERY_START_GAPS | BA_FREE_QUERY_END_GAPS)) ? 1 : 0; }
 constexpr int BA_KIND_PROFILE_ = ba::KIND_PROFILE;   // batches whose "reference" is an AAProfile (sequence bytes: AA alphabet)
 
 // ------------------------------------------------------------------ errors
@@ -325,7 +331,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    if (g_occ[kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
+    if (g_occ[special_of(mode)][kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return nullptr;
     }
     if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
@@ -403,7 +409,7 @@ static int batch_run(BaBatch* b, float* kernel_ms) {
     HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    HIP_TRY(g_launch[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
+    HIP_TRY(g_launch[special_of(b->mode)][b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));

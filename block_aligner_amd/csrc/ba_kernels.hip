@@ -10,27 +10,36 @@
 #error "define BA_PMAX"
 #endif
 
+#ifndef BA_SPECIAL
+#define BA_SPECIAL 0   // 1: the kernels of this TU handle LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS batches
+#endif
+
 #define BA_CAT_(a, b, c, d) a##b##c##d
 #define BA_CAT(a, b, c, d) BA_CAT_(a, b, c, d)
+#if BA_SPECIAL
+#define BA_LAUNCH BA_CAT(ba_launch_s_k, BA_KIND, _p, BA_PMAX)
+#define BA_OCC BA_CAT(ba_occupancy_s_k, BA_KIND, _p, BA_PMAX)
+#else
 #define BA_LAUNCH BA_CAT(ba_launch_k, BA_KIND, _p, BA_PMAX)
 #define BA_OCC BA_CAT(ba_occupancy_k, BA_KIND, _p, BA_PMAX)
+#endif
 
 template <bool TRACE, bool XDROP>
 static hipError_t launch1(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
     if (lds > 64 * 1024) {   // more than the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
-        hipError_t e = hipFuncSetAttribute((const void*)ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP, (BA_SPECIAL != 0)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP, (BA_SPECIAL != 0)><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
     return hipGetLastError();
 }
 template <bool TRACE, bool XDROP>
 static hipError_t occ1(int* blocks_per_cu, unsigned lds) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP, (BA_SPECIAL != 0)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP>, ba::WAVES_PER_WG * 64, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_align<BA_PMAX, BA_KIND, TRACE, XDROP, (BA_SPECIAL != 0)>, ba::WAVES_PER_WG * 64, lds);
 }
 
 extern "C" hipError_t BA_LAUNCH(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
@@ -42,7 +51,7 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
     return xdrop ? occ1<false, true>(blocks_per_cu, lds) : occ1<false, false>(blocks_per_cu, lds);
 }
 
-#if BA_KIND == 0 && BA_PMAX == 1
+#if BA_KIND == 0 && BA_PMAX == 1 && !BA_SPECIAL
 // kernels that exist once
 // Traceback from an arbitrary end cell over slot 0's trace (the per-handle API: block_cigar_* after block_align_*).
 __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {

@@ -16,11 +16,20 @@ if want:
     for row in c.execute(f"select {', '.join(want)} from kernels order by start limit 40"):
         lines.append("| " + " | ".join(str(x) for x in row) + " |")
 try:
+    ccols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    kcol = next((x for x in ccols if x in ("kernel_name", "name", "kernel")), None)
+    if kcol and "counter_name" in ccols and "value" in ccols and "dispatch_id" in ccols:
+        # counters are stored per dimension instance (XCD / SE / ...): sum them per dispatch, then average over dispatches
+        agg = c.execute(f"select {kcol}, counter_name, count(distinct dispatch_id), sum(value) from counters_collection group by {kcol}, counter_name").fetchall()
+        if agg:
+            lines += ["", "## counter totals (summed over all hardware instances; per dispatch = total / dispatches)", "",
+                      "| kernel | counter | dispatches | total | per dispatch |", "|---|---|---|---|---|"]
+            for k, cn, nd, tot in agg:
+                lines.append(f"| `{k}` | {cn} | {nd} | {tot:.0f} | {tot / max(nd, 1):.0f} |")
     rows = c.execute("select * from counters_collection limit 2000").fetchall()
     if rows:
-        ccols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
         lines += ["", "## counters (view counters_collection)", "", "| " + " | ".join(ccols) + " |", "|" + "---|" * len(ccols)]
-        for row in rows[:200]:
+        for row in rows[:40]:
             lines.append("| " + " | ".join(str(x) for x in row) + " |")
 except Exception as e:
     lines.append(f"(no counters: {e})")
