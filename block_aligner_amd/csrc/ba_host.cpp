@@ -665,6 +665,64 @@ void block_free_aaprofile(AAProfile* p) { delete p; }
 
 }  // extern "C"
 
+
+// Block::align_exp / align_profile_exp over a batch (scan_block.rs:884-902, 974-992): a second (third, ...) kernel
+// pass over the subset of pairs that stayed below the target score, with the min block size doubled each time.
+template <class MakeBatch>
+static int batch_exp(size_t n, SizeRange size, int32_t target, MakeBatch make, AlignResult* results, uintptr_t* reached_min) {
+    if (!results || !reached_min) return fail("null argument");
+    size_t min_size = size.min < 16 ? 16 : size.min;
+    const size_t max_size = size.max < 16 ? 16 : size.max;
+    std::vector<size_t> todo(n);
+    for (size_t p = 0; p < n; p++) { todo[p] = p; reached_min[p] = 0; }
+    while (min_size <= max_size && !todo.empty()) {
+        std::unique_ptr<BaBatch> b(make(todo, SizeRange{min_size, max_size}));
+        if (!b) return 1;
+        if (batch_run(b.get(), nullptr)) return 1;
+        const size_t m = todo.size();
+        std::vector<int32_t> sc(m); std::vector<uint32_t> qi(m), ri(m), st(m);
+        if (ba_batch_results(b.get(), sc.data(), qi.data(), ri.data(), nullptr, nullptr, st.data())) return 1;
+        std::vector<size_t> next;
+        for (size_t k = 0; k < m; k++) {
+            const size_t p = todo[k];
+            if (st[k]) return fail("pair %zu failed on the device (status 0x%x)", p, st[k]);
+            results[p] = AlignResult{sc[k], qi[k], ri[k]};
+            if (sc[k] >= target) reached_min[p] = min_size; else next.push_back(p);
+        }
+        todo.swap(next);
+        min_size *= 2;
+    }
+    return 0;
+}
+
+extern "C" {
+int block_batch_align_exp(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, int32_t target_score, uint32_t mode,
+                          const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len,
+                          uintptr_t n, AlignResult* results, uintptr_t* reached_min) {
+    if (!matrix || !pool || !q_off || !q_len || !r_off || !r_len) return fail("null argument");
+    if (kind == BA_KIND_PROFILE_) return fail("use block_batch_align_profile_exp for profiles");
+    mode &= ~(uint32_t)(BA_TRACE | BA_CIGAR_EQ);   // scores only: trace the finished pairs with a plain batch at reached_min
+    return batch_exp(n, size, target_score, [&](const std::vector<size_t>& idx, SizeRange s) {
+        return batch_build(kind, matrix, gaps, s, x_drop, mode, idx.size(), false, [&](size_t k, int w, const uint8_t** ptr, size_t* len) {
+            const size_t p = idx[k];
+            if (w == 0) { *ptr = pool + q_off[p]; *len = q_len[p]; } else { *ptr = pool + r_off[p]; *len = r_len[p]; }
+        });
+    }, results, reached_min);
+}
+int block_batch_align_profile_exp(const AAProfile* const* profiles, SizeRange size, int32_t x_drop, int32_t target_score, uint32_t mode,
+                                  const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, uintptr_t n,
+                                  AlignResult* results, uintptr_t* reached_min) {
+    if (!profiles || !pool || !q_off || !q_len || n == 0 || !profiles[0]) return fail("null argument");
+    mode &= ~(uint32_t)(BA_TRACE | BA_CIGAR_EQ);
+    const Gaps g{0, profiles[0]->gap_extend};
+    return batch_exp(n, size, target_score, [&](const std::vector<size_t>& idx, SizeRange s) {
+        return batch_build(BA_KIND_PROFILE_, nullptr, g, s, x_drop, mode, idx.size(), false,
+                           [&](size_t k, int, const uint8_t** ptr, size_t* len) { *ptr = pool + q_off[idx[k]]; *len = q_len[idx[k]]; },
+                           [&](size_t k) { return profiles[idx[k]]; });
+    }, results, reached_min);
+}
+}  // extern "C"
+
 // ------------------------------------------------------------------ Block handles (Part 1 + generic)
 struct BlockImpl {
     uint32_t mode;                 // BA_TRACE | BA_X_DROP | ...
@@ -745,8 +803,24 @@ static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const 
     for (uint32_t k = 0; k < n; k++) cigar->ops[k] = OpLen{(Operation)(runs[k] & 15), (uintptr_t)(runs[k] >> 4)};
 }
 
+// Trace::blocks() (scan_block.rs:1676-1691): the rectangles on the trace stack of the last alignment, in fill order
+static size_t block_trace_blocks_impl(BlockImpl* b, Rectangle* out, size_t capacity) {
+    if (!(b->mode & BA_TRACE)) die("trace() requires a Block created with TRACE");
+    BaBatch* d = b->last.get();
+    if (!d) die("blocks requested before any alignment");
+    uint32_t nb, slot;
+    if (d2h(d->nblocks, &nb, 1) || d2h(d->pair_slot, &slot, 1)) die("%s", g_err.c_str());
+    if (!out) return nb;
+    std::vector<BlockRec> recs(nb);
+    if (nb && hipMemcpy(recs.data(), d->blocks.as<BlockRec>() + (size_t)slot * d->blocks_stride, (size_t)nb * sizeof(BlockRec), hipMemcpyDeviceToHost) != hipSuccess)
+        die("hipMemcpy of the rectangle list failed");
+    for (size_t k = 0; k < nb && k < capacity; k++) out[k] = Rectangle{recs[k].i, recs[k].j, recs[k].w, recs[k].h};
+    return nb;
+}
+
 extern "C" {
 
+uintptr_t block_trace_blocks_generic(BlockHandle b, Rectangle* out, uintptr_t capacity) { return block_trace_blocks_impl((BlockImpl*)b, out, capacity); }
 BlockHandle block_new_generic(uint32_t mode, uintptr_t ql, uintptr_t rl, uintptr_t max_size) { return block_new_impl(mode, ql, rl, max_size); }
 void block_align_generic(BlockHandle b, int kind, const PaddedBytes* q, const PaddedBytes* r, const void* matrix, Gaps g, SizeRange s, int32_t x) {
     block_align_impl((BlockImpl*)b, kind, q, r, matrix, g, s, x);

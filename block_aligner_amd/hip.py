@@ -30,6 +30,10 @@ class SizeRangeC(C.Structure):
     _fields_ = [("min", C.c_size_t), ("max", C.c_size_t)]
 
 
+class RectangleC(C.Structure):
+    _fields_ = [("row", C.c_size_t), ("col", C.c_size_t), ("width", C.c_size_t), ("height", C.c_size_t)]
+
+
 class AlignResultC(C.Structure):
     _fields_ = [("score", C.c_int32), ("query_idx", C.c_size_t), ("reference_idx", C.c_size_t)]
 
@@ -84,6 +88,10 @@ def lib() -> C.CDLL:
         L.block_cigar_eq_generic.argtypes = [vp, vp, vp, sz, sz, vp]
         L.block_free_generic.argtypes = [vp]
         L.block_align_profile_generic.argtypes = [vp, vp, vp, SizeRangeC, i32]
+        L.block_trace_blocks_generic.restype = sz
+        L.block_trace_blocks_generic.argtypes = [vp, vp, sz]
+        L.block_batch_align_exp.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, i32, u32, vp, vp, vp, vp, vp, sz, vp, vp]
+        L.block_batch_align_profile_exp.argtypes = [vp, SizeRangeC, i32, i32, u32, vp, vp, vp, sz, vp, vp]
         L.block_new_aaprofile.restype = vp
         L.block_new_aaprofile.argtypes = [sz, sz, i8]
         L.block_free_aaprofile.argtypes = [vp]
@@ -238,6 +246,13 @@ class _Trace:
     def cigar_eq(self, q: PaddedBytes, r: PaddedBytes, i: int, j: int, cigar: Cigar) -> None:
         lib().block_cigar_eq_generic(self._b._h, q._h, r._h, i, j, cigar._h)
 
+    def blocks(self):
+        """Trace::blocks() (scan_block.rs:1676-1691): [(row, col, width, height), ...] in fill order."""
+        n = lib().block_trace_blocks_generic(self._b._h, None, 0)
+        arr = (RectangleC * max(n, 1))()
+        lib().block_trace_blocks_generic(self._b._h, arr, n)
+        return [(r.row, r.col, r.width, r.height) for r in arr[:n]]
+
 
 class Block:
     """Block::<TRACE, X_DROP, LOCAL_START, FREE_QUERY_START_GAPS, FREE_QUERY_END_GAPS> (scan_block.rs:89, 798-1244)."""
@@ -371,6 +386,43 @@ class ProfileBatchAligner(BatchAligner):
         self._h = L.ba_batch_create_profile(arr, _size(size), x_drop, mode, pool.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, self.n)
         if not self._h:
             raise RuntimeError(last_error())
+
+
+def batch_align_exp(matrix, gaps, size, x_drop: int, target_score: int, mode: int, pool, q_off, q_len, r_off, r_len):
+    """Block::align_exp over a batch (scan_block.rs:884-902) -> (score, query_idx, reference_idx, reached_min) arrays;
+    reached_min[p] = 0 where the reference returns None."""
+    n = len(q_len)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    q_off = np.ascontiguousarray(q_off, dtype=np.uint64); r_off = np.ascontiguousarray(r_off, dtype=np.uint64)
+    q_len = np.ascontiguousarray(q_len, dtype=np.uint32); r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+    raw = matrix.raw()
+    g = GapsC(gaps.open, gaps.extend) if isinstance(gaps, S.Gaps) else GapsC(gaps[0], gaps[1])
+    res = (AlignResultC * n)()
+    reached = np.zeros(n, np.uint64)
+    if lib().block_batch_align_exp(matrix.KIND, raw.ctypes.data, g, _size(size), x_drop, target_score, mode, pool.ctypes.data,
+                                   q_off.ctypes.data, q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, n, res, reached.ctypes.data):
+        raise RuntimeError(last_error())
+    return _unpack_results(res, n) + (reached,)
+
+
+def batch_align_profile_exp(profiles, size, x_drop: int, target_score: int, mode: int, pool, q_off, q_len):
+    """Block::align_profile_exp over a batch (scan_block.rs:974-992)."""
+    n = len(q_len)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    q_off = np.ascontiguousarray(q_off, dtype=np.uint64); q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+    natives = [_NativeProfile(p) for p in profiles]
+    arr = (C.c_void_p * n)(*[x._h for x in natives])
+    res = (AlignResultC * n)()
+    reached = np.zeros(n, np.uint64)
+    if lib().block_batch_align_profile_exp(arr, _size(size), x_drop, target_score, mode, pool.ctypes.data, q_off.ctypes.data,
+                                           q_len.ctypes.data, n, res, reached.ctypes.data):
+        raise RuntimeError(last_error())
+    return _unpack_results(res, n) + (reached,)
+
+
+def _unpack_results(res, n):
+    a = np.frombuffer(res, dtype=np.dtype([("score", np.int32), ("_pad", np.int32), ("qi", np.uint64), ("ri", np.uint64)]), count=n)
+    return a["score"].copy(), a["qi"].copy(), a["ri"].copy()
 
 
 def runs_to_string(runs) -> str:

@@ -157,6 +157,10 @@ void block_cigar_generic(BlockHandle b, uintptr_t query_idx, uintptr_t reference
 void block_cigar_eq_generic(BlockHandle b, const struct PaddedBytes* q, const struct PaddedBytes* r, uintptr_t query_idx,
                             uintptr_t reference_idx, struct Cigar* cigar);
 void block_free_generic(BlockHandle b);
+/* Trace::blocks() (scan_block.rs:1676-1691): the rectangles computed for the last alignment, in fill order. Returns their
+ * number; writes at most `capacity` of them (out may be NULL to query the count). */
+struct Rectangle { uintptr_t row, col, width, height; };
+uintptr_t block_trace_blocks_generic(BlockHandle b, struct Rectangle* out, uintptr_t capacity);
 
 /* ---- batch launcher: many independent pairs, one persistent kernel launch, one wavefront per pair.
  *
@@ -204,6 +208,18 @@ int block_batch_align(int kind, const void* matrix, struct Gaps gaps, struct Siz
                       const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
                       const uint32_t* r_len, uintptr_t n_pairs, struct AlignResult* results, uint32_t* cigar_runs,
                       uint64_t cigar_capacity, uint32_t* cigar_len);
+
+/* Block::align_exp / align_profile_exp over a batch (scan_block.rs:884-902, 974-992): every pair is aligned with the min
+ * block size size.min; the pairs whose score stays below target_score go through another kernel pass with the min size
+ * doubled, until they reach the target or the min size would exceed size.max. reached_min[p] = the min block size at
+ * which pair p reached the target, 0 if it never did (results[p] is then that of the last attempt, as in the reference).
+ * Scores and end positions only: BA_TRACE / BA_CIGAR_EQ are ignored (trace the finished pairs with ba_batch_create). */
+int block_batch_align_exp(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, int32_t target_score,
+                          uint32_t mode, const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
+                          const uint32_t* r_len, uintptr_t n_pairs, struct AlignResult* results, uintptr_t* reached_min);
+int block_batch_align_profile_exp(const struct AAProfile* const* profiles, struct SizeRange size, int32_t x_drop, int32_t target_score,
+                                  uint32_t mode, const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, uintptr_t n_pairs,
+                                  struct AlignResult* results, uintptr_t* reached_min);
 
 #ifdef __cplusplus
 }

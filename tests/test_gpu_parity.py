@@ -191,3 +191,33 @@ def test_profile_batch(hip, oracle, mode, size):
         if "trace" in mode:
             assert hip.runs_to_string(runs[int(off[k]): int(off[k + 1])]) == ref["cigar"], k
     b.close()
+
+
+def test_batch_align_exp(hip, oracle):
+    """Block::align_exp as kernel passes over the shrinking subset of pairs below the target (scan_block.rs:884-902):
+    long indels make the small block sizes miss the optimum, so several passes run."""
+    pairs = synth.make_pairs(200, (600, 1500), (20, 120), 30, synth.DNA, seed=321, indels=2, indel_len=(30, 150))
+    # targets between "always reached" and "never reached"
+    base = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (512, 512), 0, ())
+    for frac in (0.5, 0.98, 1.5):
+        target = int(np.median(base["scores"]) * frac)
+        sc, qi, ri, reached = hip.batch_align_exp(NUC, (-5, -1), (32, 512), 0, target, 0, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        for p in range(len(pairs)):
+            ref = oracle.align_exp(NUC, pairs.query(p), pairs.reference(p), (-5, -1), (32, 512), 0, target)
+            assert (int(sc[p]), int(qi[p]), int(ri[p]), int(reached[p]) or None) == (ref["score"], ref["query_idx"], ref["reference_idx"], ref["reached"]), (p, target)
+
+
+def test_trace_blocks(hip, oracle):
+    """Trace::blocks(): the surviving rectangles tile what the oracle reports as surviving cells, start at the origin and
+    chain by steps of 8 (scan_block.rs:1676-1691)."""
+    rng = np.random.default_rng(9)
+    r = synth.rand_str(rng, 900, synth.DNA)
+    q = synth.mutate(rng, r, 90, synth.DNA)
+    qb, rb = q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()
+    a = hip.Block(len(qb), len(rb), 256, trace=True)
+    a.align(hip.PaddedBytes.from_bytes(qb, 256, S.NucMatrix), hip.PaddedBytes.from_bytes(rb, 256, S.NucMatrix), NUC, S.Gaps(-5, -1), (32, 256), 0)
+    blocks = a.trace().blocks()
+    ref = oracle.align(NUC, qb, rb, (-5, -1), (32, 256), 0, ("trace",))
+    assert a.res().score == ref["score"]
+    assert sum(w * h for _, _, w, h in blocks) == ref["surviving_cells"]
+    assert blocks[0][:2] == (0, 0) and all(w % 8 == 0 and h % 8 == 0 for _, _, w, h in blocks)
