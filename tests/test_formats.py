@@ -57,16 +57,16 @@ def test_pssm(tmp_path):
 
 @pytest.mark.gpu
 def test_parsed_batches_align(tmp_path, hip, oracle):
-    # README.md:44-49 pair through the two-line reader
+    # README.md:44-53 pair through the two-line reader (reference line first)
     p = tmp_path / "readme.txt"
-    p.write_bytes(b"AAAAAAAAAAAAAAAAAAAAA\nTTAAAAAATATATTTTTTTTTTTT\n".upper())
+    p.write_bytes(b"TTAAAAAAATTTTTTTTTTTT".lower() + b"\n" + b"TTTTTTTTAAAAAAATTTTTTTTT".lower() + b"\n")
     ps = F.pairs_from_two_line_text(p)
-    b = hip.BatchAligner(S.NW1, (-2, -1), (32, 32), 0, hip.TRACE | hip.CIGAR_EQ, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len)
+    b = hip.BatchAligner(S.NW1, (-2, -1), (32, 256), 0, hip.TRACE | hip.CIGAR_EQ, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len)
     b.run()
     res = b.results()
-    ref = oracle.align(S.NW1, ps.query(0), ps.reference(0), (-2, -1), (32, 32), 0, ("trace",), cigar_eq=True)
     runs, off = b.cigars(res["cigar_len"])
-    assert int(res["score"][0]) == ref["score"] and hip.runs_to_string(runs) == ref["cigar"]
+    assert (int(res["score"][0]), int(res["query_idx"][0]), int(res["reference_idx"][0])) == (7, 24, 21)
+    assert hip.runs_to_string(runs) == "2=6I16=3D"
     # a PSSM file through the profile reader and the profile batch launcher
     rng = np.random.default_rng(3)
     cases = []
