@@ -137,8 +137,12 @@ struct FastIO {
 // max over lanes 0..3 of max(lo, hi) of a packed register (quad-permute DPP reduce), wave-uniform result
 __device__ __forceinline__ int first8_max(int v) {
     int m = max((int)as_s(v).x, (int)as_s(v).y);
-    m = max(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
-    m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+    // quad_perm:[1,0,3,2] then [2,3,0,1], fused into the max (same hazard padding as wave_prefix_max)
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(m));
     return __builtin_amdgcn_readlane(m, 0);
 }   // rect max (i16 value) and, for X-drop, its resolved location
 
