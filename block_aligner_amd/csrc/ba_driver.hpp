@@ -324,7 +324,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
                 t.q = bp.pool + bp.q_off[t.pair]; t.r = bp.pool + bp.r_off[t.pair];
                 t.lo = bp.cig_off[t.pair]; t.wp = bp.cig_off[t.pair + 1];
                 t.status = bp.status[t.pair];
-                if (t.status) t.i = t.j = 0;          // the fill failed: nothing to walk
+                if (t.status || (bp.flags & 0x200u)) t.i = t.j = 0;          // the fill failed (or development switch: skip the walk)
                 phase = WALK;
             }
         } else if (phase == WALK) {
