@@ -158,17 +158,14 @@ struct TbLane {
     uint64_t wp, lo;
     const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
     uint32_t bi, bj, tbase, zoff, nch, nl; bool right, in_rect;
-    // look-ahead state: the next rectangle record, a 5-lane x 2-column-group window of this rectangle's trace words,
-    // and 16-byte windows of both sequences -- so that most cells are walked from registers
+    // look-ahead state: the next rectangle record; what the LDS record of this lane currently holds: a 5-lane x
+    // 2-column-group window of trace words (chunk tw_chunk, column groups tw_g and tw_g - 1, lanes from tw_lane0) and
+    // 16-byte windows of both sequences ([qw0, qw0 + 16), [rw0, rw0 + 16); 0xffffffff = empty)
     uint4 nrec; bool nrec_ok;
-    uint32_t tw[10]; uint32_t tw_lane0; bool tw_ok;
-    uint32_t qw[4], rw[4]; uint32_t qw0, rw0;     // windows cover [qw0, qw0 + 16) and [rw0, rw0 + 16); 0xffffffff = empty
+    uint32_t tw_chunk, tw_g, tw_lane0; bool tw_ok;
+    uint32_t qw0, rw0;
 };
 
-__device__ __forceinline__ uint32_t sel4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t k) {
-    return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
-}
-__device__ __forceinline__ uint32_t sel5(const uint32_t* w, uint32_t k) { return k == 4 ? w[4] : sel4(w[0], w[1], w[2], w[3], k); }
 __device__ __forceinline__ void tb_emit(TbLane& t, uint32_t* __restrict__ out) {
     if (t.run_len) {
         if (t.wp == t.lo) { t.status |= ST_CIGAR_OVERFLOW; t.i = t.j = 0; return; }
@@ -177,12 +174,15 @@ __device__ __forceinline__ void tb_emit(TbLane& t, uint32_t* __restrict__ out) {
 }
 __device__ __forceinline__ void tb_fail(TbLane& t) { t.status |= ST_TRACEBACK_LOST; t.i = t.j = 0; t.run_len = 0; }
 
-// One iteration of scan_block.rs:1576-1670 for one lane: either move to the next rectangle (and issue the loads that
-// will let it be walked from registers) or walk up to four cells. At most one round of memory latency per call.
-__device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned long long* tacc = nullptr) {
+// One iteration of scan_block.rs:1576-1670 for one lane: move to the rectangle that holds the current cell if needed,
+// bring the trace words around the cell (and the sequence bytes below it) into this lane's LDS record -- at most one
+// round of global-memory latency per call -- then walk up to 12 cells out of LDS: one byte read for the cell's trace
+// bits, one for the move (OP_LUT of scan_block.rs:1532-1558 as a 128-entry table), two for the =/X comparison.
+__device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned char* lrec,
+                                        const unsigned char* lut, unsigned long long* tacc = nullptr) {
     const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
     BA_TSTAMP(ts0);
-    bool fresh = true;   // may this call still issue a direct (non-window) load?
+    bool fresh = true;   // LOCAL_START only: may this call still issue a direct load?
     if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
         if (t.bidx == 0) { tb_fail(t); return; }
         t.bidx--;
@@ -195,38 +195,50 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         t.zoff = h * w / 8;
         t.right = rec.w >> 31;
         t.tbase = rec.w & 0x7fffffffu;
-        const uint32_t Hv = t.right ? h : w, ncol = t.right ? w : h;
+        const uint32_t Hv = t.right ? h : w;
         t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
         t.tw_ok = false;
-        if (t.in_rect) {
-            if (t.nch == 1 && ncol == 8 && !local) {   // a shift step: both column groups of the 4 lanes ending at the entry cell
-                const uint32_t v = t.right ? t.i - t.bi : t.j - t.bj, lc = v >> 1;
-                t.tw_lane0 = lc >= 4 ? lc - 4 : 0;
-                const uint32_t* base = t.trace + t.tbase;
+        if (!t.in_rect) return;
+    }
+    {
+        const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
+        const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
+        const uint32_t chunk = v >> 7, lc = (v & 127) >> 1, g = w >> 2;
+        if (!local && !(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u)) {
+            // the two column groups ending at the cell's and the five lanes ending at the cell's
+            t.tw_chunk = chunk; t.tw_g = g; t.tw_lane0 = lc >= 4 ? lc - 4 : 0; t.tw_ok = true;
+            const uint32_t* hi = t.trace + t.tbase + (g * t.nch + chunk) * t.nl;
+            const uint32_t* lo = g ? hi - t.nch * t.nl : hi;
+            uint32_t wv[10];
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const uint32_t l = min(t.tw_lane0 + k, t.nl - 1);
-                    t.tw[k] = base[l]; t.tw[5 + k] = base[t.nl + l];
-                }
-                t.tw_ok = true;
+            for (int k = 0; k < 5; k++) {
+                const uint32_t l = min(t.tw_lane0 + k, t.nl - 1);
+                wv[k] = hi[l]; wv[5 + k] = lo[l];
             }
-            if (eq) {   // refill the sequence windows when fewer than 8 positions are left below the current one
-                if (t.qw0 == 0xffffffffu || t.i < t.qw0 + 8 || t.i >= t.qw0 + 16) {
-                    t.qw0 = t.i >= 12 ? (t.i - 12) & ~3u : 0;
-                    const uint32_t* p = (const uint32_t*)(t.q + t.qw0);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) t.qw[k] = p[k];
-                }
-                if (t.rw0 == 0xffffffffu || t.j < t.rw0 + 8 || t.j >= t.rw0 + 16) {
-                    t.rw0 = t.j >= 12 ? (t.j - 12) & ~3u : 0;
-                    const uint32_t* p = (const uint32_t*)(t.r + t.rw0);
+            for (int k = 0; k < 10; k++) ((uint32_t*)lrec)[k] = wv[k];
+            fresh = false;
+        }
+        if (eq) {   // refill the sequence windows when fewer than 8 positions are left below the current one
+            if (t.qw0 == 0xffffffffu || t.i < t.qw0 + 8 || t.i >= t.qw0 + 16) {
+                t.qw0 = t.i >= 12 ? (t.i - 12) & ~3u : 0;
+                const uint32_t* p = (const uint32_t*)(t.q + t.qw0);
+                uint32_t b4[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) t.rw[k] = p[k];
-                }
+                for (int k = 0; k < 4; k++) b4[k] = p[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ((uint32_t*)lrec)[10 + k] = b4[k];
+            }
+            if (t.rw0 == 0xffffffffu || t.j < t.rw0 + 8 || t.j >= t.rw0 + 16) {
+                t.rw0 = t.j >= 12 ? (t.j - 12) & ~3u : 0;
+                const uint32_t* p = (const uint32_t*)(t.r + t.rw0);
+                uint32_t b4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) b4[k] = p[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ((uint32_t*)lrec)[14 + k] = b4[k];
             }
         }
-        if (!t.in_rect) return;
-        fresh = false;    // this call already spent its round of memory latency on the window loads
     }
 #ifdef BA_TIMING
     const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
@@ -240,48 +252,53 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
         const uint32_t lc = (v & 127) >> 1;
         if (t.right && fqs && t.i == 0) { t.i = t.j = 0; break; }                       // scan_block.rs:1597-1599
-        uint32_t word;
-        if (local) {   // zero mask first (scan_block.rs:1604-1611); no register window in this mode: one cell per call
+        uint32_t nib;
+        if (local) {   // zero mask first (scan_block.rs:1604-1611); no window in this mode: one cell per call
             if (!(s == 0 && fresh)) break;
-            const uint32_t widx = t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc;
-            word = t.trace[widx];
+            const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
             if (t.table == 0) {
                 const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
                 if ((z >> ((v & 1) * 16)) & 1) { t.i = t.j = 0; break; }
             }
-        } else if (t.tw_ok && lc >= t.tw_lane0 && lc < t.tw_lane0 + 5) {
-            const uint32_t k = lc - t.tw_lane0;
-            word = (w >> 2) ? sel5(t.tw + 5, k) : sel5(t.tw, k);
-        } else if (s == 0 && fresh) {
-            word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
-        } else break;
-        const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 "differs", bit 3 "equal"
-        const Move m = tb_lut(t.right, nib & 3, nib >> 2, t.table);
-        uint32_t op = m.op;
-        if (eq && op == 1) {
-            uint32_t qb, rb;
-            const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
-            if (t.qw0 != 0xffffffffu && qo < 16 && t.rw0 != 0xffffffffu && ro < 16) {
-                qb = (sel4(t.qw[0], t.qw[1], t.qw[2], t.qw[3], qo >> 2) >> ((qo & 3) * 8)) & 0xff;
-                rb = (sel4(t.rw[0], t.rw[1], t.rw[2], t.rw[3], ro >> 2) >> ((ro & 3) * 8)) & 0xff;
-            } else if (s == 0 && fresh) { qb = t.q[t.i]; rb = t.r[t.j]; }
-            else break;
-            op = qb == rb ? 2 : 3;
+            nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;
+        } else {
+            const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
+            if ((v >> 7) != t.tw_chunk || gi > 1u || k > 4u) break;                     // left the window: next call reloads it
+            const uint32_t byte = lrec[gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1)];
+            nib = ((byte >> ((w & 1) * 4)) ^ 7u) & 15u;                                 // bits 0-2 "differs", bit 3 "equal"
         }
-        if (m.di > t.i || m.dj > t.j) { tb_fail(t); return; }   // would leave the matrix: corrupt trace
-        t.i -= m.di; t.j -= m.dj; t.table = m.next;
+        const uint32_t m = lut[((uint32_t)t.right << 6) | (t.table << 4) | nib];        // op | di << 3 | dj << 4 | next << 5
+        uint32_t op = m & 7u;
+        const uint32_t di = (m >> 3) & 1u, dj = (m >> 4) & 1u;
+        if (eq && op == 1) {
+            const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
+            if (qo > 15u || ro > 15u) break;                                            // next call refills the windows
+            op = lrec[40 + qo] == lrec[56 + ro] ? 2 : 3;
+        }
+        if (di > t.i || dj > t.j) { tb_fail(t); return; }   // would leave the matrix: corrupt trace
+        t.i -= di; t.j -= dj; t.table = m >> 5;
         if (op == t.run_op) t.run_len++;
         else { tb_emit(t, out); t.run_op = op; t.run_len = 1; }
     }
 }
 
-__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask) {
+__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
     int phase = IDLE;
     uint32_t claimed = 0;
     TbLane t{};
     const uint32_t eq = bp.flags & flag_mask;   // mode bits the walk looks at: CIGAR_EQ, LOCAL_START, FREE_QUERY_START_GAPS
     uint32_t* head = bp.tb_ctrl + 32;
+    // this lane's LDS record and the move table (scan_block.rs:1532-1558), two entries built per lane
+    unsigned char* lrec = tb_lds + (uint32_t)lane_id() * TB_LANE_BYTES;
+    unsigned char* lut = tb_lds + TB_LUT_OFFSET;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const uint32_t idx = (uint32_t)lane_id() + 64u * e;
+        const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 3, (idx >> 4) & 3);
+        lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
+    }
+    lds_sync();
     // A walk is a long dependent chain of short instructions sharing its SIMD with VALU-saturating fill waves; without
     // priority it gets a quarter of the issue slots and every pending walk pins a whole trace slot meanwhile.
     __builtin_amdgcn_s_setprio(3);
@@ -315,7 +332,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
                 phase = IDLE;
             } else if (got) {
                 t = TbLane{};
-                t.qw0 = t.rw0 = 0xffffffffu;
+                t.qw0 = t.rw0 = 0xffffffffu; t.tw_ok = false;
                 t.slot = entry - 1;
                 const SlotInfo si = bp.slot_info[t.slot];
                 t.pair = si.pair; t.i = si.end_i; t.j = si.end_j; t.bidx = si.nblocks;
@@ -330,10 +347,10 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
         } else if (phase == WALK) {
 #ifdef BA_TIMING
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, c_sec);
+            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut, c_sec);
             c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
 #else
-            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops);
+            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut);
 #endif
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
@@ -805,7 +822,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
-        traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ);
+        traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
+                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(bp.max_size));
         return;
     }
     // dense index among the fill waves (consumer waves of this and earlier workgroups skipped)

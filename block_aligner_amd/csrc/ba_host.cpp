@@ -325,7 +325,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return nullptr; }
-    b->lds = ba::lds_wg_bytes_h(kind, (uint32_t)max_size);
+    b->lds = ba::lds_wg_bytes_h(kind, (uint32_t)max_size) + (trace ? ba::TB_LDS_BYTES : 0u);   // + the traceback wave's windows
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return nullptr; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
@@ -350,8 +350,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     b->tb_stride = 0; b->slots_per_wave = 1;
     b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
     if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
-        // 3 is coprime with the 8 XCDs the workgroups are dealt over, so the traceback waves land on every XCD
-        uint32_t stride = b->grid >= 32 ? 3 : 2;
+        // 5 is coprime with the 8 XCDs the workgroups are dealt over, so the traceback waves land on every XCD; one
+        // traceback wave per 39 fill waves keeps up with config 3 with margin (7 does not)
+        uint32_t stride = b->grid >= 32 ? 5 : 2;
         if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
@@ -359,7 +360,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         (void)hipMemGetInfo(&free_b, &total_b);
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
-        uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (186 GB at config 3)
+        uint32_t spw = 3;   // one being filled + two pending walks per fill wave, HBM permitting (142 GB at config 3)
         if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         b->slots_per_wave = spw;
