@@ -586,6 +586,13 @@ struct Aligner {
                 const int lane = lane_id();
                 const bool hit = pf_B == block_size && ((dir == DIR_RIGHT && pf_si == si && pf_sj + STEP == sj) ||
                                                         (dir == DIR_DOWN && pf_si + STEP == si && pf_sj == sj));
+#ifdef BA_TIMING
+                {   // how long does the step wait for its (prefetched) sequence bytes, i.e. for everything older in the in-order counter?
+                    const unsigned long long tv0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    prof[18] += __builtin_amdgcn_s_memtime() - tv0; prof[19] += hit ? 1 : 0;
+                }
+#endif
                 int vc;
                 if (hit) { vc = right ? pf_qv : pf_rv; fs.col_chars = right ? pf_rc : pf_qc; }
                 else {
@@ -728,7 +735,7 @@ struct Aligner {
         BA_TADD(prof, 15, tr0, tr1);
 #ifdef BA_TIMING
         prof[16] += steps;
-        if (coldp()->prof && is_lane(0)) for (int k = 0; k < 17; k++) atomicAdd(coldp()->prof + k, prof[k]);
+        if (coldp()->prof && is_lane(0)) for (int k = 0; k < 20; k++) if (k != 17) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
         int score; uint32_t ri, rj;
         if (XDROP || FQE) { score = best_max; ri = best_i; rj = best_j; }
@@ -776,7 +783,7 @@ template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL>
 __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_align(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
-    const int wave = (int)threadIdx.x >> 6;
+    const int wave = uni((int)threadIdx.x >> 6);   // wave-uniform: keeps every per-wave pointer (LDS borders, trace slot) in SGPRs
     // ---- workgroup-shared scoring table
     {
         char* tab = smem;

@@ -16,9 +16,10 @@ prof = np.zeros(32, np.uint64)
 H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
 H.lib().ba_batch_prof(b._h, prof.ctypes.data)
 names = {0: "fast prologue", 1: "fast columns", 2: "fast epilogue", 4: "generic<=128 prologue", 5: "generic<=128 columns", 6: "generic<=128 epilogue",
-         8: "tall prologue", 9: "tall columns", 10: "tall epilogue", 12: "driver: rect setup", 13: "driver: place (all)", 14: "driver: post-step", 15: "pair total", 17: "waiting for a free trace slot"}
+         8: "tall prologue", 9: "tall columns", 10: "tall epilogue", 12: "driver: rect setup", 13: "driver: place (all)", 14: "driver: post-step", 15: "pair total", 17: "waiting for a free trace slot", 18: "fast step: wait for outstanding memory ops"}
 tot = float(prof[15]); steps = float(prof[16])
 print(f"pairs={n} trace={trace} kernel_ms={ms:.2f} steps/pair={steps/n:.0f} cycles/pair={tot/n:.0f} (s_memtime ticks)")
+print(f"  prefetch hits per step: {float(prof[19])/max(steps,1):.3f}")
 for k, v in names.items():
     print(f"  {v:28s} {float(prof[k])/n:12.0f} ticks/pair  {100*float(prof[k])/tot:5.1f}%   {float(prof[k])/max(steps,1):8.1f} ticks/step")
 if prof[26]:
