@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
     {
         const int g = bp.gap_extend;
         fc.gap_extend = g;
-        fc.go2 = splat(bp.gap_open); fc.ge2 = splat(g); fc.ome2 = subs(splat(bp.gap_open), splat(g));
+        fc.go2 = splat(bp.gap_open); fc.ge2 = splat(g); fc.ome2 = splat(clamp16(bp.gap_open - g));   // (scalar arithmetic: stays in an SGPR)
         fc.g12 = pk(g, 2 * g);
         fc.ones = 0x00010001;
         fc.laneKG = lane * 2 * g; fc.lanem1KG = lane ? (lane - 1) * 2 * g : -(1 << 29);
