@@ -403,7 +403,7 @@ struct Aligner {
     unsigned long long cells = 0;
     // sequence bytes for the next shift step, fetched one step ahead for both possible directions
     int pf_qv = 0, pf_rv = 0, pf_qc = 0, pf_rc = 0;
-    uint32_t pf_si = 0, pf_sj = 0, pf_B = 0;   // pf_B = 0: nothing prefetched
+    bool pf_ok = false;   // the prefetched bytes serve the next step if it is a shift by 8 from where they were fetched
     FastIO fs;
 #ifdef BA_TIMING
     unsigned long long prof[32] = {};
@@ -417,7 +417,7 @@ struct Aligner {
         pf_rv = *(const unsigned short*)(r + sj + 2 * lane);
         pf_qc = q[si + B + (lane & 7)];
         pf_rc = r[sj + B + (lane & 7)];
-        pf_si = si; pf_sj = sj; pf_B = B;
+        pf_ok = true;
     }
     // While the block is a single chunk (<= 128 cells) the whole checkpoint is four VGPRs: a fast step parks its
     // register images here instead of storing to memory (D_col, C_col, D_row, R_row order).
@@ -545,8 +545,10 @@ struct Aligner {
         Best grow{0, 0, 0};
         int off_add = 0;
 
-        const uint32_t max_steps = 64u * ((qlen + rlen) / STEP + 64u);   // watchdog: far above any legal run
+        uint32_t step_budget = 64u * ((qlen + rlen) / STEP + 64u);   // watchdog: far above any legal run
+#ifdef BA_TIMING
         uint32_t steps = 0;
+#endif
         BA_TSTAMP(tr0);
         for (;;) {
             BA_TSTAMP(ts0);
@@ -554,7 +556,10 @@ struct Aligner {
             const uint8_t* seqV; const uint8_t* seqC; uint32_t lenV, lenC, ri, rj, rw, rh;
             short *Dc, *Cc, *Dr, *Rr; int corner = 0; bool right;
             if (gphase == 0) {
-                if (++steps > max_steps) { status |= ST_WATCHDOG; break; }
+                if (--step_budget == 0) { status |= ST_WATCHDOG; break; }
+#ifdef BA_TIMING
+                steps++;
+#endif
                 prev_off = off;
                 grow = Best{0, 0, 0};
             }
@@ -581,11 +586,12 @@ struct Aligner {
             }
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
             const bool fast = KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special;
+            const bool pf_hit = pf_ok;   // only a fast step that ends in a plain shift leaves usable prefetched bytes behind
+            pf_ok = false;
             if (fast) {   // before any store of this step: the memory counter is in-order
                 // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
                 const int lane = lane_id();
-                const bool hit = pf_B == block_size && ((dir == DIR_RIGHT && pf_si == si && pf_sj + STEP == sj) ||
-                                                        (dir == DIR_DOWN && pf_si + STEP == si && pf_sj == sj));
+                const bool hit = pf_hit;
 #ifdef BA_TIMING
                 {   // how long does the step wait for its (prefetched) sequence bytes, i.e. for everything older in the in-order counter?
                     const unsigned long long tv0 = __builtin_amdgcn_s_memtime();
@@ -714,6 +720,7 @@ struct Aligner {
             if (block_size > min_size && y_drop_iter == 0) {   // SHRINK
                 const int shrink_max = max(lds_suffix_max2(L.D_row, block_size), lds_suffix_max2(L.D_col, block_size));
                 if (shrink_max >= mx) {
+                    pf_ok = false;   // the block moves and halves: the prefetched bytes are for the old position
                     prev_dir = DIR_GROW;
                     block_size /= 2;
                     lds_copy(L.D_col, L.D_col + block_size, block_size); lds_copy(L.C_col, L.C_col + block_size, block_size);
