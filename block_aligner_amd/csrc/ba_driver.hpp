@@ -384,7 +384,7 @@ struct Aligner {
     // The batch descriptor lives in device memory. Only the scalars the step loop needs are copied into registers;
     // everything else (a couple of dozen per-pair output pointers) is re-read where it is used, once per pair, so it
     // does not sit in SGPRs across the whole persistent loop and get spilled to VGPR lanes.
-    uint32_t h_flags, h_min_size, h_max_size, h_blocks_stride, h_trace_stride; int h_x_drop;
+    uint32_t h_flags, h_max_size; int h_x_drop;
     // cold fields: scalar loads from the kernel-argument segment at the point of use (the empty asm keeps the compiler
     // from hoisting them out of the persistent loop and pinning ~50 SGPRs)
     typedef const __attribute__((address_space(4))) BatchParams* ColdPtr;
@@ -430,15 +430,14 @@ struct Aligner {
     }
 
     __device__ Aligner(const BatchParams& b, const WaveLds& L_, const FillConsts& fc_) : L(L_), fc(fc_) {
-        h_flags = b.flags; h_min_size = b.min_size; h_max_size = b.max_size; h_x_drop = b.x_drop;
-        h_blocks_stride = (uint32_t)b.blocks_stride; h_trace_stride = (uint32_t)b.trace_stride;
+        h_flags = b.flags; h_max_size = b.max_size; h_x_drop = b.x_drop;
     }
 
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
-        if (nblocks >= h_blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
+        if (nblocks >= (uint32_t)coldp()->blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
         // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
         const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 5u : 1u);
-        if ((uint64_t)trace_top + words > h_trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
+        if ((uint64_t)trace_top + words > coldp()->trace_stride) { status |= ST_TRACE_OVERFLOW; return; }
         if (is_lane(0)) {
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
@@ -516,7 +515,7 @@ struct Aligner {
     __device__ void run(uint32_t pair, uint32_t slot, bool batch_traceback) {
         q = coldp()->pool + coldp()->q_off[pair]; r = coldp()->pool + coldp()->r_off[pair];
         qlen = coldp()->q_len[pair]; rlen = coldp()->r_len[pair];
-        const uint32_t min_size = h_min_size, max_size = h_max_size;
+        const uint32_t min_size = coldp()->min_size, max_size = h_max_size;
         ProfileView pv{};
         if constexpr (KIND == KIND_PROFILE) {   // r points at the pair's AAProfile image (ba_params.h)
             pv.P = profile_positions(rlen, max_size);
