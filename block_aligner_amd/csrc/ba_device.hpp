@@ -56,6 +56,14 @@ __device__ __forceinline__ int set_lane0(int v, int uniform_val) {
     asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(uniform_val)));
     return v;
 }
+// Rarely read wave-uniform state parked in the lanes of one VGPR (one v_writelane per update) instead of in SGPRs:
+// the step loop is over the SGPR budget, and what the compiler picks to spill is not what is cold.
+template <int LANE>
+__device__ __forceinline__ void park(int& v, int uniform_val) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(uniform_val)), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ int unpark(int v) { return __builtin_amdgcn_readlane(v, LANE); }
 // a[l-1] + b[l] in one instruction (lane 0: 0 + b[0])
 __device__ __forceinline__ int add_shr1(int a, int b) {
     int t;

@@ -398,7 +398,8 @@ struct Aligner {
     const uint8_t* q; const uint8_t* r;
     uint32_t qlen, rlen;
     uint32_t* trace; BlockRec* blocks; short* ckpt;   // this wave's slot in the global scratch arenas
-    uint32_t trace_top = 0, nblocks = 0, ck_trace_top = 0, ck_nblocks = 0;
+    uint32_t trace_top = 0, nblocks = 0;
+    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j (see park())
     uint32_t status = 0;
     unsigned long long cells = 0;
     // sequence bytes for the next shift step, fetched one step ahead for both possible directions
@@ -533,12 +534,12 @@ struct Aligner {
         lds_fill0(temp1, 32);
 
         uint32_t si = 0, sj = 0;
-        int best_max = 0; uint32_t best_i = 0, best_j = 0;
+        int best_max = 0;
+        parked = 0;
         int prev_dir = DIR_GROW, dir = DIR_GROW;
         uint32_t prev_size = 0, block_size = min_size;
         int off = 0, prev_off = 0, off_max = 0;
         uint32_t y_drop_iter = 0; int x_drop_iter = 0;
-        uint32_t i_ckpt = 0, j_ckpt = 0; int off_ckpt = 0;
         int D_corner = 0;
         int gphase = 0;                 // 0 = first rectangle of this driver step, 1 = second rectangle of a grow
         Best grow{0, 0, 0};
@@ -660,7 +661,7 @@ struct Aligner {
                 right_max = lds_prefix_max8(L.D_col);
                 down_max = lds_prefix_max8(L.D_row);
                 save_ckpt_borders(block_size);
-                if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
+                if (TRACE) { park<3>(parked, (int)trace_top); park<4>(parked, (int)nblocks); }
             }
 
             const int this_dir = dir;
@@ -674,22 +675,24 @@ struct Aligner {
 
             if (off_max > best_max) {
                 if (FQE) {     // scan_block.rs:354-368
-                    best_i = qlen;
-                    if (this_dir == DIR_RIGHT) best_j = sj + (block_size - STEP) + (uint32_t)fq.j;
-                    else if (this_dir == DIR_GROW) best_j = sj + prev_size + (uint32_t)fq.j;
+                    park<5>(parked, (int)qlen);
+                    if (this_dir == DIR_RIGHT) park<6>(parked, (int)(sj + (block_size - STEP) + (uint32_t)fq.j));
+                    else if (this_dir == DIR_GROW) park<6>(parked, (int)(sj + prev_size + (uint32_t)fq.j));
                     else status |= ST_MODE;   // the reference panics: min block size > query length rules out down steps
                 }
                 if (XDROP) {   // scan_block.rs:370-404
-                    if (this_dir == DIR_RIGHT) { best_i = si + cur.row; best_j = sj + (block_size - STEP) + cur.col; }
-                    else if (this_dir == DIR_DOWN) { best_i = si + (block_size - STEP) + cur.col; best_j = sj + cur.row; }
-                    else if (D_max_max >= grow_max) { best_i = si + cur.row; best_j = sj + prev_size + cur.col; }
-                    else { best_i = si + prev_size + grow.col; best_j = sj + grow.row; }
+                    uint32_t bi_, bj_;
+                    if (this_dir == DIR_RIGHT) { bi_ = si + cur.row; bj_ = sj + (block_size - STEP) + cur.col; }
+                    else if (this_dir == DIR_DOWN) { bi_ = si + (block_size - STEP) + cur.col; bj_ = sj + cur.row; }
+                    else if (D_max_max >= grow_max) { bi_ = si + cur.row; bj_ = sj + prev_size + cur.col; }
+                    else { bi_ = si + prev_size + grow.col; bj_ = sj + grow.row; }
+                    park<5>(parked, (int)bi_); park<6>(parked, (int)bj_);
                 }
                 if (block_size < max_size) {
-                    i_ckpt = si; j_ckpt = sj; off_ckpt = off;
+                    park<0>(parked, (int)si); park<1>(parked, (int)sj); park<2>(parked, off);
                     if (fast) save_ckpt_regs(this_dir == DIR_RIGHT);
                     else save_ckpt_borders(block_size);
-                    if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
+                    if (TRACE) { park<3>(parked, (int)trace_top); park<4>(parked, (int)nblocks); }
                     grow_no_max = false;
                 }
                 best_max = off_max;
@@ -710,9 +713,9 @@ struct Aligner {
             const uint32_t next_size = block_size * 2;
             if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
                 prev_size = block_size; block_size = next_size; dir = DIR_GROW;
-                si = i_ckpt; sj = j_ckpt; off = off_ckpt;
+                si = (uint32_t)unpark<0>(parked); sj = (uint32_t)unpark<1>(parked); off = unpark<2>(parked);
                 restore_ckpt_borders(prev_size);
-                if (TRACE) { trace_top = ck_trace_top; nblocks = ck_nblocks; }
+                if (TRACE) { trace_top = (uint32_t)unpark<3>(parked); nblocks = (uint32_t)unpark<4>(parked); }
                 y_drop_iter = 0;
                 continue;
             }
@@ -725,11 +728,11 @@ struct Aligner {
                     lds_copy(L.D_col, L.D_col + block_size, block_size); lds_copy(L.C_col, L.C_col + block_size, block_size);
                     lds_copy(L.D_row, L.D_row + block_size, block_size); lds_copy(L.R_row, L.R_row + block_size, block_size);
                     si += block_size; sj += block_size;
-                    i_ckpt = si; j_ckpt = sj; off_ckpt = off;
+                    park<0>(parked, (int)si); park<1>(parked, (int)sj); park<2>(parked, off);
                     save_ckpt_borders(block_size);
                     right_max = lds_prefix_max8(L.D_col);
                     down_max = lds_prefix_max8(L.D_row);
-                    if (TRACE) { ck_trace_top = trace_top; ck_nblocks = nblocks; }
+                    if (TRACE) { park<3>(parked, (int)trace_top); park<4>(parked, (int)nblocks); }
                     y_drop_iter = 0;
                 }
             }
@@ -744,7 +747,7 @@ struct Aligner {
         if (coldp()->prof && is_lane(0)) for (int k = 0; k < 20; k++) if (k != 17) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
         int score; uint32_t ri, rj;
-        if (XDROP || FQE) { score = best_max; ri = best_i; rj = best_j; }
+        if (XDROP || FQE) { score = best_max; ri = (uint32_t)unpark<5>(parked); rj = (uint32_t)unpark<6>(parked); }
         else {
             lds_sync();
             if (dir == DIR_DOWN) score = off + uni((int)L.D_row[rlen - sj]) - ZERO;
