@@ -399,7 +399,7 @@ struct Aligner {
     uint32_t qlen, rlen;
     uint32_t* trace; BlockRec* blocks; short* ckpt;   // this wave's slot in the global scratch arenas
     uint32_t trace_top = 0, nblocks = 0;
-    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j (see park())
+    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot (see park())
     uint32_t status = 0;
     unsigned long long cells = 0;
     // sequence bytes for the next shift step, fetched one step ahead for both possible directions
@@ -513,9 +513,9 @@ struct Aligner {
         }
     }
 
-    __device__ void run(uint32_t pair, uint32_t slot, bool batch_traceback) {
-        q = coldp()->pool + coldp()->q_off[pair]; r = coldp()->pool + coldp()->r_off[pair];
-        qlen = coldp()->q_len[pair]; rlen = coldp()->r_len[pair];
+    __device__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback) {
+        q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
+        qlen = coldp()->q_len[pair_in]; rlen = coldp()->r_len[pair_in];
         const uint32_t min_size = coldp()->min_size, max_size = h_max_size;
         ProfileView pv{};
         if constexpr (KIND == KIND_PROFILE) {   // r points at the pair's AAProfile image (ba_params.h)
@@ -536,6 +536,7 @@ struct Aligner {
         uint32_t si = 0, sj = 0;
         int best_max = 0;
         parked = 0;
+        park<7>(parked, (int)pair_in); park<8>(parked, (int)slot_in);   // not needed again before the pair is done
         int prev_dir = DIR_GROW, dir = DIR_GROW;
         uint32_t prev_size = 0, block_size = min_size;
         int off = 0, prev_off = 0, off_max = 0;
@@ -746,6 +747,7 @@ struct Aligner {
         prof[16] += steps;
         if (coldp()->prof && is_lane(0)) for (int k = 0; k < 20; k++) if (k != 17) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
+        const uint32_t pair = (uint32_t)unpark<7>(parked), slot = (uint32_t)unpark<8>(parked);
         int score; uint32_t ri, rj;
         if (XDROP || FQE) { score = best_max; ri = (uint32_t)unpark<5>(parked); rj = (uint32_t)unpark<6>(parked); }
         else {
