@@ -810,8 +810,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         }
     }
     __syncthreads();
-    const uint32_t ab = lds_array_bytes_h(bp.max_size);
-    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(bp.max_size);
+    // The LDS layout depends only on the kernel's block class (PMAX * 128 cells), not on the batch's max size: the
+    // four border arrays then sit at compile-time offsets from one per-wave base, i.e. in the immediate offset field of
+    // the DS instructions instead of in five SGPRs (which the step loop does not have: they were spilled and reloaded).
+    constexpr uint32_t ab = lds_array_bytes_h(PMAX * 128);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(PMAX * 128);
     WaveLds L;
     L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
     L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
@@ -841,7 +844,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
     const bool batch_traceback = TRACE && stride > 0;
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
-                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(bp.max_size));
+                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(PMAX * 128));
         return;
     }
     // dense index among the fill waves (consumer waves of this and earlier workgroups skipped)

@@ -325,7 +325,8 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return nullptr; }
-    b->lds = ba::lds_wg_bytes_h(kind, (uint32_t)max_size) + (trace ? ba::TB_LDS_BYTES : 0u);   // + the traceback wave's windows
+    // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
+    b->lds = ba::lds_wg_bytes_h(kind, 128u << pc) + (trace ? ba::TB_LDS_BYTES : 0u);
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return nullptr; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip

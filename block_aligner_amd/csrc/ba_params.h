@@ -74,10 +74,10 @@ struct BatchParams {
 constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
-BA_HD inline uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
-BA_HD inline uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_array_bytes_h(max_size) + 128; }
-BA_HD inline uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }
-BA_HD inline uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
+BA_HD constexpr uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
+BA_HD constexpr uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_array_bytes_h(max_size) + 128; }
+BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }
+BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
 // TRACE batches: one more region behind the waves' for the workgroup's traceback wave (ba_driver.hpp tb_step): per lane
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
 constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_OFFSET = 64 * TB_LANE_BYTES, TB_LDS_BYTES = 5120;
