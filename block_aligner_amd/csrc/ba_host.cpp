@@ -503,7 +503,7 @@ int ba_batch_prof(BaBatch* b, uint64_t out[32]) {   // development: phase timers
 }
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {
     if (!b) return fail("null batch");
-    out[0] = b->slots; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
+    out[0] = (uint64_t)b->grid * ba::WAVES_PER_WG; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
     return 0;
 }
 void ba_batch_destroy(BaBatch* b) { delete b; }
