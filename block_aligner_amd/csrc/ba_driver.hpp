@@ -407,7 +407,7 @@ struct Aligner {
     bool pf_ok = false;   // the prefetched bytes serve the next step if it is a shift by 8 from where they were fetched
     FastIO fs;
 #ifdef BA_TIMING
-    unsigned long long prof[32] = {};
+    unsigned long long prof[48] = {};
 #else
     unsigned long long* prof = nullptr;
 #endif
@@ -586,6 +586,7 @@ struct Aligner {
                 Dc = L.D_col; Cc = L.C_col; Dr = L.D_row + prev_size; Rr = L.R_row + prev_size; right = true;
             }
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
+            BA_TSTAMP(tsa);
             const bool fast = KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special;
             const bool pf_hit = pf_ok;   // only a fast step that ends in a plain shift leaves usable prefetched bytes behind
             pf_ok = false;
@@ -611,6 +612,7 @@ struct Aligner {
                 // must be issued only after the wait for the previous one
                 asm volatile("" : "+v"(fs.vec_a), "+v"(fs.vec_b), "+v"(fs.col_chars));
             }
+            BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
             if (TRACE) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
                 if (right) add_block(ri, rj, rw, rh, true);
@@ -620,6 +622,7 @@ struct Aligner {
             uint32_t* tout = TRACE ? trace + tb : nullptr;
             const int rz = clamp16(-off + ZERO);
             BA_TSTAMP(ts1);
+            BA_TADD(prof, 32, ts0, tsa); BA_TADD(prof, 33, tsa, tsb); BA_TADD(prof, 34, tsb, ts1);
             Best cur{0, 0, 0};
             const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
 #define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
@@ -665,6 +668,7 @@ struct Aligner {
                 if (TRACE) { park<3>(parked, (int)trace_top); park<4>(parked, (int)nblocks); }
             }
 
+            BA_TSTAMP(tpa);
             const int this_dir = dir;
             prev_dir = dir;
             // FREE_QUERY_END_GAPS: only the vector lane that holds the last query row counts (scan_block.rs:333-339)
@@ -699,6 +703,7 @@ struct Aligner {
                 best_max = off_max;
                 y_drop_iter = 0;
             }
+            BA_TSTAMP(tpb);
             if (XDROP) {
                 if (off_max < best_max - h_x_drop) {
                     if (x_drop_iter < 1) x_drop_iter++;   // X_DROP_ITER = 2
@@ -707,6 +712,7 @@ struct Aligner {
             }
             BA_TSTAMP(ts3);
             BA_TADD(prof, 14, ts2, ts3);
+            BA_TADD(prof, 35, ts2, tpa); BA_TADD(prof, 36, tpa, tpb); BA_TADD(prof, 37, tpb, ts3);
             if (si + block_size > qlen && sj + block_size > rlen) break;
             if (sj + block_size > rlen) { si += STEP; dir = DIR_DOWN; continue; }
             if (si + block_size > qlen) { sj += STEP; dir = DIR_RIGHT; continue; }
@@ -745,7 +751,7 @@ struct Aligner {
         BA_TADD(prof, 15, tr0, tr1);
 #ifdef BA_TIMING
         prof[16] += steps;
-        if (coldp()->prof && is_lane(0)) for (int k = 0; k < 20; k++) if (k != 17) atomicAdd(coldp()->prof + k, prof[k]);
+        if (coldp()->prof && is_lane(0)) for (int k = 0; k < 48; k++) if (k != 17 && !(k >= 20 && k < 32)) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
         const uint32_t pair = (uint32_t)unpark<7>(parked), slot = (uint32_t)unpark<8>(parked);
         int score; uint32_t ri, rj;

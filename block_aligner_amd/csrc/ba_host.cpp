@@ -386,7 +386,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * max_size * sizeof(short));
-    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 256); BA_ALLOC(params_dev, sizeof(BatchParams)); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
+    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams)); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
 #undef BA_ALLOC
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -406,7 +406,7 @@ static int batch_run(BaBatch* b, float* kernel_ms) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
     HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
-    HIP_TRY(hipMemsetAsync(b->prof.p, 0, 256, b->stream));
+    HIP_TRY(hipMemsetAsync(b->prof.p, 0, 512, b->stream));
     HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
     HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
     const BatchParams bp = b->params();
@@ -496,9 +496,9 @@ int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
     HIP_TRY(hipMemcpy(runs, d_out.p, total * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-int ba_batch_prof(BaBatch* b, uint64_t out[32]) {   // development: phase timers of a -DBA_TIMING build
+int ba_batch_prof(BaBatch* b, uint64_t out[64]) {   // development: phase timers of a -DBA_TIMING build
     if (!b) return fail("null batch");
-    HIP_TRY(hipMemcpy(out, b->prof.p, 256, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, b->prof.p, 512, hipMemcpyDeviceToHost));
     return 0;
 }
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {

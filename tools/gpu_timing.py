@@ -12,11 +12,11 @@ pairs = synth.make_pairs(n, 10000, 1000, 500, synth.DNA, seed=1234)
 mode = H.X_DROP | ((H.TRACE | H.CIGAR_EQ) if trace else 0)
 b = H.BatchAligner(S.NucMatrix.new_simple(2, -3), (-5, -1), (128, maxb), 100, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
 b.run(); ms = b.run()
-prof = np.zeros(32, np.uint64)
+prof = np.zeros(64, np.uint64)
 H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
 H.lib().ba_batch_prof(b._h, prof.ctypes.data)
 names = {0: "fast prologue", 1: "fast columns", 2: "fast epilogue", 4: "generic<=128 prologue", 5: "generic<=128 columns", 6: "generic<=128 epilogue",
-         8: "tall prologue", 9: "tall columns", 10: "tall epilogue", 12: "driver: rect setup", 13: "driver: place (all)", 14: "driver: post-step", 15: "pair total", 17: "waiting for a free trace slot", 18: "fast step: wait for outstanding memory ops"}
+         8: "tall prologue", 9: "tall columns", 10: "tall epilogue", 12: "driver: rect setup", 13: "driver: place (all)", 14: "driver: post-step", 15: "pair total", 17: "waiting for a free trace slot", 18: "fast step: wait for outstanding memory ops", 32: "setup: direction / pointers", 33: "setup: prefetch consumption", 34: "setup: add_block, rz", 35: "post: border maxima (+ generic border moves)", 36: "post: offset, best cell, checkpoint", 37: "post: x-drop test"}
 tot = float(prof[15]); steps = float(prof[16])
 print(f"pairs={n} trace={trace} kernel_ms={ms:.2f} steps/pair={steps/n:.0f} cycles/pair={tot/n:.0f} (s_memtime ticks)")
 print(f"  prefetch hits per step: {float(prof[19])/max(steps,1):.3f}")
