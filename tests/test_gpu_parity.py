@@ -221,3 +221,12 @@ def test_trace_blocks(hip, oracle):
     assert a.res().score == ref["score"]
     assert sum(w * h for _, _, w, h in blocks) == ref["surviving_cells"]
     assert blocks[0][:2] == (0, 0) and all(w % 8 == 0 and h % 8 == 0 for _, _, w, h in blocks)
+
+
+def test_long_pairs(hip, oracle):
+    """150 kbp pairs (tens of thousands of driver steps each, trace stacks of tens of MB): 32-bit trace offsets, the
+    rectangle list and the CIGAR capacity at scale; a few pairs so both the inline and the in-launch traceback run."""
+    pairs = synth.make_pairs(3, 150000, 12000, 2000, synth.DNA, seed=4242, indels=4, indel_len=(50, 400))
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 1024), 100, ("trace", "x_drop"))      # (X-drop may stop at a long indel)
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), (32, 2048), 0, ("trace",))             # global: always to the end
+    assert (res["query_idx"] == pairs.q_len).all() and (res["cigar_len"] > 10000).all()
