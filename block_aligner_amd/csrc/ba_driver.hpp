@@ -4,14 +4,6 @@
 #pragma once
 #include "ba_device.hpp"
 
-// development aid: -DBA_DEBUG makes the kernels drop progress markers into host-mapped memory
-#ifdef BA_DEBUG
-extern __device__ volatile uint32_t* g_ba_dbg;
-#define __threadfence_system(); } } while (0)
-#else
-#define BA_DBG(slot, val) do { } while (0)
-#endif
-
 namespace ba {
 
 // ------------------------------------------------------------------ LDS border helpers (whole wave cooperates)
