@@ -46,6 +46,25 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota if there is one (a pod
+    that sees 256 logical CPUs but is throttled to a few would otherwise report a meaningless core count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())            # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -63,7 +82,7 @@ def main():
 
     # ---- synthetic workload (forked workers: must happen before any GPU initialisation)
     t0 = time.time()
-    workers = a.gen_workers or min(32, max(1, (os.cpu_count() or 8) // max(1, world)))
+    workers = a.gen_workers or min(32, max(1, usable_cpus() // max(1, world)))
     pairs = synth.make_pairs(a.pairs, a.len, a.edits, a.tail, synth.DNA, seed=shard_seed(1234, rank), workers=workers)
     t_gen = time.time() - t0
 
@@ -142,8 +161,8 @@ def main():
             build()
             o = Oracle("avx2")
             modes = ("trace", "x_drop") if trace else ("x_drop",)
-            cores = os.cpu_count() or 1
-            n_s = a.cpu_baseline_pairs or min(a.pairs, max(64, 3000 * cores))   # ~3 ms per pair per core -> <= ~10 s on all cores
+            cores = usable_cpus()
+            n_s = a.cpu_baseline_pairs or min(a.pairs, max(64, 8000 * cores))   # ~1 ms per pair per core -> <= ~10 s on all usable cores
             sub = pairs.subset(np.arange(n_s))
             ref = o.batch_align(matrix, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, gaps, size, x_drop, modes,
                                 cigar_eq=True, threads=cores)
