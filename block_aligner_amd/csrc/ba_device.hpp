@@ -12,6 +12,7 @@
 //   border moves  /root/reference/src/scan_block.rs:1003-1061
 // The trace encoding, LDS layout and work distribution are this implementation's own.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ba_params.h"
@@ -291,8 +292,39 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     const uint32_t zwords = (width >> 2) * (uint32_t)(NCH * nl);   // SP_LOCAL: the zero mask follows the rectangle's trace words
     int corner_cur = corner;
     int cvec = FAST ? fs->col_chars : (PDIR == 1 ? 0 : (int)seqC[start_j + (lane & 7)]);   // 8 column bytes at a time, one per lane (lanes 0..7)
+    // Profiles, blocks up to 256 cells: the scores (and per-position gap costs) of a whole group of 8 columns are fetched
+    // from the pair's image at once -- one round of HBM latency per 8 columns instead of one per column. Vectors along
+    // the query: the transposed table aa_pos holds the 8 positions of a residue contiguously (two 16-byte loads per lane
+    // and chunk); vectors along the profile: one 4-byte load per column and chunk.
+    constexpr bool PGROUP = PDIR != 0 && NCH <= 2;
+    uint4 ga[PGROUP && PDIR == 1 ? NCH : 1], gb[PGROUP && PDIR == 1 ? NCH : 1];
+    int gs[PGROUP && PDIR == 2 ? STEP : 1][PGROUP && PDIR == 2 ? NCH : 1];
+    int gg_goC = 0, gg_clC = 0, gg_goR = 0;      // PDIR == 1: lane k holds the gap costs of the group's k-th column
+    auto refill_group = [&](uint32_t j0) {
+        if constexpr (PGROUP && PDIR == 1) {
+            const uint32_t idx = start_j + j0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                ga[ch] = uint4{0, 0, 0, 0}; gb[ch] = uint4{0, 0, 0, 0};
+                if (active) {
+                    __builtin_memcpy(&ga[ch], pv->aa_pos + (uint64_t)key[ch].a * pv->P + idx, 16);
+                    __builtin_memcpy(&gb[ch], pv->aa_pos + (uint64_t)key[ch].b * pv->P + idx, 16);
+                }
+            }
+            gg_goC = (int)pv->goC[idx + (lane & 7)]; gg_clC = (int)pv->clC[idx + (lane & 7)]; gg_goR = (int)pv->goR[idx + (lane & 7)];
+        } else if constexpr (PGROUP && PDIR == 2) {
+            cvec = (int)seqC[start_j + j0 + (lane & 7)];
+#pragma unroll
+            for (int k = 0; k < STEP; k++) {
+                const int cbyte = __builtin_amdgcn_readlane(cvec, k);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++)
+                    gs[k][ch] = active ? load_pair_i16(pv->aa_pos + (uint64_t)(cbyte & 31) * pv->P + start_i + ch * 128 + 2 * lane) : 0;
+            }
+        }
+    };
     int sc_next[NCH];
-    {
+    if constexpr (!PGROUP) {
         const int cb0 = __builtin_amdgcn_readlane(cvec, 0);
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sc_next[ch] = PDIR ? profile_score(start_j, cb0, ch) : fetch_score<KIND>(L.table, key[ch], cb0);
@@ -300,14 +332,32 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     }
     BA_TSTAMP(tp1);
     const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
-    auto column = [&](const uint32_t j) -> bool {   // returns false when the fill stops early (scan_block.rs:1216-1224)
+    // kc: an integral_constant; >= 0 in the grouped profile mode = the column's index inside its group of 8
+    auto column = [&](const uint32_t j, auto kc) -> bool {   // returns false when the fill stops early (scan_block.rs:1216-1224)
+        constexpr int K = decltype(kc)::value;
         int sc[NCH];
+        if constexpr (K >= 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                if constexpr (PDIR == 1) {
+                    const uint32_t wa = K < 2 ? ga[ch].x : (K < 4 ? ga[ch].y : (K < 6 ? ga[ch].z : ga[ch].w));
+                    const uint32_t wb = K < 2 ? gb[ch].x : (K < 4 ? gb[ch].y : (K < 6 ? gb[ch].z : gb[ch].w));
+                    sc[ch] = pk((int)(wa >> ((K & 1) * 16)), (int)(wb >> ((K & 1) * 16)));
+                } else sc[ch] = gs[K][ch];
+            }
+            if constexpr (PDIR == 1) {
+                col_goC = splat(clamp16(__builtin_amdgcn_readlane(gg_goC, K) + fc.gap_extend));
+                col_clC = splat(__builtin_amdgcn_readlane(gg_clC, K));
+                col_goR = splat(__builtin_amdgcn_readlane(gg_goR, K));
+            }
+        } else {
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) sc[ch] = sc_next[ch];
+        }
         // scores of the next column are fetched while this one is computed
-        if (!FAST && PDIR != 1 && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
-        if constexpr (PDIR == 1) { col_goC = nxt_goC; col_clC = nxt_clC; col_goR = nxt_goR; }
-        if (!(FAST && j == 7)) {   // (last column of a shift step: nothing left to fetch)
+        if (K < 0 && !FAST && PDIR != 1 && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
+        if constexpr (K < 0 && PDIR == 1) { col_goC = nxt_goC; col_clC = nxt_clC; col_goR = nxt_goR; }
+        if (K < 0 && !(FAST && j == 7)) {   // (last column of a shift step: nothing left to fetch)
             const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) sc_next[ch] = PDIR ? profile_score(start_j + j + 1, cbn, ch) : fetch_score<KIND>(L.table, key[ch], cbn);
@@ -408,13 +458,22 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         }
         return true;
     };
+    using NoGroup = std::integral_constant<int, -1>;
     if constexpr (FAST) {
         // a shift step is exactly 8 columns: fully unrolled, so column indices, trace shifts and border offsets are
         // immediates and only column 0 carries the corner / first-cell handling
 #pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)STEP; j++) { if (!column(j)) break; }
+        for (uint32_t j = 0; j < (uint32_t)STEP; j++) { if (!column(j, NoGroup{})) break; }
+    } else if constexpr (PGROUP) {
+        bool go = true;
+        for (uint32_t j0 = 0; go && j0 < width; j0 += STEP) {   // (rectangle widths are multiples of 8)
+            refill_group(j0);
+#define BA_GCOL(K) if (go) go = column(j0 + K, std::integral_constant<int, K>{})
+            BA_GCOL(0); BA_GCOL(1); BA_GCOL(2); BA_GCOL(3); BA_GCOL(4); BA_GCOL(5); BA_GCOL(6); BA_GCOL(7);
+#undef BA_GCOL
+        }
     } else {
-        for (uint32_t j = 0; j < width; j++) { if (!column(j)) break; }
+        for (uint32_t j = 0; j < width; j++) { if (!column(j, NoGroup{})) break; }
     }
     BA_TSTAMP(tp2);
     if (!FAST && fq) { fq->M = fqM; fq->j = fqJ; }
