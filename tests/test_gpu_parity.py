@@ -230,3 +230,39 @@ def test_long_pairs(hip, oracle):
     compare(hip, oracle, pairs, NUC, (-5, -1), (128, 1024), 100, ("trace", "x_drop"))      # (X-drop may stop at a long indel)
     res = compare(hip, oracle, pairs, NUC, (-5, -1), (32, 2048), 0, ("trace",))             # global: always to the end
     assert (res["query_idx"] == pairs.q_len).all() and (res["cigar_len"] > 10000).all()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations(hip, oracle, seed):
+    """Seeded sweep over the whole parameter space of the path at once: matrix kind, gap costs, block range, X-drop
+    threshold, mode combination and sequence shapes are all drawn at random; every draw must match the oracle exactly."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["nuc", "aa", "bytes"][int(rng.integers(0, 3))]
+    ext = -int(rng.integers(1, 6)); opn = ext - int(rng.integers(1, 16))
+    lo = 16 << int(rng.integers(0, 4)); hi = lo << int(rng.integers(0, 4))            # 16..128 up to x8
+    x_drop = int(rng.integers(0, 120))
+    modes = [(), ("x_drop",), ("trace",), ("trace", "x_drop"), ("trace", "local_start"), ("local_start", "x_drop"),
+             ("trace", "free_query_start_gaps"), ("trace", "free_query_end_gaps"), ("free_query_end_gaps", "local_start")]
+    mode = modes[int(rng.integers(0, len(modes)))]
+    if kind == "nuc":
+        matrix, alpha = S.NucMatrix.new_simple(int(rng.integers(1, 6)), -int(rng.integers(1, 8))), synth.DNA
+    elif kind == "aa":
+        matrix, alpha = [S.BLOSUM62, S.static_matrix("PAM120"), S.static_matrix("BLOSUM90")][int(rng.integers(0, 3))], synth.AMINO
+    else:
+        matrix, alpha = S.ByteMatrix.new_simple(int(rng.integers(1, 5)), -int(rng.integers(1, 5))), np.frombuffer(b"abcdxyz\x00\xfe", np.uint8)
+    fqe = "free_query_end_gaps" in mode
+    lists = []
+    for _ in range(40):
+        rl = int(rng.integers(0, 700))
+        r = synth.rand_str(rng, rl, alpha)
+        if fqe:   # min block size must exceed the query length (scan_block.rs:860-862)
+            ql = int(rng.integers(0, lo))
+            st = int(rng.integers(0, max(1, rl - ql + 1)))
+            q = synth.mutate(rng, r[st: st + ql], int(rng.integers(0, 4)), alpha)[: lo - 1]
+        else:
+            q = synth.mutate(rng, r, int(rng.integers(0, max(1, rl // 6 + 1))), alpha)
+            if rng.random() < 0.3:
+                q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 40)), alpha), q])
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    pairs = synth.PairSet.from_lists(lists)
+    compare(hip, oracle, pairs, matrix, (opn, ext), (lo, hi), x_drop, mode, cigar_eq=bool(rng.integers(0, 2)))
