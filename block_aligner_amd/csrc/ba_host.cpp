@@ -13,6 +13,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <thread>
 
 #include "../../include/block_aligner_hip.h"
 #include "aa_matrices.inc"
@@ -168,6 +170,7 @@ struct BaBatch {
     int gap_open = 0, gap_extend = 0, x_drop = 0;
     uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
+    uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace, blocks, ckpt, counter,
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1;
@@ -246,12 +249,101 @@ static void profile_image(const AAProfile* pr, uint32_t P, uint8_t* dst) {
 }
 struct NoProfiles { const AAProfile* operator()(size_t) const { return nullptr; } };
 
+struct Packed {   // host-side packing of a set of pairs: padded images + the per-pair arrays the kernels read
+    std::vector<uint64_t> qo, ro, cig_off;
+    std::vector<uint32_t> ql, rl;
+    std::vector<uint8_t> image;
+    uint64_t total = 0, maxlen2 = 0, cig_total = 0;
+};
+template <class GetSeq, class GetProfile, class Lap>
+static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uint32_t mode, size_t n, bool already_converted,
+                      GetSeq get, GetProfile getp, Packed& P, Lap lap) {
+    const bool profile = kind == BA_KIND_PROFILE_;
+    // ---- PaddedBytes images: [NULL] + bytes + NULL x (max_size + 16)
+    const size_t pad = max_size + 16;
+    std::vector<uint64_t>& qo = P.qo; std::vector<uint64_t>& ro = P.ro;
+    qo.resize(n); ro.resize(n);
+    std::vector<uint32_t>& ql = P.ql; std::vector<uint32_t>& rl = P.rl;
+    ql.resize(n); rl.resize(n);
+    uint64_t total = 0, maxlen2 = 0, cig_total = 0;
+    std::vector<uint64_t>& cig_off = P.cig_off;
+    cig_off.resize(n + 1);
+    for (size_t p = 0; p < n; p++) {
+        const uint8_t* ptr; size_t len;
+        get(p, 0, &ptr, &len);
+        if (len > 0x3fffffffu) { fail("sequence too long"); return 1; }
+        ql[p] = (uint32_t)len; qo[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;   // images start 4-byte aligned
+        if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > len)) {   // scan_block.rs:860-862
+            fail("pair %zu: Min block size must be larger than the query length for FREE_QUERY_END_GAPS!", p); return 1;
+        }
+        if (profile) {
+            const AAProfile* pr = getp(p);
+            if (!pr) { fail("pair %zu: null profile", p); return 1; }
+            if (pr->gap_extend != gaps.extend) { fail("pair %zu: profile gap_extend %d differs from the batch's %d", p, pr->gap_extend, gaps.extend); return 1; }
+            len = pr->str_len;
+            if (len > 0x3fffffffu) { fail("profile too long"); return 1; }
+            rl[p] = (uint32_t)len; ro[p] = total; total += ba::profile_image_bytes((uint32_t)len, (uint32_t)max_size);
+        } else {
+            get(p, 1, &ptr, &len);
+            if (len > 0x3fffffffu) { fail("sequence too long"); return 1; }
+            rl[p] = (uint32_t)len; ro[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;
+        }
+        maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
+        cig_off[p] = cig_total;
+        cig_total += (uint64_t)ql[p] + rl[p] + 1;
+    }
+    cig_off[n] = cig_total;
+    total += 64;
+    lap("offsets");
+    std::vector<uint8_t>& image = P.image;
+    image.assign(total, null_byte(kind));
+    lap("image allocation + padding");
+    {   // convert / copy the sequences into their padded images: independent per pair, spread over host threads
+        unsigned nthreads = std::thread::hardware_concurrency();
+        if (nthreads > 16) nthreads = 16;
+        if (nthreads < 1 || n < 4096) nthreads = 1;
+        std::vector<size_t> bad(nthreads, (size_t)-1);
+        std::vector<uint8_t> bad_byte(nthreads, 0);
+        auto work = [&](unsigned t) {
+            for (size_t p = (size_t)n * t / nthreads; p < (size_t)n * (t + 1) / nthreads; p++) {
+                if (profile) profile_image(getp(p), ba::profile_positions(rl[p], (uint32_t)max_size), image.data() + ro[p]);
+                for (int w = 0; w < (profile ? 1 : 2); w++) {
+                    const uint8_t* ptr; size_t len;
+                    get(p, w, &ptr, &len);
+                    uint8_t* dst = image.data() + (w ? ro[p] : qo[p]) + 1;
+                    if (already_converted) memcpy(dst, ptr, len);
+                    else for (size_t k = 0; k < len; k++) {
+                        if (!convert_char(kind, ptr[k], dst + k)) { if (bad[t] == (size_t)-1) { bad[t] = p; bad_byte[t] = ptr[k]; } break; }
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthreads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (unsigned t = 0; t < nthreads; t++)
+            if (bad[t] != (size_t)-1) { fail("pair %zu: byte 0x%02x is outside the matrix alphabet", bad[t], bad_byte[t]); return 1; }
+    }
+    lap("image fill");
+    P.total = total; P.maxlen2 = maxlen2; P.cig_total = cig_total;
+    return 0;
+}
+
 // `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1); for kind PROFILE the reference comes from
 // `getp(p)` instead.
 template <class GetSeq, class GetProfile = NoProfiles>
 static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, size_t n,
                             bool already_converted, GetSeq get, GetProfile getp = GetProfile()) {
     if (ensure_device()) return nullptr;
+    const bool verbose = getenv("BA_SETUP_TIMING") != nullptr;   // development: where the batch set-up time goes
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "block_aligner_hip setup: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (kind < 0 || kind > 3) { fail("unknown matrix kind %d", kind); return nullptr; }
     const bool profile = kind == BA_KIND_PROFILE_;
     const size_t min_size = size.min < 16 ? 16 : size.min, max_size = size.max < 16 ? 16 : size.max;   // clamp to L (scan_block.rs:853-854)
@@ -269,52 +361,13 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
     b->gap_open = gaps.open; b->gap_extend = gaps.extend; b->x_drop = x_drop;
 
-    // ---- PaddedBytes images: [NULL] + bytes + NULL x (max_size + 16)
-    const size_t pad = max_size + 16;
-    std::vector<uint64_t>& qo = b->h_q_off; std::vector<uint64_t>& ro = b->h_r_off;
-    qo.resize(n); ro.resize(n);
-    std::vector<uint32_t> ql(n), rl(n);
-    uint64_t total = 0, maxlen2 = 0, cig_total = 0;
-    std::vector<uint64_t> cig_off(n + 1);
-    for (size_t p = 0; p < n; p++) {
-        const uint8_t* ptr; size_t len;
-        get(p, 0, &ptr, &len);
-        if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
-        ql[p] = (uint32_t)len; qo[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;   // images start 4-byte aligned
-        if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > len)) {   // scan_block.rs:860-862
-            fail("pair %zu: Min block size must be larger than the query length for FREE_QUERY_END_GAPS!", p); return nullptr;
-        }
-        if (profile) {
-            const AAProfile* pr = getp(p);
-            if (!pr) { fail("pair %zu: null profile", p); return nullptr; }
-            if (pr->gap_extend != gaps.extend) { fail("pair %zu: profile gap_extend %d differs from the batch's %d", p, pr->gap_extend, gaps.extend); return nullptr; }
-            len = pr->str_len;
-            if (len > 0x3fffffffu) { fail("profile too long"); return nullptr; }
-            rl[p] = (uint32_t)len; ro[p] = total; total += ba::profile_image_bytes((uint32_t)len, (uint32_t)max_size);
-        } else {
-            get(p, 1, &ptr, &len);
-            if (len > 0x3fffffffu) { fail("sequence too long"); return nullptr; }
-            rl[p] = (uint32_t)len; ro[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;
-        }
-        maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
-        cig_off[p] = cig_total;
-        cig_total += (uint64_t)ql[p] + rl[p] + 1;
-    }
-    cig_off[n] = cig_total;
-    total += 64;
-    std::vector<uint8_t> image(total, null_byte(kind));
-    for (size_t p = 0; p < n; p++) {
-        if (profile) profile_image(getp(p), ba::profile_positions(rl[p], (uint32_t)max_size), image.data() + ro[p]);
-        for (int w = 0; w < (profile ? 1 : 2); w++) {
-            const uint8_t* ptr; size_t len;
-            get(p, w, &ptr, &len);
-            uint8_t* dst = image.data() + (w ? ro[p] : qo[p]) + 1;
-            if (already_converted) memcpy(dst, ptr, len);
-            else for (size_t k = 0; k < len; k++) {
-                if (!convert_char(kind, ptr[k], dst + k)) { fail("pair %zu: byte 0x%02x is outside the matrix alphabet", p, ptr[k]); return nullptr; }
-            }
-        }
-    }
+    Packed P;
+    if (pack_pairs(kind, gaps, min_size, max_size, mode, n, already_converted, get, getp, P, lap)) return nullptr;
+    std::vector<uint64_t>& qo = P.qo; std::vector<uint64_t>& ro = P.ro; std::vector<uint32_t>& ql = P.ql; std::vector<uint32_t>& rl = P.rl;
+    std::vector<uint64_t>& cig_off = P.cig_off; std::vector<uint8_t>& image = P.image;
+    const uint64_t total = P.total, maxlen2 = P.maxlen2, cig_total = P.cig_total;
+    b->h_q_off = qo; b->h_r_off = ro;
+    b->cap_n = n; b->cap_pool = total; b->cap_cig = cig_total; b->cap_maxlen2 = maxlen2;
     b->pool_bytes = total;
 
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate failed"); return nullptr; }
@@ -376,6 +429,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     }
     b->cig_total = trace ? cig_total : 0;
 
+    lap("launch geometry");
 #define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return nullptr
     BA_ALLOC(pool, total); BA_ALLOC(q_off, n * 8); BA_ALLOC(q_len, n * 4); BA_ALLOC(r_off, n * 8); BA_ALLOC(r_len, n * 4);
     BA_ALLOC(matrix, 1024);
@@ -388,6 +442,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * max_size * sizeof(short));
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams)); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
 #undef BA_ALLOC
+    lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
     BA_H2D(r_off, ro.data(), n * 8); BA_H2D(r_len, rl.data(), n * 4); BA_H2D(cig_off, cig_off.data(), (n + 1) * 8);
@@ -398,8 +453,36 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         BA_H2D(matrix, tmp, 1024);
     }
 #undef BA_H2D
+    lap("host-to-device copies");
     if (hipMemset(b->cig_len.p, 0, n * 4) != hipSuccess || hipMemset(b->status.p, 0, n * 4) != hipSuccess) { fail("hipMemset failed"); return nullptr; }
     return b.release();
+}
+
+
+// Replace the pairs of an existing batch (same matrix, gaps, block range and modes); the device buffers -- above all the
+// trace arena, whose allocation dominates the set-up time -- are reused, so the new set must fit what they were sized for.
+template <class GetSeq, class GetProfile = NoProfiles>
+static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get, GetProfile getp = GetProfile()) {
+    if (!b) return fail("null batch");
+    if (n == 0 || n > b->cap_n) return fail("reload: %zu pairs exceed the batch's capacity of %llu", n, (unsigned long long)b->cap_n);
+    HIP_TRY(hipSetDevice(b->device));
+    Packed P;
+    if (pack_pairs(b->kind, Gaps{(int8_t)b->gap_open, (int8_t)b->gap_extend}, b->min_size, b->max_size, b->mode, n, already_converted, get, getp, P, [](const char*) {})) return 1;
+    if (P.total > b->cap_pool) return fail("reload: %llu sequence bytes exceed the batch's capacity of %llu", (unsigned long long)P.total, (unsigned long long)b->cap_pool);
+    if (P.maxlen2 > b->cap_maxlen2) return fail("reload: a pair is longer (%llu) than the longest pair the batch was created with (%llu)", (unsigned long long)P.maxlen2 - 2, (unsigned long long)b->cap_maxlen2 - 2);
+    if ((b->mode & BA_TRACE) && P.cig_total > b->cap_cig) return fail("reload: CIGAR capacity exceeded");
+    HIP_TRY(hipMemcpy(b->pool.p, P.image.data(), P.total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->q_off.p, P.qo.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->q_len.p, P.ql.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->r_off.p, P.ro.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->r_len.p, P.rl.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->cig_off.p, P.cig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b->cig_len.p, 0, n * 4));
+    HIP_TRY(hipMemset(b->status.p, 0, n * 4));
+    b->n = (uint32_t)n; b->h_q_off = P.qo; b->h_r_off = P.ro; b->pool_bytes = P.total;
+    b->cig_total = (b->mode & BA_TRACE) ? P.cig_total : 0;
+    b->ran = false;
+    return 0;
 }
 
 static int batch_run(BaBatch* b, float* kernel_ms) {
@@ -465,6 +548,19 @@ BaBatch* ba_batch_create_profile(const AAProfile* const* profiles, SizeRange siz
     return batch_build(BA_KIND_PROFILE_, nullptr, g, size, x_drop, mode, n, false,
                        [&](size_t p, int, const uint8_t** ptr, size_t* len) { *ptr = pool + q_off[p]; *len = q_len[p]; },
                        [&](size_t p) { return profiles[p]; });
+}
+int ba_batch_reload(BaBatch* b, const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n) {
+    if (!b || !pool || !q_off || !q_len || !r_off || !r_len) return fail("null argument");
+    if (b->kind == BA_KIND_PROFILE_) return fail("profile batches are reloaded with ba_batch_reload_profile");
+    return batch_reload(b, n, false, [&](size_t p, int w, const uint8_t** ptr, size_t* len) {
+        if (w == 0) { *ptr = pool + q_off[p]; *len = q_len[p]; } else { *ptr = pool + r_off[p]; *len = r_len[p]; }
+    });
+}
+int ba_batch_reload_profile(BaBatch* b, const AAProfile* const* profiles, const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, uintptr_t n) {
+    if (!b || !profiles || !pool || !q_off || !q_len) return fail("null argument");
+    if (b->kind != BA_KIND_PROFILE_) return fail("not a profile batch");
+    return batch_reload(b, n, false, [&](size_t p, int, const uint8_t** ptr, size_t* len) { *ptr = pool + q_off[p]; *len = q_len[p]; },
+                        [&](size_t p) { return profiles[p]; });
 }
 int ba_batch_run(BaBatch* b, float* kernel_ms) { return b ? batch_run(b, kernel_ms) : fail("null batch"); }
 int ba_batch_results(BaBatch* b, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {

@@ -100,6 +100,8 @@ def lib() -> C.CDLL:
         L.ba_batch_create_profile.argtypes = [vp, SizeRangeC, i32, u32, vp, vp, vp, sz]
         L.ba_batch_create.restype = vp
         L.ba_batch_create.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, u32, vp, vp, vp, vp, vp, sz]
+        L.ba_batch_reload.argtypes = [vp, vp, vp, vp, vp, vp, sz]
+        L.ba_batch_reload_profile.argtypes = [vp, vp, vp, vp, vp, sz]
         L.ba_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
         L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
@@ -330,6 +332,15 @@ class BatchAligner:
                                     q_off.ctypes.data, q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, self.n)
         if not self._h:
             raise RuntimeError(last_error())
+
+    def reload(self, pool, q_off, q_len, r_off, r_len) -> None:
+        """Replace the pairs and keep the device buffers (ba_batch_reload): the new set must fit the original one's sizes."""
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64); r_off = np.ascontiguousarray(r_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32); r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+        if lib().ba_batch_reload(self._h, pool.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, len(q_len)):
+            raise RuntimeError(last_error())
+        self.n = len(q_len)
 
     def run(self) -> float:
         """Launch and wait; returns the kernel's HIP-event time in milliseconds."""

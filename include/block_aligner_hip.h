@@ -188,6 +188,13 @@ int ba_aaprofile_set_raw(struct AAProfile* profile, const int8_t* pos_aa, const 
  * BA_CIGAR_EQ is rejected (there is no second sequence to compare with). */
 BaBatch* ba_batch_create_profile(const struct AAProfile* const* profiles, struct SizeRange size, int32_t x_drop, uint32_t mode,
                                  const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, uintptr_t n_pairs);
+/* Replace the pairs of an existing batch and keep its device buffers (the trace arena above all, whose allocation
+ * dominates the set-up time): same matrix, gaps, block range and modes. The new set must fit what the batch was created
+ * with: no more pairs, no more sequence bytes in total, no pair longer than the longest original one. */
+int ba_batch_reload(BaBatch* batch, const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
+                    const uint32_t* r_len, uintptr_t n_pairs);
+int ba_batch_reload_profile(BaBatch* batch, const struct AAProfile* const* profiles, const uint8_t* pool, const uint64_t* q_off,
+                            const uint32_t* q_len, uintptr_t n_pairs);
 /* Launch on the batch's stream and wait. kernel_ms (optional) = HIP-event time of the alignment kernel alone. */
 int ba_batch_run(BaBatch* batch, float* kernel_ms);
 /* Copy results to host arrays of n_pairs elements; any pointer may be NULL. status: 0 = ok, else BA_ST_* bits. */

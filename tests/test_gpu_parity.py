@@ -266,3 +266,29 @@ def test_random_configurations(hip, oracle, seed):
         lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
     pairs = synth.PairSet.from_lists(lists)
     compare(hip, oracle, pairs, matrix, (opn, ext), (lo, hi), x_drop, mode, cigar_eq=bool(rng.integers(0, 2)))
+
+
+def test_batch_reload(hip, oracle):
+    """ba_batch_reload: new pairs through an existing batch's device buffers (the trace arena is allocated once)."""
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    first = synth.make_pairs(400, (300, 1200), (5, 100), 30, synth.DNA, seed=50)
+    b = hip.BatchAligner(NUC, (-5, -1), (32, 256), 60, mode, first.pool, first.q_off, first.q_len, first.r_off, first.r_len)
+    for seed, count in ((51, 400), (52, 123), (53, 1)):
+        nxt = synth.make_pairs(count, (0, 1000), (0, 80), 20, synth.DNA, seed=seed)
+        b.reload(nxt.pool, nxt.q_off, nxt.q_len, nxt.r_off, nxt.r_len)
+        b.run()
+        res = b.results()
+        ref = oracle.batch_align(NUC, nxt.pool, nxt.q_off, nxt.q_len, nxt.r_off, nxt.r_len, (-5, -1), (32, 256), 60, ("trace", "x_drop"), cigar_eq=True, threads=8)
+        assert not res["status"].any()
+        assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["query_idx"], ref["query_idx"]) and np.array_equal(res["cigar_len"], ref["cig_len"])
+        runs, off = b.cigars(res["cigar_len"])
+        for p in range(count):
+            want = ref["cig_ops"][int(ref["cig_off"][p]): int(ref["cig_off"][p]) + int(ref["cig_len"][p])]
+            assert np.array_equal(runs[int(off[p]): int(off[p + 1])], want), p
+    too_many = synth.make_pairs(401, 100, 5, 0, synth.DNA, seed=54)
+    with pytest.raises(RuntimeError):
+        b.reload(too_many.pool, too_many.q_off, too_many.q_len, too_many.r_off, too_many.r_len)
+    too_long = synth.make_pairs(2, 5000, 5, 0, synth.DNA, seed=55)
+    with pytest.raises(RuntimeError):
+        b.reload(too_long.pool, too_long.q_off, too_long.q_len, too_long.r_off, too_long.r_len)
+    b.close()
