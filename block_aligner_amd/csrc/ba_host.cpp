@@ -393,12 +393,24 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
     const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
     if (grid > need) grid = need;
-    b->grid = (uint32_t)grid;
     // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
     // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
     b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) : 0;
     b->blocks_stride = trace ? maxlen2 : 0;
     if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
+    if (trace) {
+        // very long pairs: a trace slot can be hundreds of MB, so fewer waves may be resident than the chip could hold --
+        // shrink the launch until one slot per wave fits in device memory (a long pair keeps its wave busy for long anyway)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
+        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
+        const uint64_t budget = free_b * 9 / 10 > fixed ? free_b * 9 / 10 - fixed : 0;
+        const uint64_t max_waves = per_slot ? budget / per_slot : ~0ull;
+        if (max_waves < ba::WAVES_PER_WG) { fail("device memory: one workgroup's trace slots need %llu MB, %llu MB are free", (unsigned long long)(per_slot * ba::WAVES_PER_WG >> 20), (unsigned long long)(budget >> 20)); return nullptr; }
+        if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
+    }
+    b->grid = (uint32_t)grid;
     // TRACE batches big enough to keep them busy get dedicated traceback workgroups (ba_driver.hpp traceback_consumer)
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
     b->tb_stride = 0; b->slots_per_wave = 1;

@@ -292,3 +292,20 @@ def test_batch_reload(hip, oracle):
     with pytest.raises(RuntimeError):
         b.reload(too_long.pool, too_long.q_off, too_long.q_len, too_long.r_off, too_long.r_len)
     b.close()
+
+
+def test_trace_slots_larger_than_memory_share(hip, oracle):
+    """330 pairs of 2 x 400 kbp at max block 2048: one trace slot is 0.8 GB, so the full launch (4096 waves) would need
+    3 TB; the launch shrinks to the waves whose slots fit in device memory instead of failing to allocate."""
+    pairs = synth.make_pairs(330, 400000, 12000, 100, synth.DNA, seed=777, workers=8)
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 2048), 200, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    info = b.info()
+    assert info["grid"] < 330 and info["trace_arena_bytes"] > 100e9        # fewer waves than pairs, arena near the memory size
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (128, 2048), 200, ("trace", "x_drop"), cigar_eq=True, threads=8)
+    assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["query_idx"], ref["query_idx"]) and np.array_equal(res["cigar_len"], ref["cig_len"])
+    assert int(res["cells"].sum()) == ref["cells"]
+    b.close()
