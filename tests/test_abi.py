@@ -69,3 +69,16 @@ def test_host_objects_without_gpu(hip):
     c = hip.Cigar(10, 10)
     assert c.len() == 0 and str(c) == ""
     assert hip.percent_len(10000, 0.01) == 128 and hip.percent_len(10000, 0.1) == 1024
+
+
+def test_alignment_fails_loudly_without_a_device(hip):
+    """There is no CPU fallback: without a usable HIP device the batch constructor reports it (and never computes)."""
+    import numpy as np
+    import pytest
+    from block_aligner_amd import scores as S
+    if hip.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    pool = np.frombuffer(b"ACGTACGTAC" + b"\0" * 8, np.uint8)
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        hip.BatchAligner(S.NW1, (-2, -1), (32, 32), 0, 0, pool, np.array([0], np.uint64), np.array([4], np.uint32),
+                         np.array([4], np.uint64), np.array([6], np.uint32))
