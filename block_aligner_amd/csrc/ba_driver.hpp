@@ -391,7 +391,7 @@ struct Aligner {
     uint32_t qlen, rlen;
     uint32_t* trace; BlockRec* blocks; short* ckpt;   // this wave's slot in the global scratch arenas
     uint32_t trace_top = 0, nblocks = 0;
-    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot (see park())
+    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot, 9-11 the first grow rectangle's max / row / col (see park())
     uint32_t status = 0;
     unsigned long long cells = 0;
     // sequence bytes for the next shift step, fetched one step ahead for both possible directions
@@ -535,7 +535,6 @@ struct Aligner {
         uint32_t y_drop_iter = 0; int x_drop_iter = 0;
         int D_corner = 0;
         int gphase = 0;                 // 0 = first rectangle of this driver step, 1 = second rectangle of a grow
-        Best grow{0, 0, 0};
         int off_add = 0;
 
         uint32_t step_budget = 64u * ((qlen + rlen) / STEP + 64u);   // watchdog: far above any legal run
@@ -554,7 +553,6 @@ struct Aligner {
                 steps++;
 #endif
                 prev_off = off;
-                grow = Best{0, 0, 0};
             }
             if (dir == DIR_RIGHT) {
                 off = off_max;
@@ -636,7 +634,10 @@ struct Aligner {
 #undef BA_PLACE1
             BA_TSTAMP(ts2);
             BA_TADD(prof, 12, ts0, ts1); BA_TADD(prof, 13, ts1, ts2);
-            if (dir == DIR_GROW && gphase == 0) { grow = cur; gphase = 1; continue; }
+            if (dir == DIR_GROW && gphase == 0) {   // first rectangle of a grow: its maximum waits (parked) for the second one
+                park<9>(parked, cur.mx); park<10>(parked, cur.row); park<11>(parked, cur.col);
+                gphase = 1; continue;
+            }
             gphase = 0;
 
             // ---- the rest of the driver step
@@ -664,7 +665,8 @@ struct Aligner {
             const int this_dir = dir;
             prev_dir = dir;
             // FREE_QUERY_END_GAPS: only the vector lane that holds the last query row counts (scan_block.rs:333-339)
-            const int D_max_max = FQE ? fq.M : cur.mx, grow_max = grow.mx;
+            const bool was_grow = dir == DIR_GROW;
+            const int D_max_max = FQE ? fq.M : cur.mx, grow_max = was_grow ? unpark<9>(parked) : 0;   // (0 = MIN: no grow rectangle)
             const int mx = max(D_max_max, grow_max);
             off_max = off + mx - ZERO;
             y_drop_iter++;
@@ -682,7 +684,7 @@ struct Aligner {
                     if (this_dir == DIR_RIGHT) { bi_ = si + cur.row; bj_ = sj + (block_size - STEP) + cur.col; }
                     else if (this_dir == DIR_DOWN) { bi_ = si + (block_size - STEP) + cur.col; bj_ = sj + cur.row; }
                     else if (D_max_max >= grow_max) { bi_ = si + cur.row; bj_ = sj + prev_size + cur.col; }
-                    else { bi_ = si + prev_size + grow.col; bj_ = sj + grow.row; }
+                    else { bi_ = si + prev_size + (uint32_t)unpark<11>(parked); bj_ = sj + (uint32_t)unpark<10>(parked); }
                     park<5>(parked, (int)bi_); park<6>(parked, (int)bj_);
                 }
                 if (block_size < max_size) {
