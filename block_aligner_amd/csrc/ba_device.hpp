@@ -273,10 +273,12 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     for (int ch = 0; ch < NCH; ch++) {
         const int r0 = ch * 128 + 2 * lane;
         int dv = 0, cv = 0, a = ca[ch], b = cb_[ch];
-        if (active) { dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0); }
+        // (fast path: unpredicated reads -- every lane's address is inside the border arrays and their padding, and what
+        // the inactive lanes of a block below 128 cells compute never reaches an active lane, a store or a reduction)
+        if (FAST || active) { dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0); }
         if (FAST) {
             // every LDS read of the step is issued here, in one batch
-            if (pas_in) { pasD = *(const int*)(fs->Pd + r0 + STEP); pasR = *(const int*)(fs->Pr + r0 + STEP); }
+            pasD = *(const int*)(fs->Pd + r0 + STEP); pasR = *(const int*)(fs->Pr + r0 + STEP);
             const int c7 = (int)fs->Pd[STEP - 1];
             fs->corner_new = uni((int)as_s(adds(splat(c7), offa)).x);
             pasD = adds(pasD, offa); pasR = adds(pasR, offa);
