@@ -244,12 +244,14 @@ def test_random_configurations(hip, oracle, seed):
     modes = [(), ("x_drop",), ("trace",), ("trace", "x_drop"), ("trace", "local_start"), ("local_start", "x_drop"),
              ("trace", "free_query_start_gaps"), ("trace", "free_query_end_gaps"), ("free_query_end_gaps", "local_start")]
     mode = modes[int(rng.integers(0, len(modes)))]
+    if kind == "bytes":   # the byte matrix does not penalise the padding (scores.rs:235-239): X-drop / free-end maxima can
+        mode = tuple(m for m in mode if m not in ("x_drop", "free_query_end_gaps"))   # land past the sequence end, where the reference's cigar() panics
     if kind == "nuc":
         matrix, alpha = S.NucMatrix.new_simple(int(rng.integers(1, 6)), -int(rng.integers(1, 8))), synth.DNA
     elif kind == "aa":
         matrix, alpha = [S.BLOSUM62, S.static_matrix("PAM120"), S.static_matrix("BLOSUM90")][int(rng.integers(0, 3))], synth.AMINO
     else:
-        matrix, alpha = S.ByteMatrix.new_simple(int(rng.integers(1, 5)), -int(rng.integers(1, 5))), np.frombuffer(b"abcdxyz\x00\xfe", np.uint8)
+        matrix, alpha = S.ByteMatrix.new_simple(int(rng.integers(1, 5)), -int(rng.integers(1, 5))), np.frombuffer(b"abcdxyz\x01\xfe", np.uint8)   # (not byte 0: it is the pad byte and would match the padding)
     fqe = "free_query_end_gaps" in mode
     lists = []
     for _ in range(40):
