@@ -84,7 +84,7 @@ __device__ __forceinline__ Move tb_lut(bool right_blk, uint32_t t, uint32_t t2, 
 
 // Walk back from (i, j); emit run-length ops right-aligned into [out_lo, out_hi). Returns run count, or
 // sets *status on failure. Executed by lane 0 only. (scan_block.rs:1482-1672)
-__device__ inline uint32_t traceback(const BlockRec* __restrict__ blocks, uint32_t nblocks, const uint32_t* __restrict__ trace,
+__device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ blocks, uint32_t nblocks, const uint32_t* __restrict__ trace,
                                      uint32_t i, uint32_t j, const uint8_t* __restrict__ q, const uint8_t* __restrict__ r, uint32_t flags,
                                      uint32_t* __restrict__ out, uint64_t out_lo, uint64_t out_hi, uint32_t* status) {
     const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
@@ -422,7 +422,7 @@ struct Aligner {
         ck_in_regs = true;
     }
 
-    __device__ Aligner(const BatchParams& b, const WaveLds& L_, const FillConsts& fc_) : L(L_), fc(fc_) {
+    __device__ __forceinline__ Aligner(const BatchParams& b, const WaveLds& L_, const FillConsts& fc_) : L(L_), fc(fc_) {
         h_flags = b.flags; h_max_size = b.max_size; h_x_drop = b.x_drop;
     }
 
@@ -505,7 +505,8 @@ struct Aligner {
         }
     }
 
-    __device__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback) {
+    // (always inlined: as a real call the Aligner object and everything it references would live in scratch memory)
+    __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback) {
         q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
         qlen = coldp()->q_len[pair_in]; rlen = coldp()->r_len[pair_in];
         const uint32_t min_size = coldp()->min_size, max_size = h_max_size;

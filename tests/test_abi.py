@@ -82,3 +82,25 @@ def test_alignment_fails_loudly_without_a_device(hip):
     with pytest.raises(RuntimeError, match="no usable HIP device"):
         hip.BatchAligner(S.NW1, (-2, -1), (32, 32), 0, 0, pool, np.array([0], np.uint64), np.array([4], np.uint32),
                          np.array([4], np.uint64), np.array([6], np.uint32))
+
+
+def test_kernels_contain_no_function_calls(tmp_path):
+    """Every device function must be inlined into its kernel: a real call puts the per-pair state (and everything it
+    references) into scratch memory -- one such build faulted on the GPU. Disassembles every gfx950 code object of the
+    library and looks for call instructions."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    from block_aligner_amd import hip as H
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("llvm-objdump not available")
+    lib = shutil.copy(H.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert len(objs) >= 40, objs
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", o], capture_output=True, text=True, check=True).stdout
+        assert "s_swappc" not in dis and "s_call" not in dis, o

@@ -311,3 +311,39 @@ def test_trace_slots_larger_than_memory_share(hip, oracle):
     assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["query_idx"], ref["query_idx"]) and np.array_equal(res["cigar_len"], ref["cig_len"])
     assert int(res["cells"].sum()) == ref["cells"]
     b.close()
+
+
+@pytest.mark.parametrize("mode", [("trace", "local_start"), ("local_start", "x_drop"), ("trace", "free_query_start_gaps"),
+                                  ("trace", "free_query_end_gaps"), ("free_query_end_gaps",)])
+def test_profile_special_modes(hip, oracle, mode):
+    """The special modes on the sequence-to-profile path (the const generics of Block apply to align_profile too)."""
+    rng = np.random.default_rng(91 + len(mode[0]) + len(mode))
+    fqe = "free_query_end_gaps" in mode
+    size = (128, 256) if fqe else (32, 128)
+    cases = []
+    for _ in range(60):
+        q, p = _pssm_case(rng, int(rng.integers(1, 300)), size[1])
+        if fqe:
+            q = q[: int(rng.integers(0, 100))]          # min block size must exceed the query length
+        elif rng.random() < 0.5:
+            q = bytes(AA20[i] for i in rng.integers(0, 20, int(rng.integers(0, 30)))) + q   # unrelated prefix
+        cases.append((q, p))
+    pool = np.frombuffer(b"".join(q for q, _ in cases) + b"\0" * 8, np.uint8)
+    q_len = np.array([len(q) for q, _ in cases], np.uint32)
+    q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.uint64)
+    m = 0
+    for name in mode:
+        m |= {"trace": hip.TRACE, "x_drop": hip.X_DROP, "local_start": hip.LOCAL_START,
+              "free_query_start_gaps": hip.FREE_QUERY_START_GAPS, "free_query_end_gaps": hip.FREE_QUERY_END_GAPS}[name]
+    b = hip.ProfileBatchAligner([p for _, p in cases], size, 25, m, pool, q_off, q_len)
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"]) if "trace" in mode else (None, None)
+    for k, (q, p) in enumerate(cases):
+        ref = oracle.align_profile(q, p, size, 25, mode)
+        got = (int(res["score"][k]), int(res["query_idx"][k]), int(res["reference_idx"][k]), int(res["cells"][k]))
+        assert got == (ref["score"], ref["query_idx"], ref["reference_idx"], ref["cells"]), (k, len(q), p.str_len, got, ref)
+        if "trace" in mode:
+            assert hip.runs_to_string(runs[int(off[k]): int(off[k + 1])]) == ref["cigar"], k
+    b.close()
