@@ -347,3 +347,57 @@ def test_profile_special_modes(hip, oracle, mode):
         if "trace" in mode:
             assert hip.runs_to_string(runs[int(off[k]): int(off[k + 1])]) == ref["cigar"], k
     b.close()
+
+
+@pytest.mark.parametrize("mode,size", [(("trace", "local_start", "x_drop"), (32, 2048)), (("trace", "free_query_start_gaps"), (64, 1024)),
+                                       (("trace", "free_query_end_gaps"), (2048, 2048)), (("free_query_end_gaps", "local_start"), (1024, 2048))])
+def test_special_modes_large_blocks(hip, oracle, mode, size):
+    """The special-mode kernels keep whole columns in registers up to 2048 cells (8 and 16 chunks): long indels make the
+    block grow all the way."""
+    if "free_query_end_gaps" in mode:
+        pairs = _substring_pairs(60, 3 + size[0], qlen=(200, size[0] - 40), rlen=(1500, 4000), edits=(0, 30))
+    else:
+        pairs = synth.make_pairs(60, (1500, 4000), (50, 300), 60, synth.DNA, seed=size[1], indels=3, indel_len=(50, 500))
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 80, mode)
+    prot = synth.make_pairs(40, (300, 1500), (20, 200), 0, synth.AMINO, seed=5 + size[1], indels=2, indel_len=(30, 200))
+    if "free_query_end_gaps" not in mode:
+        compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), size, 60, mode, cigar_eq=False)
+
+
+def test_profile_traceback_lanes_and_exp(hip, oracle, monkeypatch):
+    """Profile batches through the in-launch traceback hand-off (forced on a small batch), and align_profile_exp as a batch."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", "1")
+    rng = np.random.default_rng(2024)
+    cases = [_pssm_case(rng, int(rng.integers(20, 400)), 256) for _ in range(3000)]
+    pool = np.frombuffer(b"".join(q for q, _ in cases) + b"\0" * 8, np.uint8)
+    q_len = np.array([len(q) for q, _ in cases], np.uint32)
+    q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.uint64)
+    profiles = [p for _, p in cases]
+    b = hip.ProfileBatchAligner(profiles, (32, 256), 0, hip.TRACE, pool, q_off, q_len)
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"])
+    for k in range(0, len(cases), 7):
+        ref = oracle.align_profile(cases[k][0], cases[k][1], (32, 256), 0, ("trace",))
+        assert (int(res["score"][k]), int(res["query_idx"][k]), int(res["reference_idx"][k])) == (ref["score"], ref["query_idx"], ref["reference_idx"]), k
+        assert hip.runs_to_string(runs[int(off[k]): int(off[k + 1])]) == ref["cigar"], k
+    b.close()
+    monkeypatch.delenv("BA_FORCE_TB"); monkeypatch.delenv("BA_WGS_PER_CU")
+    # align_profile_exp over the first 300 pairs: the median score of the fixed-size run as target
+    sub = slice(0, 300)
+    target = int(np.median(res["score"][sub]))
+    sc, qi, ri, reached = hip.batch_align_profile_exp(profiles[sub], (32, 256), 0, target, 0, pool, q_off[sub], q_len[sub])
+    lib = oracle.lib
+    import ctypes as C
+    for k in range(300):
+        # the oracle's align_profile_exp (scan_block.rs:974-992), written out with align_profile
+        mn, got = 32, None
+        while mn <= 256:
+            r = oracle.align_profile(cases[k][0], cases[k][1], (mn, 256), 0, ())
+            if r["score"] >= target:
+                got = mn
+                break
+            mn *= 2
+        assert (int(sc[k]), int(qi[k]), int(ri[k]), int(reached[k]) or None) == (r["score"], r["query_idx"], r["reference_idx"], got), k
