@@ -401,3 +401,33 @@ def test_profile_traceback_lanes_and_exp(hip, oracle, monkeypatch):
                 break
             mn *= 2
         assert (int(sc[k]), int(qi[k]), int(ri[k]), int(reached[k]) or None) == (r["score"], r["query_idx"], r["reference_idx"], got), k
+
+
+def test_batch_api_errors_and_coexisting_batches(hip, oracle):
+    """Argument errors come back as errors (never aborts, never a silent fallback); two TRACE batches alive at once share
+    the device memory that is left."""
+    good = synth.make_pairs(64, (100, 600), (0, 40), 10, synth.DNA, seed=8)
+    args = (good.pool, good.q_off, good.q_len, good.r_off, good.r_len)
+    with pytest.raises(RuntimeError, match="alphabet"):
+        bad = good.pool.copy(); bad[int(good.q_off[3]) + 1] = ord("!")
+        hip.BatchAligner(NUC, (-5, -1), (32, 64), 0, 0, bad, *args[1:])
+    with pytest.raises(RuntimeError, match="negative"):
+        hip.BatchAligner(NUC, (5, -1), (32, 64), 0, 0, *args)
+    with pytest.raises(RuntimeError, match="powers of two"):
+        hip.BatchAligner(NUC, (-5, -1), (48, 64), 0, 0, *args)
+    with pytest.raises(RuntimeError, match="not supported"):
+        hip.BatchAligner(NUC, (-5, -1), (32, 4096), 0, 0, *args)
+    with pytest.raises(RuntimeError, match="LOCAL_START"):
+        hip.BatchAligner(NUC, (-5, -1), (32, 64), 0, hip.LOCAL_START | hip.FREE_QUERY_START_GAPS, *args)
+    with pytest.raises(RuntimeError):
+        hip.BatchAligner(NUC, (-5, -1), (32, 64), 0, 0, good.pool, good.q_off[:0], good.q_len[:0], good.r_off[:0], good.r_len[:0])
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    a = hip.BatchAligner(NUC, (-5, -1), (32, 256), 50, mode, *args)
+    other = synth.make_pairs(80, (100, 900), (0, 60), 10, synth.DNA, seed=9)
+    b = hip.BatchAligner(NUC, (-5, -1), (32, 256), 50, mode, other.pool, other.q_off, other.q_len, other.r_off, other.r_len)
+    b.run(); a.run()
+    for batch, ps in ((a, good), (b, other)):
+        res = batch.results()
+        ref = oracle.batch_align(NUC, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len, (-5, -1), (32, 256), 50, ("trace", "x_drop"), cigar_eq=True, threads=4)
+        assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["cigar_len"], ref["cig_len"])
+    a.close(); b.close()
