@@ -104,3 +104,22 @@ def test_kernels_contain_no_function_calls(tmp_path):
     for o in objs:
         dis = subprocess.run([objdump, "-d", o], capture_output=True, text=True, check=True).stdout
         assert "s_swappc" not in dis and "s_call" not in dis, o
+
+
+def test_reference_preconditions_abort_like_the_reference():
+    """The per-pair API keeps the reference's contract: a violated assert! aborts the process with the reference's
+    message (release profile: panic = abort, Cargo.toml:41) -- no error code is invented. Checked in a child process."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from block_aligner_amd import hip as H, scores as S\n"
+            "q = H.PaddedBytes.from_bytes(b'ACGT', 32, S.NucMatrix); r = H.PaddedBytes.from_bytes(b'ACGT', 32, S.NucMatrix)\n"
+            "H.Block(4, 4, 32).align(q, r, S.NW1, S.Gaps(%d, %d), (%d, 32), 0)\n")
+    for gaps, lo, msg in (((2, -1), 32, "Gap costs must be negative!"), ((-1, -2), 32, "Gap open must cost more than gap extend!"),
+                          ((-2, -1), 24, "Block sizes must be powers of two!")):
+        p = subprocess.run([sys.executable, "-c", code % (root, gaps[0], gaps[1], lo)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == -signal.SIGABRT, (p.returncode, p.stderr[-300:])
+        assert msg in p.stderr, p.stderr[-300:]
