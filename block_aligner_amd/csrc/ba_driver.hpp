@@ -139,10 +139,10 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
 }
 
 // ------------------------------------------------------------------ traceback lanes (batch path)
-// In a TRACE batch the fill waves do not walk their own tracebacks: a walk is ~(|q|+|r|) dependent global loads and
-// would idle 63 lanes for as long as the fill itself takes. Finished trace stacks are handed to dedicated traceback
-// workgroups of the same persistent launch through a global ring (agent-scope release / acquire, MI355X guide G16);
-// there every LANE walks one alignment, one cell per loop iteration, so 64 latency-bound walks overlap per wave.
+// In a TRACE batch the fill waves do not walk their own tracebacks: a walk is ~(|q|+|r|) dependent steps and would
+// idle 63 lanes for as long as the fill itself takes. Finished trace stacks are handed to traceback waves of the same
+// persistent launch (wave 0 of every tb_stride-th workgroup) through a global ring (agent-scope release / acquire,
+// MI355X guide G16); there every LANE walks one alignment out of per-lane LDS windows, so 64 walks overlap per wave.
 #define BA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 struct TbLane {
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         if (bp.prof && is_lane(0)) atomicAdd(bp.prof + 17, tw1 - tw0);
 #endif
         if (!got_slot) {
-            // the traceback workgroups are not making progress: report instead of hanging. The pair still has to
+            // the traceback waves are not making progress: report instead of hanging. The pair still has to
             // produce its queue entry so the consumers' task count stays exact.
             al.status = ST_SLOT_TIMEOUT;
             if (is_lane(0)) { bp.score[pair] = 0; bp.query_idx[pair] = 0; bp.reference_idx[pair] = 0; }

@@ -411,7 +411,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
     }
     b->grid = (uint32_t)grid;
-    // TRACE batches big enough to keep them busy get dedicated traceback workgroups (ba_driver.hpp traceback_consumer)
+    // TRACE batches big enough to keep them busy get dedicated traceback waves (ba_driver.hpp traceback_consumer)
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
     b->tb_stride = 0; b->slots_per_wave = 1;
     b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
