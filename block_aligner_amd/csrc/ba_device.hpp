@@ -371,7 +371,6 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
-        int up_ro = 0;                                   // "R opened" flag of the cell above the chunk (0 at the top)
         const int jp1 = splat((int)j + 1);
         int r_last = 0;
 #pragma unroll
@@ -408,14 +407,12 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             if (TRACE) {
                 const int nC = neq01(dn, cend, fc.ones), nR = neq01(dn, rend, fc.ones);
                 const int nCo = neq01(cn, copen, fc.ones), eRo = eq01(r, x, fc.ones);
-                // "R opened" belongs to the cell below it (scan_block.rs:1179-1182): stored as an "equal" bit so the
-                // column top needs no fill value
-                int pn = wave_shr1_z(eRo);
-                if (NCH > 1) { if (up_ro != 0) pn = set_lane0(pn, up_ro); up_ro = __builtin_amdgcn_readlane(eRo, 63); }
-                const int eRs = __builtin_amdgcn_alignbit(eRo, pn, 16);
+                // "R opened" (R == D_open) is stored with the cell it was computed in; the reference shifts it to the cell
+                // below (scan_block.rs:1179-1182) -- the traceback resolves it at the destination of the gap move instead,
+                // which saves the lane shift here and the carry between chunks
                 int nib = pk_mad(nR, 0x00020002, nC);
                 nib = pk_mad(nCo, 0x00040004, nib);
-                nib = pk_mad(eRs, 0x00080008, nib);
+                nib = pk_mad(eRo, 0x00080008, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
                 if (!FAST && (sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
                     trace_out[zwords + (j * NCH + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);

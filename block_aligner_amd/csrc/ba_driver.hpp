@@ -68,18 +68,32 @@ __device__ __forceinline__ int lds_shift_and_offset(uint32_t n, short* b1, short
 
 // ------------------------------------------------------------------ traceback (one lane walks the path)
 struct Move { uint32_t op, di, dj, next; };
-// OP_LUT of scan_block.rs:1532-1558 as branches; table: 0 = D, 1 = C, 2 = R; t/t2 as the reference defines them
+// OP_LUT of scan_block.rs:1532-1558 as branches; table: 0 = D, 1 = C, 2 = R, 3 = pending; t as the reference defines it,
+// t2 bit 0 = "C opened here". The reference's trace2 bit 1 -- "the scan-direction gap that reaches this cell was opened
+// in the cell above" -- is not stored per cell: a scan-direction gap move leaves the state PENDING (3) and the walker
+// resolves it at the destination from that cell's own "opened here" bit (tb_resolve), which is the same value.
+constexpr uint32_t TB_PENDING = 3;
 __device__ __forceinline__ Move tb_lut(bool right_blk, uint32_t t, uint32_t t2, uint32_t table) {
     constexpr uint32_t OP_M = 1, OP_I = 4, OP_D = 5;
     const uint32_t gapA_op = right_blk ? OP_D : OP_I, gapB_op = right_blk ? OP_I : OP_D;
     const uint32_t A_di = right_blk ? 0 : 1, A_dj = right_blk ? 1 : 0;
     const uint32_t A_tab = right_blk ? 1 : 2, B_tab = right_blk ? 2 : 1;
-    // "A" = the gap kind tracked by trace bit 0 / trace2 bit 0 (C for right blocks, R for down blocks)
+    // "A" = the gap kind tracked by trace bit 0 / trace2 bit 0 (C for right blocks, R for down blocks); "B" = the
+    // scan-direction gap (along the vectors)
     if (table == A_tab) return (t2 & 1) ? Move{gapA_op, A_di, A_dj, 0} : Move{gapA_op, A_di, A_dj, A_tab};
-    if (table == B_tab) return (t2 & 2) ? Move{gapB_op, 1 - A_di, 1 - A_dj, 0} : Move{gapB_op, 1 - A_di, 1 - A_dj, B_tab};
+    if (table == B_tab) return Move{gapB_op, 1 - A_di, 1 - A_dj, TB_PENDING};
     if (t == 0) return Move{OP_M, 1, 1, 0};
     if (t & 1) return (t2 & 1) ? Move{gapA_op, A_di, A_dj, 0} : Move{gapA_op, A_di, A_dj, A_tab};
-    return (t2 & 2) ? Move{gapB_op, 1 - A_di, 1 - A_dj, 0} : Move{gapB_op, 1 - A_di, 1 - A_dj, B_tab};
+    return Move{gapB_op, 1 - A_di, 1 - A_dj, TB_PENDING};
+}
+// state on arrival at a cell: a pending scan-direction gap continues unless it was opened in this very cell
+__device__ __forceinline__ uint32_t tb_resolve(bool right_blk, uint32_t table, uint32_t nib) {
+    return table == TB_PENDING ? ((nib & 8u) ? 0u : (right_blk ? 2u : 1u)) : table;
+}
+// state after a move: a scan-direction gap leaving through the top row of a rectangle stays a gap (the reference's
+// flag for the first vector of a column is 0, scan_block.rs:1103,1180)
+__device__ __forceinline__ uint32_t tb_next(bool right_blk, uint32_t next, uint32_t v) {
+    return (next == TB_PENDING && v == 0) ? (right_blk ? 2u : 1u) : next;
 }
 
 // Walk back from (i, j); emit run-length ops right-aligned into [out_lo, out_hi). Returns run count, or
@@ -110,17 +124,18 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             const uint32_t v = right_blk ? ci : cj, w = right_blk ? cj : ci;
             const uint32_t chunk = v >> 7, lane = (v & 127) >> 1;
             if (right_blk && fqs && i == 0) { stop = true; break; }                     // scan_block.rs:1597-1599
+            const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
+            const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 stored as "differs", bit 3 as "equal"
+            table = tb_resolve(right_blk, table, nib);
             if (local && table == 0) {                                                   // scan_block.rs:1604-1611
                 const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
                 if ((z >> ((v & 1) * 16)) & 1) { stop = true; break; }
             }
-            const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
-            const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 stored as "differs", bit 3 as "equal"
-            const Move m = tb_lut(right_blk, nib & 3, nib >> 2, table);
+            const Move m = tb_lut(right_blk, nib & 3, (nib >> 2) & 1, table);
             uint32_t op = m.op;
             if (eq && op == 1) op = q[i] == r[j] ? 2 : 3;
             if (m.di > i || m.dj > j) { *status |= ST_TRACEBACK_LOST; return 0; }   // would leave the matrix: corrupt trace
-            i -= m.di; j -= m.dj; table = m.next;
+            i -= m.di; j -= m.dj; table = tb_next(right_blk, m.next, v);
             if (op == run_op) run_len++;
             else {
                 if (run_len) {
@@ -245,19 +260,21 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         const uint32_t lc = (v & 127) >> 1;
         if (t.right && fqs && t.i == 0) { t.i = t.j = 0; break; }                       // scan_block.rs:1597-1599
         uint32_t nib;
-        if (local) {   // zero mask first (scan_block.rs:1604-1611); no window in this mode: one cell per call
+        if (local) {   // no window in this mode: one cell per call
             if (!(s == 0 && fresh)) break;
             const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
-            if (t.table == 0) {
+            nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;
+            t.table = tb_resolve(t.right, t.table, nib);
+            if (t.table == 0) {   // zero mask (scan_block.rs:1604-1611)
                 const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
                 if ((z >> ((v & 1) * 16)) & 1) { t.i = t.j = 0; break; }
             }
-            nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;
         } else {
             const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
             if ((v >> 7) != t.tw_chunk || gi > 1u || k > 4u) break;                     // left the window: next call reloads it
             const uint32_t byte = lrec[gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1)];
             nib = ((byte >> ((w & 1) * 4)) ^ 7u) & 15u;                                 // bits 0-2 "differs", bit 3 "equal"
+            t.table = tb_resolve(t.right, t.table, nib);
         }
         const uint32_t m = lut[((uint32_t)t.right << 6) | (t.table << 4) | nib];        // op | di << 3 | dj << 4 | next << 5
         uint32_t op = m & 7u;
@@ -268,7 +285,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
             op = lrec[40 + qo] == lrec[56 + ro] ? 2 : 3;
         }
         if (di > t.i || dj > t.j) { tb_fail(t); return; }   // would leave the matrix: corrupt trace
-        t.i -= di; t.j -= dj; t.table = m >> 5;
+        t.i -= di; t.j -= dj; t.table = tb_next(t.right, m >> 5, v);
         if (op == t.run_op) t.run_len++;
         else { tb_emit(t, out); t.run_op = op; t.run_len = 1; }
     }
@@ -287,7 +304,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const uint32_t idx = (uint32_t)lane_id() + 64u * e;
-        const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 3, (idx >> 4) & 3);
+        const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);   // (bit 3 of the cell's nibble is resolved before the lookup)
         lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
     }
     lds_sync();
