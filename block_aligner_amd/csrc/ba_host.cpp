@@ -416,9 +416,11 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     b->tb_stride = 0; b->slots_per_wave = 1;
     b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
     if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
-        // 5 is coprime with the 8 XCDs the workgroups are dealt over, so the traceback waves land on every XCD; one
-        // traceback wave per 39 fill waves keeps up with config 3 with margin (7 does not)
-        uint32_t stride = b->grid >= 32 ? 5 : 2;
+        // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 is as fast and one per 6 already
+        // 8 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
+        // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
+        // no difference now that a walk runs out of LDS.)
+        uint32_t stride = b->grid >= 32 ? 4 : 2;
         if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
