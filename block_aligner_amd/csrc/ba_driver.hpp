@@ -294,7 +294,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
 __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
     int phase = IDLE;
-    uint32_t claimed = 0;
+    uint32_t claimed = 0, pend = 0;
     TbLane t{};
     const uint32_t eq = bp.flags & flag_mask;   // mode bits the walk looks at: CIGAR_EQ, LOCAL_START, FREE_QUERY_START_GAPS
     uint32_t* head = bp.tb_ctrl + 32;
@@ -324,13 +324,13 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
         if (phase == IDLE) {
             claimed = __hip_atomic_fetch_add(head, 1u, BA_RLX_AGENT);
             phase = claimed >= bp.n ? RETIRED : WAIT;     // every pair yields exactly one task
+            pend = 0;
         }
-        bool got = false;
-        uint32_t entry = 0;
-        if (phase == WAIT) {
-            entry = __hip_atomic_load(bp.tb_queue + (claimed & bp.tb_qmask), BA_RLX_AGENT);
-            got = entry != 0;
-        }
+        // `pend` = this lane's ring entry as read at the END of the previous iteration: the poll's round trip to L2
+        // overlaps with the other lanes' walk instead of stalling every iteration in which some lane is waiting
+        const bool got = phase == WAIT && pend != 0;
+        const bool walking = phase == WALK;
+        const uint32_t entry = pend;
         if (__any(got)) {
             // ONE acquire per poll round that found work, then plain loads (guide G16): drops stale L1 lines of
             // arenas this CU read during earlier walks
@@ -353,7 +353,8 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
                 if (t.status || (bp.flags & 0x200u)) t.i = t.j = 0;          // the fill failed (or development switch: skip the walk)
                 phase = WALK;
             }
-        } else if (phase == WALK) {
+        }
+        if (walking) {
 #ifdef BA_TIMING
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
             if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut, c_sec);
@@ -369,6 +370,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
                 phase = IDLE;
             }
         }
+        if (phase == WAIT) pend = __hip_atomic_load(bp.tb_queue + (claimed & bp.tb_qmask), BA_RLX_AGENT);
 #ifdef BA_TIMING
         if (any_walk) c_walk_ticks += __builtin_amdgcn_s_memtime() - it0;
 #endif
