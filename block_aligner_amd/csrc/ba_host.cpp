@@ -175,7 +175,7 @@ struct BaBatch {
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
-    bool ran = false;
+    bool ran = false, in_flight = false;
     BatchParams params() const {
         BatchParams bp{};
         bp.pool = pool.as<uint8_t>();
@@ -478,6 +478,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
 template <class GetSeq, class GetProfile = NoProfiles>
 static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get, GetProfile getp = GetProfile()) {
     if (!b) return fail("null batch");
+    if (b->in_flight) return fail("reload: the batch has a launch in flight (ba_batch_wait first)");
     if (n == 0 || n > b->cap_n) return fail("reload: %zu pairs exceed the batch's capacity of %llu", n, (unsigned long long)b->cap_n);
     HIP_TRY(hipSetDevice(b->device));
     Packed P;
@@ -499,7 +500,9 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     return 0;
 }
 
-static int batch_run(BaBatch* b, float* kernel_ms) {
+// Enqueue one pass over the batch on its stream and return; batch_wait collects it. (Two batches on two streams
+// overlap; with ba_batch_reload the host packs the next set while the device aligns the current one.)
+static int batch_launch(BaBatch* b) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
     HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
@@ -510,10 +513,21 @@ static int batch_run(BaBatch* b, float* kernel_ms) {
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     HIP_TRY(g_launch[special_of(b->mode)][b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    b->in_flight = true;
+    return 0;
+}
+static int batch_wait(BaBatch* b, float* kernel_ms) {
+    if (!b->in_flight) return fail("nothing was launched on this batch");
+    HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));
+    b->in_flight = false;
     b->ran = true;
     return 0;
+}
+static int batch_run(BaBatch* b, float* kernel_ms) {
+    if (batch_launch(b)) return 1;
+    return batch_wait(b, kernel_ms);
 }
 
 template <class T>
@@ -577,6 +591,8 @@ int ba_batch_reload_profile(BaBatch* b, const AAProfile* const* profiles, const 
                         [&](size_t p) { return profiles[p]; });
 }
 int ba_batch_run(BaBatch* b, float* kernel_ms) { return b ? batch_run(b, kernel_ms) : fail("null batch"); }
+int ba_batch_launch(BaBatch* b) { return b ? batch_launch(b) : fail("null batch"); }
+int ba_batch_wait(BaBatch* b, float* kernel_ms) { return b ? batch_wait(b, kernel_ms) : fail("null batch"); }
 int ba_batch_results(BaBatch* b, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {
     if (!b) return fail("null batch");
     if (!b->ran) return fail("ba_batch_run has not been called");

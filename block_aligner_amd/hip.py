@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
         L.ba_batch_reload.argtypes = [vp, vp, vp, vp, vp, vp, sz]
         L.ba_batch_reload_profile.argtypes = [vp, vp, vp, vp, vp, sz]
         L.ba_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
+        L.ba_batch_launch.argtypes = [vp]
+        L.ba_batch_wait.argtypes = [vp, C.POINTER(C.c_float)]
         L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
         L.ba_batch_info.argtypes = [vp, vp]
@@ -346,6 +348,17 @@ class BatchAligner:
         """Launch and wait; returns the kernel's HIP-event time in milliseconds."""
         ms = C.c_float()
         if lib().ba_batch_run(self._h, C.byref(ms)):
+            raise RuntimeError(last_error())
+        return ms.value
+
+    def launch(self) -> None:
+        """Enqueue one pass on the batch's stream and return (ba_batch_launch); wait() collects it."""
+        if lib().ba_batch_launch(self._h):
+            raise RuntimeError(last_error())
+
+    def wait(self) -> float:
+        ms = C.c_float()
+        if lib().ba_batch_wait(self._h, C.byref(ms)):
             raise RuntimeError(last_error())
         return ms.value
 

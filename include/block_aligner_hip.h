@@ -197,6 +197,10 @@ int ba_batch_reload_profile(BaBatch* batch, const struct AAProfile* const* profi
                             const uint32_t* q_len, uintptr_t n_pairs);
 /* Launch on the batch's stream and wait. kernel_ms (optional) = HIP-event time of the alignment kernel alone. */
 int ba_batch_run(BaBatch* batch, float* kernel_ms);
+/* The two halves of ba_batch_run: enqueue on the batch's own stream and return / wait for it. Launches of different
+ * batches overlap on the device; results, cigars and reload are valid after the wait. */
+int ba_batch_launch(BaBatch* batch);
+int ba_batch_wait(BaBatch* batch, float* kernel_ms);
 /* Copy results to host arrays of n_pairs elements; any pointer may be NULL. status: 0 = ok, else BA_ST_* bits. */
 int ba_batch_results(BaBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells,
                      uint32_t* cigar_len, uint32_t* status);

@@ -425,7 +425,10 @@ def test_batch_api_errors_and_coexisting_batches(hip, oracle):
     a = hip.BatchAligner(NUC, (-5, -1), (32, 256), 50, mode, *args)
     other = synth.make_pairs(80, (100, 900), (0, 60), 10, synth.DNA, seed=9)
     b = hip.BatchAligner(NUC, (-5, -1), (32, 256), 50, mode, other.pool, other.q_off, other.q_len, other.r_off, other.r_len)
-    b.run(); a.run()
+    b.launch(); a.launch()          # both in flight on their own streams
+    with pytest.raises(RuntimeError, match="in flight"):
+        a.reload(*args)
+    a.wait(); b.wait()
     for batch, ps in ((a, good), (b, other)):
         res = batch.results()
         ref = oracle.batch_align(NUC, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len, (-5, -1), (32, 256), 50, ("trace", "x_drop"), cigar_eq=True, threads=4)
