@@ -139,6 +139,7 @@ struct FastIO {
     int vec_a, vec_b;         // in: this lane's two vector-axis bytes (already waited for by the caller)
     int col_chars;            // in: lanes 0..7 hold the 8 column bytes of the step
     short* Pd; short* Pr;     // in: the orthogonal ("passive") border pair in LDS: shifted by 8 and re-based here
+    short* sink;              // in: >= 256 bytes of this wave's LDS nothing reads (or null): lets every lane store the column's last cell unpredicated
     int act_max8, pas_max8;   // out: max of the first 8 entries of the active / passive D border (scan_block.rs:1020-1022)
     int corner_new;           // out: D_corner for a following orthogonal step (scan_block.rs:1042)
     int rAd, rAc, rPd, rPr;   // out: register images of the four borders after the step (checkpoint source)
@@ -334,6 +335,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     }
     BA_TSTAMP(tp1);
     const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
+    short* last_base = (FAST && fs->sink) ? (last_lane ? Dr : fs->sink + lane) : nullptr;
     // kc: an integral_constant; >= 0 in the grouped profile mode = the column's index inside its group of 8
     auto column = [&](const uint32_t j, auto kc) -> bool {   // returns false when the fill stops early (scan_block.rs:1216-1224)
         constexpr int K = decltype(kc)::value;
@@ -446,7 +448,9 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             for (int ch = 0; ch < NCH; ch++) tacc[ch] = 0;
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-        if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
+        if (FAST && fs->sink) {   // every lane stores; only the last lane's address is the real one (temp2 = temp1 + 16 entries)
+            last_base[j] = (short)(d[NCH - 1] >> 16); last_base[16 + j] = (short)(r_last >> 16);
+        } else if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
         cells += height;
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {
