@@ -440,7 +440,9 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             if (ch == NCH - 1) r_last = r;
         }
         if (TRACE && (j & 3) == 3) {
-            if (active) {
+            // (fast path: unpredicated -- what the lanes beyond a block of fewer than 128 cells write lands in trace words
+            // that are stored later: the next column group, the next rectangle, or the slack behind the slot)
+            if (FAST || active) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCH + ch) * nl + lane] = (uint32_t)tacc[ch];
             }

@@ -395,7 +395,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (grid > need) grid = need;
     // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
     // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
-    b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) : 0;
+    b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) + 64 : 0;   // (+ 64 words of slack: unpredicated stores of the fast path)
     b->blocks_stride = trace ? maxlen2 : 0;
     if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
     if (trace) {
