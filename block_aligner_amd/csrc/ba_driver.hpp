@@ -865,9 +865,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
     // loads, and eight of them on one CU would queue behind that CU's single memory pipeline.
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
+#ifdef BA_TIMING
+    // wall-clock (100 MHz) marks: launch start, last fill wave done, last traceback wave done -> the length of the traceback tail
+    if (bp.prof && blockIdx.x == 0 && wave == 1 && is_lane(0)) atomicMax(bp.prof + 43, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
                            (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(PMAX * 128));
+#ifdef BA_TIMING
+        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
         return;
     }
     // dense index among the fill waves (consumer waves of this and earlier workgroups skipped)
@@ -901,6 +908,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         al.ckpt = bp.ckpt + (uint64_t)fill_wave * 4 * bp.max_size;
         al.run(pair, slot, batch_traceback);
     }
+#ifdef BA_TIMING
+    if (bp.prof && is_lane(0)) atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 }  // namespace ba

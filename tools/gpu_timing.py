@@ -29,3 +29,6 @@ if prof[26]:
     print(f"  lane-iterations per walk={float(prof[21])/n:.0f}")
     wi = max(float(prof[22]), 1)
     print(f"  per walking iteration: rect entry + load issue={float(prof[27])/wi:.0f}  wait for loads={float(prof[28])/wi:.0f}  whole tb_step={float(prof[29])/wi:.0f} ticks")
+if prof[43]:
+    t0, tf, tw = float(prof[43]), float(prof[40]), float(prof[41])
+    print(f"wall clock (100 MHz counter): last fill wave done at {(tf-t0)/1e5:.2f} ms, last traceback wave done at {(tw-t0)/1e5:.2f} ms after launch start")
