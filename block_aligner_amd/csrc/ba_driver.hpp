@@ -291,16 +291,22 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
     }
 }
 
-__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
+// `nlanes` lanes of the wave take part. dedicated: a traceback wave proper. Otherwise a fill wave that found the work
+// counter exhausted: the batch ends with one full walk latency after the last fill, and a walk is a chain of ~2 500
+// dependent iterations whose length grows with the number of lanes walking in lockstep, so the last `tb_reserve`
+// hand-offs are left to these late helpers, one lane per wave on a SIMD that has nothing else left to do (the
+// dedicated waves stop claiming tickets once the ticket counter reaches that reserve).
+__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds, uint32_t nlanes, bool dedicated) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
-    int phase = IDLE;
+    int phase = (uint32_t)lane_id() < nlanes ? IDLE : RETIRED;
     uint32_t claimed = 0, pend = 0;
+    const uint32_t reserve_from = bp.n > bp.tb_reserve ? bp.n - bp.tb_reserve : 0u;
     TbLane t{};
     const uint32_t eq = bp.flags & flag_mask;   // mode bits the walk looks at: CIGAR_EQ, LOCAL_START, FREE_QUERY_START_GAPS
     uint32_t* head = bp.tb_ctrl + 32;
     // this lane's LDS record and the move table (scan_block.rs:1532-1558), two entries built per lane
-    unsigned char* lrec = tb_lds + (uint32_t)lane_id() * TB_LANE_BYTES;
-    unsigned char* lut = tb_lds + TB_LUT_OFFSET;
+    unsigned char* lut = tb_lds;
+    unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * TB_LANE_BYTES;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const uint32_t idx = (uint32_t)lane_id() + 64u * e;
@@ -322,8 +328,12 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
         c_iters++; c_walk_lanes += __popcll(__ballot(phase == WALK)); c_walk_iters += any_walk; c_poll_iters += __any(phase == WAIT);
 #endif
         if (phase == IDLE) {
-            claimed = __hip_atomic_fetch_add(head, 1u, BA_RLX_AGENT);
-            phase = claimed >= bp.n ? RETIRED : WAIT;     // every pair yields exactly one task
+            // (a dedicated lane looks before it claims: a ticket, once taken, has to be served by this lane)
+            if (dedicated && __hip_atomic_load(head, BA_RLX_AGENT) >= reserve_from) phase = RETIRED;
+            else {
+                claimed = __hip_atomic_fetch_add(head, 1u, BA_RLX_AGENT);
+                phase = claimed >= bp.n ? RETIRED : WAIT;     // every pair yields exactly one task
+            }
             pend = 0;
         }
         // `pend` = this lane's ring entry as read at the END of the previous iteration: the poll's round trip to L2
@@ -378,7 +388,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
         if (!__any(phase == WALK)) __builtin_amdgcn_s_sleep(32);               // nothing to walk: poll gently
     }
 #ifdef BA_TIMING
-    if (bp.prof && is_lane(0)) {
+    if (bp.prof && dedicated && is_lane(0)) {
         atomicAdd(bp.prof + 20, c_iters); atomicAdd(bp.prof + 21, c_walk_lanes); atomicAdd(bp.prof + 22, c_walk_iters);
         atomicAdd(bp.prof + 23, c_poll_iters); atomicAdd(bp.prof + 24, c_walk_ticks);
         atomicAdd(bp.prof + 25, __builtin_amdgcn_s_memtime() - c_t0); atomicAdd(bp.prof + 26, 1ull);
@@ -861,56 +871,66 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_ali
         }
         fc.vconst = pk(v[0], v[1]);
     }
-    // Traceback waves are spread over the chip (wave 0 of every tb_stride-th workgroup): a walk is all divergent
-    // loads, and eight of them on one CU would queue behind that CU's single memory pipeline.
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
 #ifdef BA_TIMING
-    // wall-clock (100 MHz) marks: launch start, last fill wave done, last traceback wave done -> the length of the traceback tail
+    // wall-clock (100 MHz) marks: launch start, last fill wave done, last traceback done -> the length of the traceback tail
     if (bp.prof && blockIdx.x == 0 && wave == 1 && is_lane(0)) atomicMax(bp.prof + 43, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
-                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(PMAX * 128));
+                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(PMAX * 128), 64u, true);
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
         return;
     }
-    // dense index among the fill waves (consumer waves of this and earlier workgroups skipped)
-    const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
-    const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
-    uint32_t turn = 0;
-    for (;;) {
-        uint32_t pair = 0;
-        if (is_lane(0)) pair = atomicAdd(bp.work_counter, 1u);
-        pair = (uint32_t)uni((int)pair);
-        if (pair >= bp.n) break;
-        const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
-        if (++turn == bp.slots_per_wave) turn = 0;
-        Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
-        BA_TSTAMP(tw0);
-        const bool got_slot = !batch_traceback || al.acquire_slot(slot);
-        BA_TSTAMP(tw1);
+    {
+        // dense index among the fill waves (traceback waves of this and earlier workgroups skipped)
+        const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
+        const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
+        uint32_t turn = 0;
+        for (;;) {
+            uint32_t pair = 0;
+            if (is_lane(0)) pair = atomicAdd(bp.work_counter, 1u);
+            pair = (uint32_t)uni((int)pair);
+            if (pair >= bp.n) break;
+            const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
+            if (++turn == bp.slots_per_wave) turn = 0;
+            Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
+            BA_TSTAMP(tw0);
+            const bool got_slot = !batch_traceback || al.acquire_slot(slot);
+            BA_TSTAMP(tw1);
 #ifdef BA_TIMING
-        if (bp.prof && is_lane(0)) atomicAdd(bp.prof + 17, tw1 - tw0);
+            if (bp.prof && is_lane(0)) atomicAdd(bp.prof + 17, tw1 - tw0);
 #endif
-        if (!got_slot) {
-            // the traceback waves are not making progress: report instead of hanging. The pair still has to
-            // produce its queue entry so the consumers' task count stays exact.
-            al.status = ST_SLOT_TIMEOUT;
-            if (is_lane(0)) { bp.score[pair] = 0; bp.query_idx[pair] = 0; bp.reference_idx[pair] = 0; }
-            al.hand_off(slot, pair, 0, 0, true);
-            continue;
+            if (!got_slot) {
+                // the traceback waves are not making progress: report instead of hanging. The pair still has to
+                // produce its queue entry so the consumers' task count stays exact.
+                al.status = ST_SLOT_TIMEOUT;
+                if (is_lane(0)) { bp.score[pair] = 0; bp.query_idx[pair] = 0; bp.reference_idx[pair] = 0; }
+                al.hand_off(slot, pair, 0, 0, true);
+                continue;
+            }
+            al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
+            al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
+            al.ckpt = bp.ckpt + (uint64_t)fill_wave * 4 * bp.max_size;
+            al.run(pair, slot, batch_traceback);
         }
-        al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
-        al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
-        al.ckpt = bp.ckpt + (uint64_t)fill_wave * 4 * bp.max_size;
-        al.run(pair, slot, batch_traceback);
-    }
 #ifdef BA_TIMING
-    if (bp.prof && is_lane(0)) atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
+    }
+    // Traceback waves are spread over the chip (wave 0 of every tb_stride-th workgroup): a walk is all divergent
+    // loads, and eight of them on one CU would queue behind that CU's single memory pipeline. A fill wave joins with one
+    // lane once the batch has no pairs left for it; its record and move table go where its block borders were.
+    if (batch_traceback) {
+        lds_sync();
+        traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 1u, false);
+#ifdef BA_TIMING
+        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+    }
 }
 
 }  // namespace ba

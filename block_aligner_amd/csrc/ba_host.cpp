@@ -173,7 +173,7 @@ struct BaBatch {
     uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace, blocks, ckpt, counter,
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
-    uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1;
+    uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1, tb_reserve = 0;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false, in_flight = false;
     BatchParams params() const {
@@ -191,7 +191,7 @@ struct BaBatch {
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
         bp.ckpt = ckpt.as<short>();
-        bp.tb_stride = tb_stride; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots;
+        bp.tb_stride = tb_stride; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots; bp.tb_reserve = tb_reserve;
         bp.tb_qmask = tb_qsize - 1;
         bp.tb_queue = tb_queue.as<uint32_t>(); bp.tb_ctrl = tb_ctrl.as<uint32_t>();
         bp.slot_free = slot_free.as<uint32_t>(); bp.slot_info = slot_info.as<ba::SlotInfo>();
@@ -432,10 +432,17 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         b->slots_per_wave = spw;
+        // The last hand-offs of the batch go to fill waves that have run out of pairs (one walking lane per wave, on
+        // SIMDs with nothing else left to do): a walk alone is much shorter than one among 40 in lockstep, and the
+        // batch ends one walk after its last fill. Three quarters of the fill waves (measured at config 3: flat between
+        // 3000 and 3500 of 3968, 1 % slower at 2000 or 6000); fewer than all of them, so the fill waves can never all be
+        // waiting for trace slots whose walks are reserved for helpers that do not exist yet.
+        b->tb_reserve = b->n_fill_waves / 4 * 3;
+        if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
     }
     b->slots = b->n_fill_waves * b->slots_per_wave;
     {
-        const uint64_t lanes = b->tb_stride ? (uint64_t)((b->grid + b->tb_stride - 1) / b->tb_stride) * 64 : 0;
+        const uint64_t lanes = b->tb_stride ? (uint64_t)((b->grid + b->tb_stride - 1) / b->tb_stride) * 64 + b->n_fill_waves : 0;   // + one helper lane per fill wave
         uint64_t need_q = std::max<uint64_t>(lanes, b->slots);
         uint32_t qs = 1;
         while (qs < need_q) qs <<= 1;

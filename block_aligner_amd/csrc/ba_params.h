@@ -61,6 +61,7 @@ struct BatchParams {
     uint32_t tb_stride;          // 0: fill waves walk their own tracebacks. s > 0: wave 0 of every s-th workgroup walks tracebacks
     uint32_t slots_per_wave;     // trace arena slots owned by each fill wave (a slot is busy until its traceback is done)
     uint32_t n_slots;
+    uint32_t tb_reserve;         // the last tb_reserve hand-offs are left to fill waves that ran out of pairs (one lane each: see traceback_consumer)
     uint32_t tb_qmask;           // ring size - 1 (power of two >= max(traceback lanes, n_slots): live claims never share a position)
     uint32_t* tb_queue;          // ring entries: slot + 1, or 0x80000000 | pair for a pair without a trace stack; 0 = empty
     uint32_t* tb_ctrl;           // [0] tail (next entry to produce), [32] head (next entry to claim); separate cache lines
@@ -80,6 +81,7 @@ BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ?
 BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
 // TRACE batches: one more region behind the waves' for the workgroup's traceback wave (ba_driver.hpp tb_step): per lane
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
-constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_OFFSET = 64 * TB_LANE_BYTES, TB_LDS_BYTES = 5120;
+constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;   // table first, then the records (a helper fill wave uses one)
+static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES <= lds_wave_bytes_h(128), "traceback LDS regions");
 
 }  // namespace ba
