@@ -438,6 +438,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         // 3000 and 3500 of 3968, 1 % slower at 2000 or 6000); fewer than all of them, so the fill waves can never all be
         // waiting for trace slots whose walks are reserved for helpers that do not exist yet.
         b->tb_reserve = b->n_fill_waves / 4 * 3;
+        // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
+        // less of the batch to walkers that only exist once the first wave has run out of pairs
+        if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
         if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
     }
     b->slots = b->n_fill_waves * b->slots_per_wave;
