@@ -33,6 +33,8 @@ using ba::BlockRec;
 BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_pack_sequences(hipStream_t, int, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint32_t*,
+                                               const uint64_t*, const uint32_t*, uint8_t*, uint32_t, uint32_t, unsigned long long*);
 
 typedef hipError_t (*LaunchFn)(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
 typedef hipError_t (*OccFn)(int, int, unsigned, int*);
@@ -254,6 +256,11 @@ struct Packed {   // host-side packing of a set of pairs: padded images + the pe
     std::vector<uint32_t> ql, rl;
     std::vector<uint8_t> image;
     uint64_t total = 0, maxlen2 = 0, cig_total = 0;
+    // Sequences that come out of one contiguous host buffer are not padded on the host: the raw bytes [raw, raw + raw_bytes)
+    // go to the device as they are and k_pack_sequences builds the images there (raw_qo / raw_ro: offsets into raw).
+    bool on_device = false;
+    const uint8_t* raw = nullptr; uint64_t raw_bytes = 0; uint32_t pad = 0;
+    std::vector<uint64_t> raw_qo, raw_ro;
 };
 template <class GetSeq, class GetProfile, class Lap>
 static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uint32_t mode, size_t n, bool already_converted,
@@ -268,10 +275,17 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
     uint64_t total = 0, maxlen2 = 0, cig_total = 0;
     std::vector<uint64_t>& cig_off = P.cig_off;
     cig_off.resize(n + 1);
+    const uint8_t* lo = nullptr; const uint8_t* hi = nullptr; uint64_t sum_len = 0;   // extent of the caller's bytes
+    auto span = [&](const uint8_t* ptr, size_t len) {
+        if (!lo || ptr < lo) lo = ptr;
+        if (!hi || ptr + len > hi) hi = ptr + len;
+        sum_len += len;
+    };
     for (size_t p = 0; p < n; p++) {
         const uint8_t* ptr; size_t len;
         get(p, 0, &ptr, &len);
         if (len > 0x3fffffffu) { fail("sequence too long"); return 1; }
+        span(ptr, len);
         ql[p] = (uint32_t)len; qo[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;   // images start 4-byte aligned
         if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > len)) {   // scan_block.rs:860-862
             fail("pair %zu: Min block size must be larger than the query length for FREE_QUERY_END_GAPS!", p); return 1;
@@ -286,6 +300,7 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
         } else {
             get(p, 1, &ptr, &len);
             if (len > 0x3fffffffu) { fail("sequence too long"); return 1; }
+            span(ptr, len);
             rl[p] = (uint32_t)len; ro[p] = total; total += (1 + len + pad + 3) & ~(size_t)3;
         }
         maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
@@ -295,6 +310,20 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
     cig_off[n] = cig_total;
     total += 64;
     lap("offsets");
+    P.total = total; P.maxlen2 = maxlen2; P.cig_total = cig_total; P.pad = (uint32_t)pad;
+    // One dense host buffer (the pooled batch calls): ship it as it is, pad and convert on the device. Scattered or
+    // overlapping sources (PaddedBytes handles, a reference shared by many pairs) and profile batches are packed here.
+    if (!profile && !already_converted && n >= 256 && n < (1u << 30) && (uint64_t)(hi - lo) <= 2 * sum_len + 4096 && !getenv("BA_HOST_PACK")) {
+        P.on_device = true; P.raw = lo; P.raw_bytes = (uint64_t)(hi - lo);
+        P.raw_qo.resize(n); P.raw_ro.resize(n);
+        for (size_t p = 0; p < n; p++) {
+            const uint8_t* ptr; size_t len;
+            get(p, 0, &ptr, &len); P.raw_qo[p] = (uint64_t)(ptr - lo);
+            get(p, 1, &ptr, &len); P.raw_ro[p] = (uint64_t)(ptr - lo);
+        }
+        lap("raw offsets");
+        return 0;
+    }
     std::vector<uint8_t>& image = P.image;
     image.assign(total, null_byte(kind));
     lap("image allocation + padding");
@@ -327,6 +356,26 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
     }
     lap("image fill");
     P.total = total; P.maxlen2 = maxlen2; P.cig_total = cig_total;
+    return 0;
+}
+
+// Sequence images into b->pool; the per-pair offset / length arrays must already be on the device.
+static int upload_images(BaBatch* b, const Packed& P, size_t n) {
+    if (!P.on_device) { HIP_TRY(hipMemcpy(b->pool.p, P.image.data(), P.total, hipMemcpyHostToDevice)); return 0; }
+    DevBuf raw, raw_q, raw_r, err;
+    if (raw.alloc(P.raw_bytes) || raw_q.alloc(n * 8) || raw_r.alloc(n * 8) || err.alloc(8)) return 1;
+    HIP_TRY(hipMemcpy(raw.p, P.raw, P.raw_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(raw_q.p, P.raw_qo.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(raw_r.p, P.raw_ro.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(err.p, 0xff, 8));
+    HIP_TRY(hipMemset((uint8_t*)b->pool.p + P.total - 64, null_byte(b->kind), 64));   // slack behind the last image
+    HIP_TRY(ba_launch_pack_sequences(b->stream, seq_kind(b->kind), raw.as<uint8_t>(), raw_q.as<uint64_t>(), raw_r.as<uint64_t>(),
+                                     b->q_off.as<uint64_t>(), b->q_len.as<uint32_t>(), b->r_off.as<uint64_t>(), b->r_len.as<uint32_t>(),
+                                     b->pool.as<uint8_t>(), P.pad, (uint32_t)n, err.as<unsigned long long>()));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    unsigned long long e = 0;
+    HIP_TRY(hipMemcpy(&e, err.p, 8, hipMemcpyDeviceToHost));
+    if (e != ~0ull) return fail("pair %llu: byte 0x%02x is outside the matrix alphabet", e >> 8, (unsigned)(e & 0xff));
     return 0;
 }
 
@@ -364,7 +413,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     Packed P;
     if (pack_pairs(kind, gaps, min_size, max_size, mode, n, already_converted, get, getp, P, lap)) return nullptr;
     std::vector<uint64_t>& qo = P.qo; std::vector<uint64_t>& ro = P.ro; std::vector<uint32_t>& ql = P.ql; std::vector<uint32_t>& rl = P.rl;
-    std::vector<uint64_t>& cig_off = P.cig_off; std::vector<uint8_t>& image = P.image;
+    std::vector<uint64_t>& cig_off = P.cig_off;
     const uint64_t total = P.total, maxlen2 = P.maxlen2, cig_total = P.cig_total;
     b->h_q_off = qo; b->h_r_off = ro;
     b->cap_n = n; b->cap_pool = total; b->cap_cig = cig_total; b->cap_maxlen2 = maxlen2;
@@ -468,8 +517,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
 #undef BA_ALLOC
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
-    BA_H2D(pool, image.data(), total); BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
+    BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
     BA_H2D(r_off, ro.data(), n * 8); BA_H2D(r_len, rl.data(), n * 4); BA_H2D(cig_off, cig_off.data(), (n + 1) * 8);
+    if (upload_images(b.get(), P, n)) return nullptr;
     {
         int8_t tmp[1024] = {0};
         if (kind == BA_KIND_BYTES) { const ByteMatrix* bm = (const ByteMatrix*)matrix; tmp[0] = bm->match_score; tmp[1] = bm->mismatch_score; }
@@ -496,11 +546,11 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     if (P.total > b->cap_pool) return fail("reload: %llu sequence bytes exceed the batch's capacity of %llu", (unsigned long long)P.total, (unsigned long long)b->cap_pool);
     if (P.maxlen2 > b->cap_maxlen2) return fail("reload: a pair is longer (%llu) than the longest pair the batch was created with (%llu)", (unsigned long long)P.maxlen2 - 2, (unsigned long long)b->cap_maxlen2 - 2);
     if ((b->mode & BA_TRACE) && P.cig_total > b->cap_cig) return fail("reload: CIGAR capacity exceeded");
-    HIP_TRY(hipMemcpy(b->pool.p, P.image.data(), P.total, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->q_off.p, P.qo.data(), n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->q_len.p, P.ql.data(), n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->r_off.p, P.ro.data(), n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->r_len.p, P.rl.data(), n * 4, hipMemcpyHostToDevice));
+    if (upload_images(b, P, n)) return 1;
     HIP_TRY(hipMemcpy(b->cig_off.p, P.cig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->cig_len.p, 0, n * 4));
     HIP_TRY(hipMemset(b->status.p, 0, n * 4));

@@ -80,6 +80,47 @@ extern "C" hipError_t ba_launch_compact_cigars(hipStream_t s, const uint32_t* op
     k_compact_cigars<<<dim3(grid), dim3(256), 0, s>>>(ops, cig_off, cig_len, out_off, out, n);
     return hipGetLastError();
 }
+// PaddedBytes images on the device (scan_block.rs:1798-1850: [NULL] + convert(bytes) + NULL padding; convert_char of
+// scores.rs:130-134 / 212-216 / 270-272): one workgroup per sequence, four image bytes per thread and store. A byte the
+// reference would assert on is reported through *err (lowest pair wins): pair << 8 | byte.
+__global__ void __launch_bounds__(256) k_pack_sequences(int kind, const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_q,
+                                                        const uint64_t* __restrict__ raw_r, const uint64_t* __restrict__ q_off,
+                                                        const uint32_t* __restrict__ q_len, const uint64_t* __restrict__ r_off,
+                                                        const uint32_t* __restrict__ r_len, uint8_t* __restrict__ image, uint32_t pad,
+                                                        unsigned long long* err) {
+    const uint32_t p = blockIdx.x >> 1;
+    const bool ref = blockIdx.x & 1;
+    const uint8_t* src = raw + (ref ? raw_r[p] : raw_q[p]);
+    const uint32_t len = ref ? r_len[p] : q_len[p];
+    uint32_t* dst = (uint32_t*)(image + (ref ? r_off[p] : q_off[p]));   // images start 4-byte aligned
+    const uint32_t null_b = kind == ba::KIND_AA ? 26u : (kind == ba::KIND_NUC ? (uint32_t)'Z' : 0u);
+    const uint32_t words = ((1u + len + pad + 3u) & ~3u) / 4u;
+    for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) {
+        uint32_t wd = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t pos = 4 * k + b;
+            uint32_t c = null_b;
+            if (pos >= 1 && pos <= len) {
+                c = src[pos - 1];
+                if (kind != ba::KIND_BYTES) {
+                    if (c >= 'a' && c <= 'z') c -= 32;
+                    const bool ok = kind == ba::KIND_AA ? (c >= 'A' && c <= 'A' + 26) : (c >= 'A' && c <= 'Z');
+                    if (!ok) { atomicMin(err, ((unsigned long long)p << 8) | src[pos - 1]); c = null_b; }
+                    else if (kind == ba::KIND_AA) c -= 'A';
+                }
+            }
+            wd |= c << (8 * b);
+        }
+        dst[k] = wd;
+    }
+}
+extern "C" hipError_t ba_launch_pack_sequences(hipStream_t s, int kind, const uint8_t* raw, const uint64_t* raw_q, const uint64_t* raw_r,
+                                               const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len,
+                                               uint8_t* image, uint32_t pad, uint32_t n, unsigned long long* err) {
+    k_pack_sequences<<<dim3(2 * n), dim3(256), 0, s>>>(kind, raw, raw_q, raw_r, q_off, q_len, r_off, r_len, image, pad, err);
+    return hipGetLastError();
+}
 extern "C" hipError_t ba_launch_traceback(hipStream_t s, const ba::BatchParams* bp) {
     k_traceback<<<dim3(1), dim3(64), 0, s>>>(*bp);
     return hipGetLastError();

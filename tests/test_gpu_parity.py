@@ -403,6 +403,48 @@ def test_profile_traceback_lanes_and_exp(hip, oracle, monkeypatch):
         assert (int(sc[k]), int(qi[k]), int(ri[k]), int(reached[k]) or None) == (r["score"], r["query_idx"], r["reference_idx"], got), k
 
 
+def test_device_side_packing(hip, oracle, monkeypatch):
+    """Pooled batches of 256+ pairs are padded and converted on the device (k_pack_sequences); the images must equal the
+    host packer's (BA_HOST_PACK=1): same results on mixed-case input, same error for a byte outside the alphabet."""
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    for matrix, alphabet, gaps in ((NUC, synth.DNA, (-5, -1)), (S.BLOSUM62, synth.AMINO, (-11, -1))):
+        pairs = synth.make_pairs(700, (0, 900), (0, 60), 25, alphabet, seed=91)
+        pool = pairs.pool.copy()
+        lower = np.random.default_rng(5).random(pool.size) < 0.3
+        pool[lower] = pool[lower] | 0x20          # lower case: convert_char upper-cases (scores.rs:130-134, 212-216)
+        out = []
+        for host in ("0", "1"):
+            if host == "1":
+                monkeypatch.setenv("BA_HOST_PACK", "1")
+            else:
+                monkeypatch.delenv("BA_HOST_PACK", raising=False)
+            b = hip.BatchAligner(matrix, gaps, (32, 128), 50, mode, pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+            b.run()
+            res = b.results()
+            runs, off = b.cigars(res["cigar_len"])
+            out.append((res, runs, off))
+            if host == "0":   # a reload goes the same way
+                nxt = synth.make_pairs(300, (10, 500), (0, 30), 10, alphabet, seed=92)
+                b.reload(nxt.pool, nxt.q_off, nxt.q_len, nxt.r_off, nxt.r_len)
+                b.run()
+                r2 = b.results()
+                ref2 = oracle.batch_align(matrix, nxt.pool, nxt.q_off, nxt.q_len, nxt.r_off, nxt.r_len, gaps, (32, 128), 50, ("trace", "x_drop"), cigar_eq=True, threads=8)
+                assert np.array_equal(r2["score"], ref2["scores"]) and np.array_equal(r2["cigar_len"], ref2["cig_len"])
+            b.close()
+        monkeypatch.delenv("BA_HOST_PACK", raising=False)
+        (ra, runs_a, off_a), (rb, runs_b, off_b) = out
+        for k in ("score", "query_idx", "reference_idx", "cigar_len", "status"):
+            assert np.array_equal(ra[k], rb[k]), k
+        assert np.array_equal(runs_a, runs_b) and np.array_equal(off_a, off_b)
+        ref = oracle.batch_align(matrix, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, gaps, (32, 128), 50, ("trace", "x_drop"), cigar_eq=True, threads=8)
+        assert np.array_equal(ra["score"], ref["scores"]) and np.array_equal(ra["cigar_len"], ref["cig_len"])
+        bad = pairs.pool.copy()
+        bad[int(pairs.r_off[400]) + 2] = ord("!")
+        assert int(pairs.r_len[400]) > 2
+        with pytest.raises(RuntimeError, match="pair 400: byte 0x21 is outside the matrix alphabet"):
+            hip.BatchAligner(matrix, gaps, (32, 128), 50, mode, bad, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+
+
 def test_batch_api_errors_and_coexisting_batches(hip, oracle):
     """Argument errors come back as errors (never aborts, never a silent fallback); two TRACE batches alive at once share
     the device memory that is left."""
