@@ -823,8 +823,11 @@ struct Aligner {
 
 // Persistent kernel: WAVES_PER_WG independent waves per workgroup (they share only the read-only score table in LDS);
 // every wave pulls pair indices from a global counter until the batch is exhausted.
+// Waves per SIMD (second launch bound): 4 at 128 VGPRs for blocks up to 1024 cells (their columns live in registers), 2 for
+// 2048; the kernels for blocks up to 256 cells need ~95 and are held to 80 for 6 waves (a few spills outside the
+// columns; measured +13 % on the 1 kbp DNA and protein configurations; 64 registers / 8 waves spills into the columns).
 template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL>
-__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_align(const BatchParams bp) {
+__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 2 ? 6 : 4))) k_align(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id();
     const int wave = uni((int)threadIdx.x >> 6);   // wave-uniform: keeps every per-wave pointer (LDS borders, trace slot) in SGPRs
