@@ -165,7 +165,8 @@ uintptr_t block_trace_blocks_generic(BlockHandle b, struct Rectangle* out, uintp
 /* ---- batch launcher: many independent pairs, one persistent kernel launch, one wavefront per pair.
  *
  * `pool` holds the raw (unpadded, unconverted) sequence bytes; pair p is query pool[q_off[p] .. +q_len[p]) against
- * reference pool[r_off[p] .. +r_len[p]). The library builds the PaddedBytes images (scan_block.rs:1798-1812) and keeps
+ * reference pool[r_off[p] .. +r_len[p]). The library builds the PaddedBytes images (scan_block.rs:1798-1812: convert_char,
+ * NULL pads; on the device when the pairs come out of one dense buffer, a byte outside the alphabet is an error) and keeps
  * them, the matrix and all scratch resident in device memory for the life of the batch object, so ba_batch_run can
  * be timed with inputs already in HBM.
  *
