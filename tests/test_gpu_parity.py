@@ -403,6 +403,30 @@ def test_profile_traceback_lanes_and_exp(hip, oracle, monkeypatch):
         assert (int(sc[k]), int(qi[k]), int(ri[k]), int(reached[k]) or None) == (r["score"], r["query_idx"], r["reference_idx"], got), k
 
 
+def test_longest_first_order_is_invisible(hip, oracle, monkeypatch):
+    """The library hands the pairs to the waves longest first (ba_host.cpp Packed::order); scores, end positions, cells,
+    CIGAR lengths and the CIGAR runs come back in the caller's order, identical to a batch kept in the caller's order."""
+    pairs = synth.make_pairs(500, (0, 3000), (0, 150), 40, synth.DNA, seed=123)
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    out = []
+    for keep in (False, True):
+        if keep:
+            monkeypatch.setenv("BA_CALLER_ORDER", "1")
+        else:
+            monkeypatch.delenv("BA_CALLER_ORDER", raising=False)
+        b = hip.BatchAligner(NUC, (-5, -1), (32, 256), 80, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        b.run()
+        res = b.results()
+        out.append((res,) + tuple(b.cigars(res["cigar_len"])))
+        b.close()
+    monkeypatch.delenv("BA_CALLER_ORDER", raising=False)
+    for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"):
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 256), 80, ("trace", "x_drop"), cigar_eq=True, threads=8)
+    assert np.array_equal(out[0][0]["score"], ref["scores"]) and np.array_equal(out[0][0]["cigar_len"], ref["cig_len"])
+
+
 def test_device_side_packing(hip, oracle, monkeypatch):
     """Pooled batches of 256+ pairs are padded and converted on the device (k_pack_sequences); the images must equal the
     host packer's (BA_HOST_PACK=1): same results on mixed-case input, same error for a byte outside the alphabet."""
@@ -450,7 +474,7 @@ def test_batch_api_errors_and_coexisting_batches(hip, oracle):
     the device memory that is left."""
     good = synth.make_pairs(64, (100, 600), (0, 40), 10, synth.DNA, seed=8)
     args = (good.pool, good.q_off, good.q_len, good.r_off, good.r_len)
-    with pytest.raises(RuntimeError, match="alphabet"):
+    with pytest.raises(RuntimeError, match="pair 3: byte 0x21 is outside the matrix alphabet"):   # (the caller's pair index)
         bad = good.pool.copy(); bad[int(good.q_off[3]) + 1] = ord("!")
         hip.BatchAligner(NUC, (-5, -1), (32, 64), 0, 0, bad, *args[1:])
     with pytest.raises(RuntimeError, match="negative"):
