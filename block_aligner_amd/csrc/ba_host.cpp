@@ -577,6 +577,8 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     if (P.total > b->cap_pool) return fail("reload: %llu sequence bytes exceed the batch's capacity of %llu", (unsigned long long)P.total, (unsigned long long)b->cap_pool);
     if (P.maxlen2 > b->cap_maxlen2) return fail("reload: a pair is longer (%llu) than the longest pair the batch was created with (%llu)", (unsigned long long)P.maxlen2 - 2, (unsigned long long)b->cap_maxlen2 - 2);
     if ((b->mode & BA_TRACE) && P.cig_total > b->cap_cig) return fail("reload: CIGAR capacity exceeded");
+    // from here on the device arrays change: a failure leaves no pairs loaded (a later launch says so) instead of a mix
+    b->n = 0; b->ran = false;
     HIP_TRY(hipMemcpy(b->q_off.p, P.qo.data(), n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->q_len.p, P.ql.data(), n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->r_off.p, P.ro.data(), n * 8, hipMemcpyHostToDevice));
@@ -594,6 +596,8 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
 // Enqueue one pass over the batch on its stream and return; batch_wait collects it. (Two batches on two streams
 // overlap; with ba_batch_reload the host packs the next set while the device aligns the current one.)
 static int batch_launch(BaBatch* b) {
+    if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");
+    if (b->n == 0) return fail("the batch holds no pairs (its last reload failed)");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
     HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));

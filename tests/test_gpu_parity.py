@@ -467,6 +467,16 @@ def test_device_side_packing(hip, oracle, monkeypatch):
         assert int(pairs.r_len[400]) > 2
         with pytest.raises(RuntimeError, match="pair 400: byte 0x21 is outside the matrix alphabet"):
             hip.BatchAligner(matrix, gaps, (32, 128), 50, mode, bad, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        # a reload that fails half way leaves the batch empty, not half updated
+        b = hip.BatchAligner(matrix, gaps, (32, 128), 50, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        with pytest.raises(RuntimeError, match="pair 400"):
+            b.reload(bad, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        with pytest.raises(RuntimeError, match="holds no pairs"):
+            b.run()
+        b.reload(pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        b.run()
+        assert np.array_equal(b.results()["score"], ref["scores"])
+        b.close()
 
 
 def test_batch_api_errors_and_coexisting_batches(hip, oracle):
