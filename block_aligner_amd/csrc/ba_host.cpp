@@ -508,7 +508,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         (void)hipMemGetInfo(&free_b, &total_b);
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
-        uint32_t spw = 3;   // one being filled + two pending walks per fill wave, HBM permitting (142 GB at config 3)
+        uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
         if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         b->slots_per_wave = spw;
