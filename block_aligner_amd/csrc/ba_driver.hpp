@@ -183,8 +183,13 @@ __device__ __forceinline__ void tb_fail(TbLane& t) { t.status |= ST_TRACEBACK_LO
 
 // One iteration of scan_block.rs:1576-1670 for one lane: move to the rectangle that holds the current cell if needed,
 // bring the trace words around the cell (and the sequence bytes below it) into this lane's LDS record -- at most one
-// round of global-memory latency per call -- then walk up to 12 cells out of LDS: one byte read for the cell's trace
+// round of global-memory latency per call -- then walk up to TB_CELLS_PER_STEP cells out of LDS: one byte read for the cell's trace
 // bits, one for the move (OP_LUT of scan_block.rs:1532-1558 as a 128-entry table), two for the =/X comparison.
+// The lanes of a traceback wave walk in lockstep, so a call costs what its longest-walking lane costs. A path crosses a
+// rectangle in at most 8 diagonal cells (4 on average), and the wave's instruction stream -- not memory latency -- is
+// what a walk costs the fill waves it shares a SIMD with: measured at config 3, 12 cells per call 1142 GCUPS, 8: 1145,
+// 6: 1154, 4: 1156, 3: 1154 (more calls per walk, each much shorter).
+constexpr int TB_CELLS_PER_STEP = 4;
 __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned char* lrec,
                                         const unsigned char* lut, unsigned long long* tacc = nullptr) {
     const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
@@ -253,7 +258,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
     if (tacc) { tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; }
 #endif
-    for (int s = 0; s < 12; s++) {
+    for (int s = 0; s < TB_CELLS_PER_STEP; s++) {
         if (!(t.i > 0 || t.j > 0) || !(t.i >= t.bi && t.j >= t.bj)) break;
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
         const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
