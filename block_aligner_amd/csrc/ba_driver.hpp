@@ -258,6 +258,48 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
     if (tacc) { tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; }
 #endif
+    if (!local) {
+        // Straight-line, predicated: the lanes of the wave are at different places of different walks, so every `break`
+        // of the plain loop below is an exec-mask region that all of them pay for (it had ~15 per cell). `alive` = this
+        // lane still walks in this call; a lane that is not alive computes on clamped indices and commits nothing.
+        bool alive = true;
+#pragma unroll
+        for (int s = 0; s < TB_CELLS_PER_STEP; s++) {
+            alive = alive && (t.i > 0 || t.j > 0) && t.i >= t.bi && t.j >= t.bj;
+            const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
+            const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
+            const uint32_t lc = (v & 127) >> 1;
+            if (fqs) {                                                                      // scan_block.rs:1597-1599
+                const bool stop = alive && t.right && t.i == 0;
+                if (stop) t.i = t.j = 0;
+                alive = alive && !stop;
+            }
+            const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
+            alive = alive && (v >> 7) == t.tw_chunk && gi <= 1u && k <= 4u;                 // else: left the window, the next call reloads it
+            const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
+            const uint32_t byte = lrec[alive ? gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1) : 0u];
+            const uint32_t qb = lrec[40 + (qo & 15u)], rb = lrec[56 + (ro & 15u)];          // for a match at this cell (read alongside, used if needed)
+            const uint32_t nib = ((byte >> ((w & 1) * 4)) ^ 7u) & 15u;                      // bits 0-2 "differs", bit 3 "equal"
+            const uint32_t table = tb_resolve(t.right, t.table, nib);
+            const uint32_t m = lut[((uint32_t)t.right << 6) | (table << 4) | nib];          // op | di << 3 | dj << 4 | next << 5
+            uint32_t op = m & 7u;
+            const uint32_t di = (m >> 3) & 1u, dj = (m >> 4) & 1u;
+            const bool is_match = eq && op == 1;
+            alive = alive && !(is_match && (qo > 15u || ro > 15u));                         // the next call refills the sequence windows
+            if (is_match) op = qb == rb ? 2u : 3u;
+            if (alive && (di > t.i || dj > t.j)) { tb_fail(t); alive = false; }             // would leave the matrix: corrupt trace
+            const bool same = op == t.run_op;
+            if (alive && !same && t.run_len) {                                              // the run ends: the one store of the walk
+                if (t.wp == t.lo) { t.status |= ST_CIGAR_OVERFLOW; t.i = t.j = 0; alive = false; }
+                else out[--t.wp] = (t.run_len << 4) | t.run_op;
+            }
+            t.i -= alive ? di : 0u; t.j -= alive ? dj : 0u;
+            t.table = alive ? tb_next(t.right, m >> 5, v) : t.table;
+            t.run_len = alive ? (same ? t.run_len + 1 : 1u) : t.run_len;
+            t.run_op = alive ? op : t.run_op;
+        }
+        return;
+    }
     for (int s = 0; s < TB_CELLS_PER_STEP; s++) {
         if (!(t.i > 0 || t.j > 0) || !(t.i >= t.bi && t.j >= t.bj)) break;
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
