@@ -104,13 +104,15 @@ __device__ __forceinline__ int vmaxu(int a, int b) {
 // compiler canonicalises umin(a - b, 1) into compare/select/permute sequences that cost five issue slots.
 __device__ __forceinline__ int neq01(int a, int b, int ones) {
     int t;
-    asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, %3" : "=&v"(t) : "v"(a), "v"(b), "s"(ones));
+    (void)ones;   // the 1 is an inline constant read through op_sel_hi (both halves take its low half): no SGPR
+    asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(t) : "v"(a), "v"(b));
     return t;
 }
 // per 16-bit half: 1 where a == b, else 0 (sub, then saturating 1 - diff)
 __device__ __forceinline__ int eq01(int a, int b, int ones) {
     int t;
-    asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, %3, %0 clamp" : "=&v"(t) : "v"(a), "v"(b), "s"(ones));
+    (void)ones;
+    asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, 1, %0 op_sel_hi:[0,1] clamp" : "=&v"(t) : "v"(a), "v"(b));
     return t;
 }
 __device__ __forceinline__ int pk_mul(int a, int m) {
@@ -122,6 +124,14 @@ __device__ __forceinline__ int pk_mul(int a, int m) {
 __device__ __forceinline__ int pk_mad(int a, int m, int c) {
     int t;
     asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(t) : "v"(a), "s"(m), "v"(c));
+    return t;
+}
+// per half: a * M + c (mod 2^16) for a small compile-time M: an inline constant instead of a wave-uniform register
+template <int M>
+__device__ __forceinline__ int pk_mad_k(int a, int c) {
+    static_assert(M >= 0 && M <= 64, "inline integer constant");
+    int t;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "n"(M), "v"(c));
     return t;
 }
 __device__ __forceinline__ int clamp16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
@@ -412,9 +422,9 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 // "R opened" (R == D_open) is stored with the cell it was computed in; the reference shifts it to the cell
                 // below (scan_block.rs:1179-1182) -- the traceback resolves it at the destination of the gap move instead,
                 // which saves the lane shift here and the carry between chunks
-                int nib = pk_mad(nR, 0x00020002, nC);
-                nib = pk_mad(nCo, 0x00040004, nib);
-                nib = pk_mad(eRo, 0x00080008, nib);
+                int nib = pk_mad_k<2>(nR, nC);
+                nib = pk_mad_k<4>(nCo, nib);
+                nib = pk_mad_k<8>(eRo, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
                 if (!FAST && (sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
                     trace_out[zwords + (j * NCH + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);
