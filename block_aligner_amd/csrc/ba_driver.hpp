@@ -507,7 +507,7 @@ struct Aligner {
         // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
         const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 5u : 1u);
         if ((uint64_t)trace_top + words + 64 > coldp()->trace_stride) { status |= ST_TRACE_OVERFLOW; return; }   // (64 words of slack stay free: see the host's trace_stride)
-        if (is_lane(0)) {
+        {   // every lane stores the same 16 bytes to the same address (one transaction): no exec-mask region per step
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
             blocks[nblocks] = br;
