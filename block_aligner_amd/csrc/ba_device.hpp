@@ -221,7 +221,7 @@ __device__ __forceinline__ int load_pair_i16(const short* p) { int v; __builtin_
 // height / 2 lanes are active. width is a multiple of 8.
 // PDIR (KIND_PROFILE only): 1 = vectors along the query, one profile position per column (place_block_profile_right,
 // scan_block.rs:612-783 with $right = true); 2 = vectors along the profile, one query residue per column.
-template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false, int PDIR = 0>
+template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false, int PDIR = 0, bool FULL128 = false>
 __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
@@ -232,8 +232,11 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     static_assert(!FAST || NCH == 1, "the fast path handles single-chunk steps");
     static_assert((KIND == KIND_PROFILE) == (PDIR != 0) && !(FAST && PDIR), "profile rectangles take the generic path with a direction");
     const int lane = lane_id();
-    const int nl = NCH > 1 ? 64 : (int)(height >> 1);   // active lanes
-    const bool active = lane < nl;
+    // FULL128 (fast path only): the step is exactly 128 cells high, so all 64 lanes hold cells and the lane count, the
+    // activity tests and the trace indices are compile-time
+    static_assert(!FULL128 || (FAST && NCH == 1), "FULL128 is a variant of the fast path");
+    const int nl = (NCH > 1 || FULL128) ? 64 : (int)(height >> 1);   // active lanes
+    const bool active = FULL128 ? true : lane < nl;
     Best res{0, 0, 0};                                   // MIN = 0 (avx2.rs:16)
     if (width == 0 || height == 0) return res;
 

@@ -700,8 +700,10 @@ struct Aligner {
                     // entries 160.. of the active border array are beyond any block the fast path handles (<= 128 + 16) and
                     // are rewritten by a grow before anything reads them; the array has them from the 256-cell class on
                     fs.sink = PMAX >= 2 ? Dc + 160 : nullptr;
-                    cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
-                                                                  off_add, tout, cells, &fs, prof);
+                    if (rh == 128) cur = place_rect<1, KIND, TRACE, XDROP, true, 0, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
+                                                                                           off_add, tout, cells, &fs, prof);
+                    else cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
+                                                                       off_add, tout, cells, &fs, prof);
                     prefetch_seq(si, sj, block_size);   // for the next step, behind this step's stores
                 }
             }
