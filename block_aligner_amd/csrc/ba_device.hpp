@@ -238,7 +238,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     const int nl = (NCH > 1 || FULL128) ? 64 : (int)(height >> 1);   // active lanes
     const bool active = FULL128 ? true : lane < nl;
     Best res{0, 0, 0};                                   // MIN = 0 (avx2.rs:16)
-    if (width == 0 || height == 0) return res;
+    if (!FAST && (width == 0 || height == 0)) return res;   // (a shift step is 8 x block)
 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -382,7 +382,8 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         }
         // cell (0,0) -- or, with free query start gaps, every cell of row 0 -- starts from the relative zero
         // (scan_block.rs:1130-1136)
-        const bool first_cell = (j == 0 && start_i == 0 && start_j == 0 && !(sp & SP_LOCAL)) || ((sp & SP_FQS_ROW0) && start_i == 0);
+        // (never in a fast step: a shift step's rectangle starts block - 8 > 0 cells along the step's direction)
+        const bool first_cell = !FAST && ((j == 0 && start_i == 0 && start_j == 0 && !(sp & SP_LOCAL)) || ((sp & SP_FQS_ROW0) && start_i == 0));
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
@@ -392,7 +393,8 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         for (int ch = 0; ch < NCH; ch++) {
             // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
             int prev = wave_shr1_z(d[ch]);
-            if (up_d != 0) prev = set_lane0(prev, up_d);
+            // (fast step: only column 0 has a cell above the chunk, and writing its 0 when there is none is what the shift left there)
+            if (FAST ? j == 0 : up_d != 0) prev = set_lane0(prev, up_d);
             if (NCH > 1) up_d = __builtin_amdgcn_readlane(d[ch], 63);
             const int d00 = __builtin_amdgcn_alignbit(d[ch], prev, 16);
             int d11 = adds(d00, sc[ch]);
