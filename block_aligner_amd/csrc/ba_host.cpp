@@ -496,8 +496,8 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     b->tb_stride = 0; b->slots_per_wave = 1;
     b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
     if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
-        // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 is as fast and one per 6 already
-        // 8 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
+        // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
+        // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
         // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
         // no difference now that a walk runs out of LDS.)
         uint32_t stride = b->grid >= 32 ? 4 : 2;
