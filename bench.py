@@ -10,7 +10,12 @@ data path; torch.distributed only provides the barrier and the max-over-ranks of
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0. GCUPS counts computed DP cells: the sum over every block-fill call of columns
-iterated x block height, counted on the device and checked against the oracle in the tests.
+iterated x block height, counted on the device and checked against the oracle.
+
+Besides the headline the line carries (N = 1 only): `roofline` for the binding resource of the dominant kernel (packed-int16
+VALU issue; the HBM view sits in `roofline.hbm`), `cpu_baseline` (the AVX2 oracle on the host cores, which doubles as a
+bit-exact check of scores, end positions, cell counts and CIGAR runs), `secondary` (BASELINE.json configs 2, 4, 5 at reduced
+counts on the same kernels, each oracle-checked) and the secondary metrics SURVEY.md 8(d) asks for.
 """
 import argparse
 import json
@@ -21,13 +26,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# roofline constants (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz, HBM3E 8 TB/s). A wave64 VALU instruction
-# occupies its SIMD for 4 cycles (measured for v_pk_add_i16 / v_pk_max_i16 / v_max_i32_dpp, tools/dev/valu_rate.hip),
-# i.e. 64 lanes per CU per clock; packed i16 doubles that: 256 x 64 x 2 x 2.4e9 = 78.6 T int16-op/s.
+# roofline constants. A wave64 packed-int16 VALU instruction (v_pk_add_i16 / v_pk_max_i16 / any VOP3, DPP or SDWA form)
+# occupies its SIMD for 4 cycles -- measured, profiles/r02_valu_rate.md -- i.e. 64 lanes x 2 halves per CU per clock:
+# 256 CUs x 64 x 2 x 2.4e9 = 78.6 T int16-op/s. HBM3E: 8 TB/s (MI355X_MICROARCH.md).
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_INT16_TOPS = 256 * 64 * 2 * 2.4e9 / 1e12
-OPS_PER_CELL = {"xdrop": 14, "xdrop+trace": 20, "global": 11}      # algorithmic int16 ops per DP cell
-BYTES_PER_CELL = {"xdrop": 0.008, "xdrop+trace": 0.52, "global": 0.008}   # algorithmic HBM bytes per cell
+BYTES_PER_CELL = {False: 0.008, True: 0.52}        # algorithmic HBM bytes per cell without / with trace
 
 
 def parse():
@@ -42,6 +46,7 @@ def parse():
     ap.add_argument("--no-trace", action="store_true", help="score-only variant (not the headline workload)")
     ap.add_argument("--cpu-baseline-pairs", type=int, default=0, help="0 = size the sample for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / 4 / 5 lines")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes for input generation (0 = auto; use 1 under rocprofv3)")
     return ap.parse_args()
 
@@ -65,6 +70,82 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def oracle_compare(np, o, w, res, runs, off, n_s, threads):
+    """Bit-exact comparison of the first n_s pairs of a sequence-sequence workload with the oracle: score, both end
+    indices, computed cells and -- with traceback -- every CIGAR run. Returns (oracle result dict, runs compared)."""
+    sub = w.pairs.subset(np.arange(n_s))
+    trace = "trace" in w.mode
+    ref = o.batch_align(w.matrix, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, w.gaps, w.size, w.x_drop, w.mode,
+                        cigar_eq=w.cigar_eq and trace, threads=threads)
+    ok = (np.array_equal(ref["scores"], res["score"][:n_s]) and np.array_equal(ref["query_idx"], res["query_idx"][:n_s])
+          and np.array_equal(ref["reference_idx"], res["reference_idx"][:n_s]) and int(res["cells"][:n_s].sum()) == ref["cells"])
+    n_runs = 0
+    if trace and ok:
+        ok = np.array_equal(ref["cig_len"], res["cigar_len"][:n_s])
+        if ok:
+            ln = ref["cig_len"].astype(np.int64)
+            n_runs = int(ln.sum())
+            # index of every oracle run: pair p's runs sit at cig_off[p] .. cig_off[p] + cig_len[p]
+            start = np.repeat(ref["cig_off"].astype(np.int64), ln)
+            within = np.arange(n_runs, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+            ok = np.array_equal(ref["cig_ops"][start + within], runs[: int(off[n_s])])
+    if not ok:
+        raise RuntimeError(f"bench.py: GPU results differ from the oracle on {w.name}; number is invalid")
+    return ref, n_runs
+
+
+def self_check(np, w, res, runs, off, idx):
+    """Oracle-independent: the HIP CIGARs of pairs `idx` are paths that end at the HIP end positions and re-score to the HIP scores."""
+    from block_aligner_amd.verify import check_cigar
+    for p in idx:
+        check_cigar(runs[int(off[p]): int(off[p + 1])], w.pairs.query(p), w.pairs.reference(p), w.matrix, w.gaps, int(res["score"][p]),
+                    int(res["query_idx"][p]), int(res["reference_idx"][p]), w.mode, what=(w.name, int(p)))
+    return len(idx)
+
+
+def secondary_line(np, H, W, o, w, cores):
+    """One BASELINE.json side configuration on the same kernels: best of 3 launches, oracle-checked sample."""
+    b = W.make_batch(H, w)
+    ms = min(b.run() for _ in range(3))
+    res = b.results()
+    if res["status"].any():
+        raise RuntimeError(f"bench.py: {w.name}: pairs failed on the device")
+    cells = int(res["cells"].sum())
+    n = len(w.pairs)
+    trace = "trace" in w.mode
+    runs, off = b.cigars(res["cigar_len"]) if trace else (None, None)
+    checked = 0
+    if o is not None:
+        if w.profiles:
+            checked = min(n, 300)
+            for k in range(checked):
+                ref = o.align_profile(w.pairs.query(k), w.profiles[k], w.size, w.x_drop, w.mode)
+                got = (int(res["score"][k]), int(res["query_idx"][k]), int(res["reference_idx"][k]), int(res["cells"][k]))
+                if got != (ref["score"], ref["query_idx"], ref["reference_idx"], ref["cells"]) or \
+                        (trace and H.runs_to_string(runs[int(off[k]): int(off[k + 1])]) != ref["cigar"]):
+                    raise RuntimeError(f"bench.py: GPU results differ from the oracle on {w.name}; number is invalid")
+        else:
+            checked = min(n, 4000)
+            oracle_compare(np, o, w, res, runs, off, checked, cores)
+            if trace:
+                self_check(np, w, res, runs, off, range(0, checked, 16))
+    b.close()
+    gc = cells / (ms * 1e-3) / 1e9
+    return {"config": w.name, "gcups": round(gc, 1), "valu_frac": round(gc * 1e9 * w.ops_per_cell / 1e12 / VALU_PEAK_INT16_TOPS, 4),
+            "ops_per_cell": w.ops_per_cell, "kernel_ms": round(ms, 3), "pairs": n, "m_pairs_per_s": round(n / (ms * 1e-3) / 1e6, 3),
+            "full_matrix_equiv_gcups": round(w.full_matrix_cells() / (ms * 1e-3) / 1e9, 1), "parity_checked_pairs": checked}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -77,13 +158,15 @@ def main():
             sys.exit(2)
 
     import numpy as np
-    from block_aligner_amd import scores as S, synth
+    from block_aligner_amd import workloads as W
     from block_aligner_amd.shard import reduce_job, shard_seed
 
     # ---- synthetic workload (forked workers: must happen before any GPU initialisation)
     t0 = time.time()
     workers = a.gen_workers or min(32, max(1, usable_cpus() // max(1, world)))
-    pairs = synth.make_pairs(a.pairs, a.len, a.edits, a.tail, synth.DNA, seed=shard_seed(1234, rank), workers=workers)
+    trace = not a.no_trace
+    w = W.config3(a.pairs, a.len, a.edits, a.tail, seed=shard_seed(1234, rank), trace=trace, workers=workers)
+    pairs = w.pairs
     t_gen = time.time() - t0
 
     import torch
@@ -96,15 +179,11 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    matrix = S.NucMatrix.new_simple(2, -3)       # examples/nanopore_bench.rs:73-79
-    gaps, x_drop = (-5, -1), 100
-    size = (H.percent_len(a.len, 0.01), H.percent_len(a.len, 0.1))   # 1 % .. 10 % of the length -> 128 .. 1024
-    trace = not a.no_trace
-    mode = H.X_DROP | (H.TRACE | H.CIGAR_EQ if trace else 0)
-    kind = "xdrop+trace" if trace else "xdrop"
+    w.size = (H.percent_len(a.len, 0.01), H.percent_len(a.len, 0.1))   # 1 % .. 10 % of the length -> 128 .. 1024
+    size = w.size
 
     t0 = time.time()
-    batch = H.BatchAligner(matrix, gaps, size, x_drop, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    batch = W.make_batch(H, w)
     t_setup = time.time() - t0
     info = batch.info()
 
@@ -128,73 +207,92 @@ def main():
     cells_rank = int(res["cells"].sum())
     elapsed, cells_total = reduce_job(elapsed, float(cells_rank), device="cuda")
 
-    out = None
     if rank == 0:
         gcups = cells_total * a.steps / elapsed / 1e9
         k_ms = float(np.mean(kernel_ms))
         gcups_kernel = cells_rank / (k_ms * 1e-3) / 1e9          # this rank's kernel alone, from HIP events on its stream
-        alg_bytes = BYTES_PER_CELL[kind] * cells_rank
-        achieved_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
+        achieved_gbs = BYTES_PER_CELL[trace] * cells_rank / (k_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf))
-                if t.get("pairs") == a.pairs and t.get("kind") == kind:
+                if t.get("pairs") == a.pairs and t.get("kind") == ("xdrop+trace" if trace else "xdrop"):
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+        ops = w.ops_per_cell
+        tops = gcups_kernel * 1e9 * ops / 1e12
+        roofline = {"bound": "valu-int16", "achieved": round(tops, 3), "peak": round(VALU_PEAK_INT16_TOPS, 1), "unit": "Tint16-op/s",
+                    "frac": round(tops / VALU_PEAK_INT16_TOPS, 5), "traffic": traffic,
                     "kernel": "ba::k_align<8, NUC, trace=%d, xdrop=1>" % int(trace), "kernel_ms": round(k_ms, 3),
-                    "algorithmic_bytes_per_cell": BYTES_PER_CELL[kind],
-                    "note": "integer max-plus recurrence: VALU-issue bound by construction, neither HBM nor MFMA; see valu_roofline"}
-        valu = {"bound": "valu-int16", "achieved": round(gcups_kernel * 1e9 * OPS_PER_CELL[kind] / 1e12, 3),
-                "peak": round(VALU_PEAK_INT16_TOPS, 1), "unit": "Tint16-op/s",
-                "frac": round(gcups_kernel * 1e9 * OPS_PER_CELL[kind] / 1e12 / VALU_PEAK_INT16_TOPS, 5),
-                "algorithmic_ops_per_cell": OPS_PER_CELL[kind]}
+                    "algorithmic_ops_per_cell": ops, "kernel_gcups": round(gcups_kernel, 1),
+                    "hbm": {"achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
+                            "algorithmic_bytes_per_cell": BYTES_PER_CELL[trace]},
+                    "note": "integer max-plus recurrence: bound by packed-int16 VALU issue (4 cycles per wave64 instruction, "
+                            "profiles/r02_valu_rate.md), neither HBM nor MFMA; traffic = measured HBM bytes per launch (PMC)"}
 
-        # ---- parity spot-check + CPU baseline (the oracle is the checker and the "port" baseline, never the product)
+        surviving = int(batch.surviving_cells().sum()) if trace else None
+        full_equiv = w.full_matrix_cells()
+        runs = off = None
+        if trace:
+            runs, off = batch.cigars(res["cigar_len"])
+        # oracle-independent self-check of the HIP output: a spread of pairs' CIGARs re-walked and re-scored
+        rescored = self_check(np, w, res, runs, off, range(0, a.pairs, max(1, a.pairs // 256))) if trace else 0
+
+        batch.close()      # the 10 kbp batch's trace arena is most of the device memory: free it before the side configurations
+        # ---- parity check + CPU baseline (the oracle is the checker and the "port" baseline, never the product)
         cpu = None
+        secondary = None
+        runs_checked = 0
         if not a.no_cpu_baseline and world == 1:
             from oracle.oracle_py import Oracle, build
             build()
             o = Oracle("avx2")
-            modes = ("trace", "x_drop") if trace else ("x_drop",)
             cores = usable_cpus()
             n_s = a.cpu_baseline_pairs or min(a.pairs, max(64, 8000 * cores))   # ~1 ms per pair per core -> <= ~10 s on all usable cores
-            sub = pairs.subset(np.arange(n_s))
-            ref = o.batch_align(matrix, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, gaps, size, x_drop, modes,
-                                cigar_eq=True, threads=cores)
+            ref, runs_checked = oracle_compare(np, o, w, res, runs, off, n_s, cores)
             n1 = min(n_s, 2000)                                                  # ~6 s on one core
             sub1 = pairs.subset(np.arange(n1))
-            ref1 = o.batch_align(matrix, sub1.pool, sub1.q_off, sub1.q_len, sub1.r_off, sub1.r_len, gaps, size, x_drop, modes,
+            ref1 = o.batch_align(w.matrix, sub1.pool, sub1.q_off, sub1.q_len, sub1.r_off, sub1.r_len, w.gaps, size, w.x_drop, w.mode,
                                  cigar_eq=True, threads=1)
-            ok = (np.array_equal(ref["scores"], res["score"][:n_s]) and np.array_equal(ref["query_idx"], res["query_idx"][:n_s])
-                  and np.array_equal(ref["reference_idx"], res["reference_idx"][:n_s]))
-            if trace:
-                ok = ok and np.array_equal(ref["cig_len"], res["cigar_len"][:n_s])
-            cells_ok = int(res["cells"][:n_s].sum()) == ref["cells"]
-            if not (ok and cells_ok):
-                raise RuntimeError("bench.py: GPU results differ from the oracle on the CPU-baseline sample; number is invalid")
+            # sanity anchor (first row): the reference's nanopore_bench at block 32-32 without trace
+            # took 239.7 us per 10 kbp pair on its authors' (unstated) machine, one thread
+            n32 = min(n_s, 1000)
+            sub32 = pairs.subset(np.arange(n32))
+            ref32 = o.batch_align(w.matrix, sub32.pool, sub32.q_off, sub32.q_len, sub32.r_off, sub32.r_len, w.gaps, (32, 32), w.x_drop,
+                                  ("x_drop",), threads=1)
             cpu = {"value": round(ref["cells"] / ref["seconds"] / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
                    "sample": f"first {n_s} pairs of the same batch, {cores} threads, {ref['seconds']:.1f} s; AVX2 restatement of "
                              f"block-aligner v0.5.1 (oracle/), not the Rust crate",
+                   "cpu_model": cpu_model(),
                    "single_thread_gcups": round(ref1["cells"] / ref1["seconds"] / 1e9, 3),
-                   "parity_checked_pairs": n_s}
+                   "parity_checked_pairs": n_s, "cigar_runs_checked": runs_checked,
+                   "sanity_block32_us_per_pair": round(ref32["seconds"] / n32 * 1e6, 1),
+                   "sanity_reference_notebook_us_per_pair": 239.7}
+            if not a.no_secondary:
+                secondary = [secondary_line(np, H, W, o, W.config2(50000, workers=workers), cores),
+                             secondary_line(np, H, W, o, W.config2(50000, trace=True, workers=workers), cores),
+                             secondary_line(np, H, W, o, W.config4(50000), cores),
+                             secondary_line(np, H, W, o, W.config4(50000, trace=True), cores),
+                             secondary_line(np, H, W, o, W.config5(5000), cores)]
         out = {
             "metric": "GCUPS (DP cells/s) on 10 kbp DNA X-drop batch; bit-exact score+CIGAR vs AVX2",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i16 (saturating lane scores) + i32 block offsets", "data": "synthetic",
             "config": {"workload": f"config 3: {a.pairs} pairs/GPU x {a.len} bp random DNA, {a.edits} edits, +{a.tail} bp random tails, "
-                                   f"NucMatrix(2,-3), gaps(-5,-1), X-drop {x_drop}, block {size[0]}..{size[1]}, "
+                                   f"NucMatrix(2,-3), gaps(-5,-1), X-drop {w.x_drop}, block {size[0]}..{size[1]}, "
                                    + ("traceback to =/X CIGAR" if trace else "score only"),
                        "pairs_per_gpu": a.pairs, "block": list(size), "trace": trace, "parallelism": f"{world} x independent shard",
                        "grid_waves": info["grid"], "lds_bytes_per_wave": info["lds_bytes_per_wave"],
                        "trace_arena_gb": round(info["trace_arena_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "cells_per_step": cells_total},
-            "roofline": roofline, "valu_roofline": valu, "cpu_baseline": cpu,
+            "pairs_per_s": round(a.pairs * world * a.steps / elapsed, 1),
+            "full_matrix_equiv_gcups": round(full_equiv * world * a.steps / elapsed / 1e9, 1),
+            "computed_cells": cells_rank, "surviving_cells": surviving,
+            "cigar_runs_checked": runs_checked, "cigars_rescored": rescored,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
     batch.close()

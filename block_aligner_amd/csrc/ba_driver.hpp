@@ -844,6 +844,7 @@ struct Aligner {
                 coldp()->score[pair] = score; coldp()->query_idx[pair] = ri; coldp()->reference_idx[pair] = rj;
                 if (coldp()->cells) coldp()->cells[pair] = cells;
                 if (coldp()->nblocks_out) coldp()->nblocks_out[pair] = nblocks;
+                if (coldp()->trace_words_out) coldp()->trace_words_out[pair] = trace_top;
             }
             hand_off(slot, pair, ri, rj);
             return;
@@ -865,6 +866,7 @@ struct Aligner {
             if (coldp()->cells) coldp()->cells[pair] = cells;
             if (coldp()->status) coldp()->status[pair] = status;
             if (coldp()->nblocks_out) coldp()->nblocks_out[pair] = nblocks;
+            if (coldp()->trace_words_out) coldp()->trace_words_out[pair] = trace_top;
             if (coldp()->slot_out) coldp()->slot_out[pair] = slot;
         }
     }

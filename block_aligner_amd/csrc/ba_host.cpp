@@ -173,7 +173,7 @@ struct BaBatch {
     uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
     uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
-    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace, blocks, ckpt, counter,
+    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace_words, trace, blocks, ckpt, counter,
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
     std::vector<uint32_t> h_order;   // device order -> caller's pair index (empty: identical); see Packed::order
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1, tb_reserve = 0;
@@ -190,7 +190,7 @@ struct BaBatch {
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
         bp.cig_ops = ((mode & BA_TRACE) && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
         bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
-        bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>();
+        bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>(); bp.trace_words_out = trace_words.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
         bp.ckpt = ckpt.as<short>();
@@ -538,7 +538,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(pool, total); BA_ALLOC(q_off, n * 8); BA_ALLOC(q_len, n * 4); BA_ALLOC(r_off, n * 8); BA_ALLOC(r_len, n * 4);
     BA_ALLOC(matrix, 1024);
     BA_ALLOC(score, n * 4); BA_ALLOC(qidx, n * 4); BA_ALLOC(ridx, n * 4); BA_ALLOC(cig_len, n * 4); BA_ALLOC(cells, n * 8);
-    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(pair_slot, n * 4); BA_ALLOC(counter, 64);
+    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(pair_slot, n * 4); BA_ALLOC(trace_words, n * 4); BA_ALLOC(counter, 64);
     BA_ALLOC(cig_off, (n + 1) * 8);
     BA_ALLOC(cig_ops, b->cig_total * 4);
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
@@ -704,6 +704,19 @@ int ba_batch_results(BaBatch* b, int32_t* score, uint32_t* qi, uint32_t* ri, uin
         d2h(b->cig_len, cigar_len, b->n) || d2h(b->status, status, b->n)) return 1;
     to_caller_order(b->h_order, score); to_caller_order(b->h_order, qi); to_caller_order(b->h_order, ri);
     to_caller_order(b->h_order, cells); to_caller_order(b->h_order, cigar_len); to_caller_order(b->h_order, status);
+    return 0;
+}
+// Sum of width x height over the rectangles left on each pair's trace stack (Trace::blocks(), scan_block.rs:1676-1691): what
+// the reference's "DP fraction" counts (examples/uc_accuracy.rs:88-89). Rectangles popped by a checkpoint restore are not in it.
+int ba_batch_surviving_cells(BaBatch* b, uint64_t* cells) {
+    if (!b || !cells) return fail("null argument");
+    if (!(b->mode & BA_TRACE)) return fail("batch was created without BA_TRACE");
+    if (!b->ran) return fail("ba_batch_run has not been called");
+    HIP_TRY(hipSetDevice(b->device));
+    std::vector<uint32_t> w(b->n);
+    if (d2h(b->trace_words, w.data(), b->n)) return 1;
+    const uint64_t per_word = (b->mode & BA_LOCAL_START) ? 5 : 1;   // LOCAL_START: 4 zero-mask words follow every trace word
+    for (uint32_t s = 0; s < b->n; s++) cells[b->h_order.empty() ? s : b->h_order[s]] = (uint64_t)w[s] / per_word * 8;
     return 0;
 }
 int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {

@@ -51,6 +51,7 @@ struct BatchParams {
     uint32_t* status;            // per pair error bits
     uint32_t* nblocks_out;       // per pair: rectangles on the trace stack at the end (may be null)
     uint32_t* slot_out;          // per pair: trace slot that holds its stack (for a later k_traceback; may be null)
+    uint32_t* trace_words_out;   // per pair: trace words on the stack at the end = surviving-rectangle cells / 8 (may be null)
     // scratch, one region per resident wave
     uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot

@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
         L.ba_batch_wait.argtypes = [vp, C.POINTER(C.c_float)]
         L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
+        L.ba_batch_surviving_cells.argtypes = [vp, vp]
         L.ba_batch_info.argtypes = [vp, vp]
         L.ba_batch_destroy.argtypes = [vp]
         _lib = L
@@ -380,6 +381,13 @@ class BatchAligner:
         if lib().ba_batch_cigars(self._h, runs.ctypes.data, runs.size):
             raise RuntimeError(last_error())
         return runs, off
+
+    def surviving_cells(self):
+        """TRACE batches: per pair, sum of width x height over Trace::blocks() (scan_block.rs:1676-1691)."""
+        out = np.zeros(self.n, np.uint64)
+        if lib().ba_batch_surviving_cells(self._h, out.ctypes.data):
+            raise RuntimeError(last_error())
+        return out
 
     def info(self):
         o = np.zeros(4, np.uint64)

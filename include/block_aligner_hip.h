@@ -208,6 +208,9 @@ int ba_batch_results(BaBatch* batch, int32_t* score, uint32_t* query_idx, uint32
 /* CIGAR runs of all pairs, concatenated in pair order (pair p occupies cigar_len[p] entries after the pairs before it).
  * `capacity` = number of uint32 entries available in `runs`; fails if too small. */
 int ba_batch_cigars(BaBatch* batch, uint32_t* runs, uint64_t capacity);
+/* TRACE batches: per pair, the sum of width x height over the rectangles left on its trace stack (Trace::blocks(),
+ * scan_block.rs:1676-1691; the numerator of the reference's "DP fraction", examples/uc_accuracy.rs:88-89). */
+int ba_batch_surviving_cells(BaBatch* batch, uint64_t* cells);
 /* Facts about the launch: out[0] grid (resident waves), [1] LDS bytes per wave, [2] trace arena bytes, [3] padded pool bytes */
 int ba_batch_info(BaBatch* batch, uint64_t out[4]);
 void ba_batch_destroy(BaBatch* batch);

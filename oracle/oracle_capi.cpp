@@ -113,6 +113,26 @@ int ba_oracle_align(int kind, const int8_t* matrix, const uint8_t* q, size_t qle
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// Trace::blocks() of one seq-seq TRACE alignment (scan_block.rs:1676-1691): writes up to `cap` rectangles as
+// {row, col, width, height} u64 quadruples in fill order; *count = their number.
+int ba_oracle_align_blocks(int kind, const int8_t* matrix, const uint8_t* q, size_t qlen, const uint8_t* r, size_t rlen,
+                           int8_t gap_open, int8_t gap_extend, size_t min_size, size_t max_size, int32_t x_drop,
+                           uint32_t flags, uint64_t* rects, size_t cap, uint64_t* count) {
+    try {
+        AnyMatrix m(kind, matrix);
+        size_t pad = max_size < (size_t)L ? (size_t)L : max_size;
+        PaddedBytes pq = m.pad(q, qlen, pad), pr = m.pad(r, rlen, pad);
+        Block blk(mode_of(flags | F_TRACE), qlen, rlen, pad);
+        m.align(blk, pq, pr, Gaps{gap_open, gap_extend}, min_size, max_size, x_drop);
+        const std::vector<Rectangle> bl = blk.trace().blocks();
+        *count = bl.size();
+        for (size_t k = 0; k < bl.size() && k < cap; k++) {
+            rects[4 * k] = bl[k].row; rects[4 * k + 1] = bl[k].col; rects[4 * k + 2] = bl[k].width; rects[4 * k + 3] = bl[k].height;
+        }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 // Exponential search on the min block size (scan_block.rs:884-902). *reached = min size that met the target, or 0.
 int ba_oracle_align_exp(int kind, const int8_t* matrix, const uint8_t* q, size_t qlen, const uint8_t* r, size_t rlen,
                         int8_t gap_open, int8_t gap_extend, size_t min_size, size_t max_size, int32_t x_drop,

@@ -43,6 +43,8 @@ class Oracle:
         lib.ba_oracle_align.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int8, C.c_int8,
                                         C.c_size_t, C.c_size_t, C.c_int32, C.c_uint32, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t, C.c_void_p]
+        lib.ba_oracle_align_blocks.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int8, C.c_int8,
+                                               C.c_size_t, C.c_size_t, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.ba_oracle_align_exp.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int8, C.c_int8,
                                             C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -83,6 +85,19 @@ class Oracle:
             raise self._err()
         return dict(score=score.value, query_idx=qi.value, reference_idx=ri.value, cigar=buf.value.decode(),
                     cells=int(stats[0]), steps=int(stats[1]), end_block_size=int(stats[2]), surviving_cells=int(stats[3]))
+
+    def align_blocks(self, matrix, q: bytes, r: bytes, gaps, size, x_drop=0, mode=()):
+        """Trace::blocks() of the alignment -> [(row, col, width, height), ...] in fill order (scan_block.rs:1676-1691)."""
+        raw = matrix.raw()
+        cap = (len(q) + len(r)) // 4 + 64
+        rects = np.zeros(4 * cap, np.uint64)
+        count = C.c_uint64()
+        rc = self.lib.ba_oracle_align_blocks(matrix.KIND, raw.ctypes.data, q, len(q), r, len(r), gaps[0], gaps[1], size[0], size[1],
+                                             x_drop, flags_of(mode), rects.ctypes.data, cap, C.byref(count))
+        if rc:
+            raise self._err()
+        assert count.value <= cap
+        return [tuple(int(v) for v in rects[4 * k: 4 * k + 4]) for k in range(count.value)]
 
     def align_exp(self, matrix, q, r, gaps, size, x_drop, target, mode=()):
         raw = matrix.raw()

@@ -69,3 +69,15 @@ def rescore(runs, q: bytes, r: bytes, matrix, gaps) -> int:
         elif op == 5:
             total += gaps[0] + gaps[1] * (n - 1); j += n
     return total
+
+
+def parse_cigar(text: str):
+    """CIGAR text -> packed (len << 4 | op) runs."""
+    import numpy as np
+    runs, num = [], ""
+    for ch in text:
+        if ch.isdigit():
+            num += ch
+        else:
+            runs.append((int(num) << 4) | " M=XID".index(ch)); num = ""
+    return np.array(runs, dtype=np.int64)

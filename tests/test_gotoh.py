@@ -1,0 +1,113 @@
+"""CPU tests of the oracle-independent checker (tests/gotoh.py): the full-matrix DP must reproduce the reference-held
+global scores (so the checker itself is pinned by the reference's own known answers), agree with the oracle whenever
+the block covers the whole matrix, and the CIGAR walker must accept every oracle CIGAR in every mode."""
+import numpy as np
+import pytest
+
+from block_aligner_amd import scores as S
+from block_aligner_amd import synth
+from tests.common import kat_matrix, kat_profile, parse_cigar
+from tests.gotoh import check_cigar, global_score, global_score_profile
+
+AA20 = b"ACDEFGHIKLMNPQRSTVWY"
+
+
+def test_full_dp_reproduces_reference_global_kats(kats):
+    """Every global known answer whose block covers the whole DP matrix (all of scan_block.rs:1909-1992, the trace KATs
+    and the doc-test) is a full-matrix optimum: the independent DP must give the reference's number."""
+    n = 0
+    for k in kats["align"] + kats["inferred"]:
+        if k["mode"] and set(k["mode"]) - {"trace"}:
+            continue
+        rlen = len(k["profile"][0]) if k["kind"] == "profile" else len(k["r"])
+        if max(len(k["q"]), rlen) >= k["size"][0]:      # the first (min-size) block must cover the whole matrix
+            continue
+        if k["kind"] == "profile":
+            b, ma, mi, goc, gcc, gor, ge = k["profile"]
+            if gcc != 0 or goc != gor or k["set_gap_close_C"]:
+                continue
+            got = global_score_profile(k["q"].encode(), kat_profile(k), goc)
+        else:
+            got = global_score(k["q"].encode(), k["r"].encode(), kat_matrix(k), k["gaps"])
+        assert got == k["expect"]["score"], (k["name"], got, k["expect"])
+        n += 1
+    assert n >= 20, n
+
+
+def _pow2_above(n):
+    b = 16
+    while b <= n:
+        b *= 2
+    return b
+
+
+@pytest.mark.parametrize("kind", ["dna", "protein"])
+def test_oracle_full_block_equals_full_dp(oracle, kind):
+    rng = np.random.default_rng(12)
+    for it in range(60):
+        alpha = synth.DNA if kind == "dna" else synth.AMINO
+        L = int(rng.integers(0, [14, 30, 60, 120, 250, 500, 1000][it % 7]))
+        r = synth.rand_str(rng, L, alpha)
+        q = synth.mutate(rng, r, int(rng.integers(0, L // 4 + 1)), alpha)
+        if it % 5 == 0:
+            q = synth.rand_str(rng, int(rng.integers(0, L + 1)), alpha)
+        m = S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))) if kind == "dna" else S.BLOSUM62
+        ge = -int(rng.integers(1, 4)); go = ge - int(rng.integers(1, 12))
+        B = _pow2_above(max(len(q), len(r)))
+        res = oracle.align(m, q.tobytes(), r.tobytes(), (go, ge), (B, B), 0, ("trace",), cigar_eq=True)
+        assert res["score"] == global_score(q.tobytes(), r.tobytes(), m, (go, ge)), (it, len(q), len(r), B)
+        check_cigar(parse_cigar(res["cigar"]), q.tobytes(), r.tobytes(), m, (go, ge), res["score"], res["query_idx"], res["reference_idx"])
+
+
+def test_oracle_profile_full_block_equals_full_dp(oracle):
+    rng = np.random.default_rng(3)
+    for it in range(30):
+        L = int(rng.integers(1, [14, 60, 250, 500][it % 4]))
+        cons = bytes(AA20[i] for i in rng.integers(0, 20, L))
+        B = _pow2_above(L + 40)
+        p = S.AAProfile(L, B, -1)
+        for i, c in enumerate(cons):
+            for b in AA20:
+                p.set(i + 1, b, S.BLOSUM62.get(c, b))
+        go = -int(rng.integers(5, 14))
+        for i in range(L + 1):
+            p.set_gap_open_C(i, go); p.set_gap_close_C(i, 0); p.set_gap_open_R(i, go)
+        q = synth.mutate(rng, np.frombuffer(cons, np.uint8), L // 3, np.frombuffer(AA20, np.uint8)).astype(np.uint8).tobytes()[: L + 30]
+        res = oracle.align_profile(q, p, (B, B), 0, ())
+        assert res["score"] == global_score_profile(q, p, go), (it, L, len(q))
+
+
+MODES = [("trace",), ("trace", "x_drop"), ("trace", "local_start"), ("trace", "local_start", "x_drop"), ("trace", "free_query_start_gaps")]
+
+
+def test_cigar_walker_accepts_oracle_cigars(oracle):
+    rng = np.random.default_rng(8)
+    for it in range(200):
+        dna = it % 2 == 0
+        alpha = synth.DNA if dna else synth.AMINO
+        L = int(rng.integers(0, 700))
+        r = synth.rand_str(rng, L, alpha)
+        q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 30)) * (it % 3 == 0), alpha), synth.mutate(rng, r, int(rng.integers(0, L // 6 + 1)), alpha)])
+        m = S.NucMatrix.new_simple(2, -3) if dna else S.BLOSUM62
+        gaps = (-5, -1) if dna else (-11, -1)
+        mode = MODES[it % len(MODES)]
+        size = [(16, 16), (32, 128), (32, 512)][it % 3]
+        eq = bool(it % 4)
+        res = oracle.align(m, q.tobytes(), r.tobytes(), gaps, size, 60, mode, cigar_eq=eq)
+        check_cigar(parse_cigar(res["cigar"]), q.tobytes(), r.tobytes(), m, gaps, res["score"], res["query_idx"], res["reference_idx"],
+                    mode, what=(it, mode, size))
+
+
+def test_cigar_walker_rejects_wrong_paths():
+    m = S.NucMatrix.new_simple(2, -3)
+    q, r = b"ACGTACGT", b"ACGTTCGT"
+    good = parse_cigar("4=1X3=")
+    check_cigar(good, q, r, m, (-5, -1), 2 * 7 - 3, 8, 8)
+    with pytest.raises(AssertionError):
+        check_cigar(parse_cigar("8="), q, r, m, (-5, -1), 16, 8, 8)          # an X called =
+    with pytest.raises(AssertionError):
+        check_cigar(good, q, r, m, (-5, -1), 12, 8, 8)                         # wrong score
+    with pytest.raises(AssertionError):
+        check_cigar(parse_cigar("4=1X2="), q, r, m, (-5, -1), 9, 8, 8)         # does not reach the origin
+    with pytest.raises(AssertionError):
+        check_cigar(parse_cigar("4=1I1X3="), q, r, m, (-5, -1), 6, 8, 8)       # consumes more than the end position

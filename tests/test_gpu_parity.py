@@ -6,6 +6,7 @@ import pytest
 from block_aligner_amd import scores as S
 from block_aligner_amd import synth
 from oracle.oracle_py import cigar_runs_to_string
+from tests.gotoh import check_cigar
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +35,10 @@ def compare(H, oracle, pairs, matrix, gaps, size, x_drop, mode_names, cigar_eq=T
             want = ref["cig_ops"][int(ref["cig_off"][p]): int(ref["cig_off"][p]) + int(ref["cig_len"][p])]
             got = runs[int(off[p]): int(off[p + 1])]
             assert np.array_equal(got, want), (p, cigar_runs_to_string(got)[:200], cigar_runs_to_string(want)[:200])
+            # oracle-independent: the HIP CIGAR is a path that ends at the HIP end position, re-scores to the HIP score by the
+            # affine-gap definition and whose =/X runs agree with the bytes (examples/verify_trace.rs:8-31)
+            check_cigar(got, pairs.query(p), pairs.reference(p), matrix, gaps, int(res["score"][p]), int(res["query_idx"][p]),
+                        int(res["reference_idx"][p]), mode_names, what=("pair", p, mode_names, size))
     b.close()
     return res
 
@@ -208,19 +213,30 @@ def test_batch_align_exp(hip, oracle):
 
 
 def test_trace_blocks(hip, oracle):
-    """Trace::blocks(): the surviving rectangles tile what the oracle reports as surviving cells, start at the origin and
-    chain by steps of 8 (scan_block.rs:1676-1691)."""
+    """Trace::blocks() (scan_block.rs:1676-1691): the rectangle list of the HIP trace stack equals the oracle's, rectangle by
+    rectangle in fill order -- on plain shift steps, with grow / checkpoint-restore / shrink (long indels), and in X-drop mode."""
     rng = np.random.default_rng(9)
+    cases = []
     r = synth.rand_str(rng, 900, synth.DNA)
-    q = synth.mutate(rng, r, 90, synth.DNA)
-    qb, rb = q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()
-    a = hip.Block(len(qb), len(rb), 256, trace=True)
-    a.align(hip.PaddedBytes.from_bytes(qb, 256, S.NucMatrix), hip.PaddedBytes.from_bytes(rb, 256, S.NucMatrix), NUC, S.Gaps(-5, -1), (32, 256), 0)
-    blocks = a.trace().blocks()
-    ref = oracle.align(NUC, qb, rb, (-5, -1), (32, 256), 0, ("trace",))
-    assert a.res().score == ref["score"]
-    assert sum(w * h for _, _, w, h in blocks) == ref["surviving_cells"]
-    assert blocks[0][:2] == (0, 0) and all(w % 8 == 0 and h % 8 == 0 for _, _, w, h in blocks)
+    cases.append((synth.mutate(rng, r, 90, synth.DNA), r, (32, 256), 0, False))
+    ps = synth.make_pairs(6, (1500, 3000), (100, 300), 100, synth.DNA, seed=77, indels=3, indel_len=(20, 200))
+    for p in range(len(ps)):
+        cases.append((np.frombuffer(ps.query(p), np.uint8), np.frombuffer(ps.reference(p), np.uint8), [(32, 256), (64, 512), (128, 1024)][p % 3], 100, p % 2 == 0))
+    grew = 0
+    for q, r, size, x_drop, xd in cases:
+        qb, rb = q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()
+        a = hip.Block(len(qb), len(rb), size[1], trace=True, x_drop=xd)
+        a.align(hip.PaddedBytes.from_bytes(qb, size[1], S.NucMatrix), hip.PaddedBytes.from_bytes(rb, size[1], S.NucMatrix), NUC, S.Gaps(-5, -1), size, x_drop)
+        blocks = a.trace().blocks()
+        mode = ("trace", "x_drop") if xd else ("trace",)
+        ref = oracle.align(NUC, qb, rb, (-5, -1), size, x_drop, mode)
+        want = oracle.align_blocks(NUC, qb, rb, (-5, -1), size, x_drop, mode)
+        assert a.res().score == ref["score"]
+        assert blocks == want, (size, len(blocks), len(want), [(k, x, y) for k, (x, y) in enumerate(zip(blocks, want)) if x != y][:3])
+        assert sum(w * h for _, _, w, h in blocks) == ref["surviving_cells"]
+        assert blocks[0][:2] == (0, 0)
+        grew += any(h > size[0] or w > size[0] for _, _, w, h in blocks)
+    assert grew >= 3          # the indel cases really exercise grown blocks
 
 
 def test_long_pairs(hip, oracle):

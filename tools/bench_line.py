@@ -8,7 +8,7 @@ for l in sys.stdin:
     if l.startswith("{"):
         j = json.loads(l)
         found = True
-        print(tag, j["value"], "GCUPS", j["ms_per_step"], "ms", j["config"]["trace_arena_gb"], "GB", j["valu_roofline"]["frac"])
+        print(tag, j["value"], "GCUPS", j["ms_per_step"], "ms", j["config"]["trace_arena_gb"], "GB", j["roofline"]["frac"])
     else:
         other.append(l.rstrip())
 if not found:
