@@ -44,6 +44,11 @@ __device__ __forceinline__ bool is_lane(int k) {
     return l == k;
 }
 
+// one wave's LDS operations execute in program order; this only keeps the compiler from reordering them across a hand-off
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_keep(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
@@ -214,6 +219,103 @@ __device__ __forceinline__ int fetch_score(const char* table, const ScoreKey<KIN
 }
 // unaligned (2-byte aligned) load of two consecutive i16
 __device__ __forceinline__ int load_pair_i16(const short* p) { int v; __builtin_memcpy(&v, p, 4); return v; }
+
+// ------------------------------------------------------------------ shift step with the borders in registers
+// One 8-column shift step of a single-chunk block (<= 128 cells) whose four borders stay in VGPRs from step to step
+// (scan_block.rs:147-246 with place_block 1083-1228 and the border moves 1003-1061 folded in). (Ad, Ac) is the border pair
+// along the step's vector axis (D_col/C_col for a right step, D_row/R_row for a down step), (Pd, Pr) the orthogonal pair,
+// which this step shifts by 8 entries and extends by the last cell of each new column. LDS is used for that shift only:
+// the re-based pair is written to Pl (D) and Pl + PR_DIST (R), every column appends behind it, and one read at +8 entries
+// yields the shifted registers. `sink`: >= 352 bytes of this wave's LDS that nothing reads (lets every lane store the
+// column's last cell unpredicated; only the last lane's address is the real one).
+struct FastOut { int mx, row, col; int act_max8, pas_max8, corner_new; };
+
+template <int KIND, bool TRACE, bool XDROP, bool FULL128, int PR_DIST>
+__device__ __forceinline__ void fast_rect(const char* table, const FillConsts& fc, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
+                                          int vec_a, int vec_b, unsigned long long colbytes, int nl_in, int corner, int off_add,
+                                          uint32_t* __restrict__ trace_out, FastOut& o) {
+    const int lane = lane_id();
+    const int nl = FULL128 ? 64 : nl_in;             // active lanes = block size / 2
+    const bool active = FULL128 ? true : lane < nl;
+    const int offa = splat(off_add);
+    int d = adds(Ad, offa), c = adds(Ac, offa);      // just_offset (scan_block.rs:1003-1012)
+    const int pd = adds(Pd, offa), pr = adds(Pr, offa);
+    lds_fence();
+    *(int*)(Pl + 2 * lane) = pd; *(int*)(Pl + PR_DIST + 2 * lane) = pr;   // (lanes beyond the block write slots nothing reads before it is rewritten)
+    // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based (scan_block.rs:1042)
+    o.corner_new = __builtin_amdgcn_readlane(pd, 3) >> 16;
+    const ScoreKey<KIND> key = make_key<KIND>(vec_a, vec_b);
+    int dmax = 0, jlast = 0, tacc = 0;
+    const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
+    short* last_base = last_lane ? Pl + 2 * nl : sink + lane;
+    int sc_next = fetch_score<KIND>(table, key, (int)(colbytes & 0xff));
+#pragma unroll
+    for (int j = 0; j < STEP; j++) {
+        const int sc = sc_next;
+        if (j < STEP - 1) sc_next = fetch_score<KIND>(table, key, (int)((colbytes >> (8 * (j + 1))) & 0xff));
+        // D00: previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
+        int prev = wave_shr1_z(d);
+        if (j == 0) prev = set_lane0(prev, (int)((uint32_t)corner << 16));
+        const int d00 = __builtin_amdgcn_alignbit(d, prev, 16);
+        int d11 = adds(d00, sc);
+        const int copen = adds(d, fc.go2);
+        const int cn = vmax(adds(c, fc.ge2), copen);
+        d11 = vmax(d11, cn);
+        const int x = adds(d11, fc.ome2);            // D11_open
+        const s16x2 t2 = as_s(adds(x, fc.ge2));
+        int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
+        const int pm = wave_prefix_max((int)as_s(r).y - fc.laneKG);
+        int cin = add_shr1(pm, fc.lanem1KG);
+        cin = max(max(cin, fc.laneKG), -32768);      // the carry above the column is MIN = 0
+        const s16x2 cs = as_s(cin);
+        r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst);
+        const int dn = vmax(d11, r);
+        if (TRACE) {
+            const int nC = neq01(dn, cn, fc.ones), nR = neq01(dn, r, fc.ones);
+            const int nCo = neq01(cn, copen, fc.ones), eRo = eq01(r, x, fc.ones);
+            int nib = pk_mad_k<2>(nR, nC);
+            nib = pk_mad_k<4>(nCo, nib);
+            nib = pk_mad_k<8>(eRo, nib);
+            tacc |= nib << ((j & 3) * 4);
+            if ((j & 3) == 3) {   // (unpredicated: lanes beyond a small block write words that a later store covers, or the slot's slack)
+                trace_out[(j >> 2) * nl + lane] = (uint32_t)tacc;
+                tacc = 0;
+            }
+        }
+        dmax = vmax(dmax, dn);
+        if (XDROP) jlast = vmaxu(jlast, pk_mul(eq01(dmax, dn, fc.ones), splat(j + 1)));
+        d = dn; c = cn;
+        // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
+        last_base[j] = (short)(d >> 16); last_base[PR_DIST + j] = (short)(r >> 16);
+    }
+    lds_fence();
+    Pd = *(const int*)(Pl + 2 * lane + STEP); Pr = *(const int*)(Pl + PR_DIST + 2 * lane + STEP);   // shift_and_offset (scan_block.rs:1040-1061)
+    Ad = d; Ac = c;
+    o.act_max8 = first8_max(d);
+    o.pas_max8 = first8_max(Pd);
+    if (XDROP) {
+        // one reduction for value and location: value (>= 0: D_max starts at MIN = 0) | 15 - row % 16 | last column + 1 | row
+        int best = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int v = h ? (int)as_s(dmax).y : (int)as_s(dmax).x;
+            const int jl1 = h ? (jlast >> 16) & 0xffff : jlast & 0xffff;
+            const int row = 2 * lane + h;
+            best = max(best, (v << 15) | ((15 - (row & 15)) << 11) | (jl1 << 7) | row);
+        }
+        if (!active) best = 0;
+        best = wave_max(best);
+        o.mx = best >> 15;
+        const int jl1 = (best >> 7) & 15;
+        o.col = jl1 ? jl1 - 1 : 0;
+        o.row = best & 127;
+        if (o.mx == 0 && jl1 == 0) o.row = 0;   // no cell equalled the max (the initial MIN): lane 0 / column 0 / vector 0
+    } else {
+        int lm = max((int)as_s(dmax).x, (int)as_s(dmax).y);
+        if (!active) lm = -32768;
+        o.mx = wave_max(lm); o.row = 0; o.col = 0;
+    }
+}
 
 // ------------------------------------------------------------------ block fill
 // Fills a width x height rectangle column by column (scan_block.rs:1083-1228; for a down shift the caller swaps the

@@ -470,32 +470,161 @@ struct Aligner {
     int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot, 9-11 the first grow rectangle's max / row / col (see park())
     uint32_t status = 0;
     unsigned long long cells = 0;
-    // sequence bytes for the next shift step, fetched one step ahead for both possible directions
-    int pf_qv = 0, pf_rv = 0, pf_qc = 0, pf_rc = 0;
+    // sequence bytes for the next shift step, fetched one step ahead for both possible directions: this lane's two
+    // vector-axis bytes (vector loads) and the step's 8 column bytes (one scalar load each, so they arrive wave-uniform)
+    int pf_qv = 0, pf_rv = 0;
+    unsigned long long pf_qc = 0, pf_rc = 0;
     bool pf_ok = false;   // the prefetched bytes serve the next step if it is a shift by 8 from where they were fetched
-    FastIO fs;
 #ifdef BA_TIMING
     unsigned long long prof[48] = {};
 #else
     unsigned long long* prof = nullptr;
 #endif
-
+    typedef const __attribute__((address_space(4))) unsigned long long* ConstU64;
+    __device__ __forceinline__ static unsigned long long load_cols(const uint8_t* p) {   // 8 sequence bytes at a 4-byte aligned position
+        return *(ConstU64)(uintptr_t)p;
+    }
     __device__ __forceinline__ void prefetch_seq(uint32_t si, uint32_t sj, uint32_t B) {
         const int lane = lane_id();
         pf_qv = *(const unsigned short*)(q + si + 2 * lane);
         pf_rv = *(const unsigned short*)(r + sj + 2 * lane);
-        pf_qc = q[si + B + (lane & 7)];
-        pf_rc = r[sj + B + (lane & 7)];
+        pf_qc = load_cols(q + si + B);
+        pf_rc = load_cols(r + sj + B);
         pf_ok = true;
     }
-    // While the block is a single chunk (<= 128 cells) the whole checkpoint is four VGPRs: a fast step parks its
-    // register images here instead of storing to memory (D_col, C_col, D_row, R_row order).
+    // While the block is a single chunk (<= 128 cells) the whole checkpoint is four VGPRs (D_col, C_col, D_row, R_row order):
+    // a fast run parks its border registers here instead of storing to memory.
     int ck_reg[4] = {0, 0, 0, 0};
     bool ck_in_regs = false;
-    __device__ __forceinline__ void save_ckpt_regs(bool right) {
-        ck_reg[0] = right ? fs.rAd : fs.rPd; ck_reg[1] = right ? fs.rAc : fs.rPr;
-        ck_reg[2] = right ? fs.rPd : fs.rAd; ck_reg[3] = right ? fs.rPr : fs.rAc;
-        ck_in_regs = true;
+
+    // A shift step is taken by the register path unless its columns could break early at the end of the matrix
+    // (scan_block.rs:1216-1224; never with X-drop): those go through place_rect, which implements the break.
+    __device__ __forceinline__ static bool fast_eligible(uint32_t ri, uint32_t B, uint32_t lenV) { return XDROP || ri + B <= lenV; }
+
+    enum { RUN_EXIT_POST = 0, RUN_EXIT_TOP = 1, RUN_EXIT_FATAL = 2 };
+    // A run of plain shift steps of a single-chunk block, borders in registers (see fast_rect). Entered with the first step
+    // already set up by the driver loop (off, off_add, corner); restates scan_block.rs:332-558 for the steps after which
+    // nothing but another shift follows, and hands the first step that needs more (exit = POST: its fill is done, `dir`,
+    // the returned maximum and `fo` describe it) or the first one it cannot take (exit = TOP) back to the driver loop.
+    struct RunState {   // the driver's loop-carried scalars, passed and returned by value (all wave-uniform)
+        uint32_t si, sj; int dir, prev_dir, off, prev_off, off_max, off_add, best_max; uint32_t y_drop_iter; int x_drop_iter, D_corner;
+        uint32_t step_budget; int run_exit; Best cur; FastOut fo;
+    };
+    __device__ __forceinline__ RunState fast_run(const RunState in, int corner, const uint32_t B, const uint32_t min_size, const uint32_t max_size) {
+        uint32_t si = in.si, sj = in.sj; int dir = in.dir, prev_dir = in.prev_dir, off = in.off, prev_off = in.prev_off, off_max = in.off_max;
+        int off_add = in.off_add, best_max = in.best_max; uint32_t y_drop_iter = in.y_drop_iter; int x_drop_iter = in.x_drop_iter, D_corner = in.D_corner;
+        uint32_t step_budget = in.step_budget; int run_exit = RUN_EXIT_POST; FastOut fo{};
+        constexpr int PR_DIST = (int)(lds_array_bytes_h(PMAX * 128) / 2);   // D_row -> R_row and D_col -> C_col, in entries
+        const int lane = lane_id();
+        const int nl = (int)(B >> 1);
+        int Dcol, Ccol, Drow, Rrow;
+        lds_sync();
+        Dcol = *(const int*)(L.D_col + 2 * lane); Ccol = *(const int*)(L.C_col + 2 * lane);
+        Drow = *(const int*)(L.D_row + 2 * lane); Rrow = *(const int*)(L.R_row + 2 * lane);
+        lds_sync();
+        // latest values of the driver state that only improving steps write (parked on the way out, if any step improved)
+        bool improved = false;
+        int n_best_i = 0, n_best_j = 0, n_ck_i = 0, n_ck_j = 0, n_ck_off = 0, n_ck_tt = 0, n_ck_nb = 0;
+        Best cur{0, 0, 0};
+        for (;;) {
+            const bool right = dir == DIR_RIGHT;
+            const uint8_t* seqV = right ? q : r; const uint8_t* seqC = right ? r : q;
+            const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + B - STEP;
+            // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
+            int vc; unsigned long long cb;
+            if (pf_ok) { vc = right ? pf_qv : pf_rv; cb = right ? pf_rc : pf_qc; }
+            else {
+                vc = 2 * lane < (int)B ? (int)*(const unsigned short*)(seqV + ri + 2 * lane) : 0;
+                cb = load_cols(seqC + rj);
+            }
+            // pin the consumption of the old prefetch here: the memory counter is in-order, so the next prefetch must be
+            // issued only after the wait for the previous one
+            asm volatile("" : "+v"(vc));
+            const uint32_t tb = trace_top;
+            if (TRACE) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
+                if (right) add_block(ri, rj, STEP, B, true);
+                else add_block(rj, ri, B, STEP, false);
+                if (status) { run_exit = RUN_EXIT_FATAL; break; }
+            }
+            uint32_t* tout = TRACE ? trace + tb : nullptr;
+#define BA_FAST(FULL) do { if (right) fast_rect<KIND, TRACE, XDROP, FULL, PR_DIST>(L.table, fc, Dcol, Ccol, Drow, Rrow, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, tout, fo); \
+                           else fast_rect<KIND, TRACE, XDROP, FULL, PR_DIST>(L.table, fc, Drow, Rrow, Dcol, Ccol, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, tout, fo); } while (0)
+            if (B == 128) BA_FAST(true); else BA_FAST(false);
+#undef BA_FAST
+            cells += (unsigned long long)(STEP * B);
+            prefetch_seq(si, sj, B);   // for the next step, behind this step's stores
+            cur = Best{fo.mx, fo.row, fo.col};
+
+            // ---- what does this step call for? (no driver state has been touched yet)
+            const int right_max = right ? fo.act_max8 : fo.pas_max8, down_max = right ? fo.pas_max8 : fo.act_max8;
+            const int mx = fo.mx;
+            const int new_off_max = off + mx - ZERO;
+            const bool improve = new_off_max > best_max;
+            const uint32_t new_y = improve ? 0u : y_drop_iter + 1;
+            const bool q_out = si + B > qlen, r_out = sj + B > rlen;
+            bool leave = q_out && r_out;                                                                      // end of the matrix
+            if (XDROP) leave = leave || (!improve && new_off_max < best_max - h_x_drop && x_drop_iter >= 1);   // X-drop termination
+            if (!q_out && !r_out) {
+                leave = leave || (2 * B <= max_size && new_y > B / STEP - 1);                                  // grow
+                if (B > min_size && new_y == 0) {                                                              // shrink (scan_block.rs:505-513)
+                    const s16x2 a = as_s(__builtin_amdgcn_readlane(Drow, nl - 1)), b = as_s(__builtin_amdgcn_readlane(Dcol, nl - 1));
+                    leave = leave || max(max((int)a.x, (int)a.y), max((int)b.x, (int)b.y)) >= mx;
+                }
+            }
+            if (leave) { run_exit = RUN_EXIT_POST; break; }
+
+            // ---- a plain step: scan_block.rs:332-450 without the grow / shrink / termination branches
+            off_max = new_off_max; y_drop_iter = new_y; prev_dir = dir; D_corner = fo.corner_new;
+            if (improve) {
+                improved = true;
+                if (XDROP) {   // scan_block.rs:370-404
+                    if (right) { n_best_i = (int)(si + (uint32_t)cur.row); n_best_j = (int)(sj + (B - STEP) + (uint32_t)cur.col); }
+                    else { n_best_i = (int)(si + (B - STEP) + (uint32_t)cur.col); n_best_j = (int)(sj + (uint32_t)cur.row); }
+                }
+                if (B < max_size) {   // checkpoint (scan_block.rs:406-427): four register copies
+                    n_ck_i = (int)si; n_ck_j = (int)sj; n_ck_off = off;
+                    ck_reg[0] = Dcol; ck_reg[1] = Ccol; ck_reg[2] = Drow; ck_reg[3] = Rrow; ck_in_regs = true;
+                    if (TRACE) { n_ck_tt = (int)trace_top; n_ck_nb = (int)nblocks; }
+                }
+                best_max = off_max;
+            }
+            if (XDROP) {
+                if (off_max < best_max - h_x_drop) x_drop_iter++;   // (the second consecutive hit left the run above; X_DROP_ITER = 2)
+                else x_drop_iter = 0;
+            }
+            const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
+            si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
+            dir = go_down ? DIR_DOWN : DIR_RIGHT;
+
+            // ---- set up the next step (what the top of the driver loop does)
+            if (!fast_eligible(dir == DIR_RIGHT ? si : sj, B, dir == DIR_RIGHT ? qlen : rlen)) { run_exit = RUN_EXIT_TOP; break; }
+            if (--step_budget == 0) { status |= ST_WATCHDOG; run_exit = RUN_EXIT_FATAL; break; }
+#ifdef BA_TIMING
+            prof[16]++;
+#endif
+            prev_off = off; off = off_max;
+            off_add = clamp16(prev_off - off);
+            corner = prev_dir != dir ? (int)as_s(adds(splat(D_corner), splat(off_add))).x : 0;
+        }
+        // borders back to LDS for the generic code
+        lds_sync();
+        if (lane < nl) {
+            *(int*)(L.D_col + 2 * lane) = Dcol; *(int*)(L.C_col + 2 * lane) = Ccol;
+            *(int*)(L.D_row + 2 * lane) = Drow; *(int*)(L.R_row + 2 * lane) = Rrow;
+        }
+        lds_sync();
+        if (improved) {
+            if (XDROP) { park<5>(parked, n_best_i); park<6>(parked, n_best_j); }
+            if (B < max_size) {
+                park<0>(parked, n_ck_i); park<1>(parked, n_ck_j); park<2>(parked, n_ck_off);
+                if (TRACE) { park<3>(parked, n_ck_tt); park<4>(parked, n_ck_nb); }
+            }
+        }
+        RunState out;
+        out.si = si; out.sj = sj; out.dir = dir; out.prev_dir = prev_dir; out.off = off; out.prev_off = prev_off; out.off_max = off_max;
+        out.off_add = off_add; out.best_max = best_max; out.y_drop_iter = y_drop_iter; out.x_drop_iter = x_drop_iter; out.D_corner = D_corner;
+        out.step_budget = step_budget; out.run_exit = run_exit; out.cur = cur; out.fo = fo;
+        return out;
     }
 
     __device__ __forceinline__ Aligner(const BatchParams& b, const WaveLds& L_, const FillConsts& fc_) : L(L_), fc(fc_) {
@@ -654,34 +783,11 @@ struct Aligner {
             }
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
             BA_TSTAMP(tsa);
-            const bool fast = KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special;
-            const bool pf_hit = pf_ok;   // only a fast step that ends in a plain shift leaves usable prefetched bytes behind
-            pf_ok = false;
-            if (fast) {   // before any store of this step: the memory counter is in-order
-                // sequence bytes: prefetched by the previous step if it predicted this position, else fetched now
-                const int lane = lane_id();
-                const bool hit = pf_hit;
-#ifdef BA_TIMING
-                {   // how long does the step wait for its (prefetched) sequence bytes, i.e. for everything older in the in-order counter?
-                    const unsigned long long tv0 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    prof[18] += __builtin_amdgcn_s_memtime() - tv0; prof[19] += hit ? 1 : 0;
-                }
-#endif
-                int vc;
-                if (hit) { vc = right ? pf_qv : pf_rv; fs.col_chars = right ? pf_rc : pf_qc; }
-                else {
-                    vc = 2 * lane < (int)rh ? (int)*(const unsigned short*)(seqV + ri + 2 * lane) : 0;
-                    fs.col_chars = seqC[rj + (lane & 7)];
-                }
-                fs.vec_a = vc & 0xff; fs.vec_b = (vc >> 8) & 0xff;
-                // pin the consumption of the old prefetch here: the memory counter is in-order, so the next prefetch
-                // must be issued only after the wait for the previous one
-                asm volatile("" : "+v"(fs.vec_a), "+v"(fs.vec_b), "+v"(fs.col_chars));
-            }
+            const bool fast = KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV);
+            if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
-            if (TRACE) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
+            if (TRACE && !fast) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
                 if (right) add_block(ri, rj, rw, rh, true);
                 else add_block(rj, ri, rh, rw, false);
                 if (status) break;
@@ -691,20 +797,26 @@ struct Aligner {
             BA_TSTAMP(ts1);
             BA_TADD(prof, 32, ts0, tsa); BA_TADD(prof, 33, tsa, tsb); BA_TADD(prof, 34, tsb, ts1);
             Best cur{0, 0, 0};
+            FastOut fo{}; int run_exit = RUN_EXIT_POST;
             const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
 #define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
 #define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
             if (fast) {
                 if constexpr (KIND != KIND_PROFILE) {
-                    fs.Pd = right ? L.D_row : L.D_col; fs.Pr = right ? L.R_row : L.C_col;
-                    // entries 160.. of the active border array are beyond any block the fast path handles (<= 128 + 16) and
-                    // are rewritten by a grow before anything reads them; the array has them from the 256-cell class on
-                    fs.sink = PMAX >= 2 ? Dc + 160 : nullptr;
-                    if (rh == 128) cur = place_rect<1, KIND, TRACE, XDROP, true, 0, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
-                                                                                           off_add, tout, cells, &fs, prof);
-                    else cur = place_rect<1, KIND, TRACE, XDROP, true>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz,
-                                                                       off_add, tout, cells, &fs, prof);
-                    prefetch_seq(si, sj, block_size);   // for the next step, behind this step's stores
+                    // ---- a run of plain shift steps with the four borders in registers (fast_rect). The run ends -- with the last
+                    // step's results handed to the generic post-processing below -- as soon as a step calls for anything but
+                    // another shift: X-drop termination, the end of the matrix, a grow, a shrink, an early column break.
+                    RunState rs;
+                    rs.si = si; rs.sj = sj; rs.dir = dir; rs.prev_dir = prev_dir; rs.off = off; rs.prev_off = prev_off; rs.off_max = off_max;
+                    rs.off_add = off_add; rs.best_max = best_max; rs.y_drop_iter = y_drop_iter; rs.x_drop_iter = x_drop_iter; rs.D_corner = D_corner;
+                    rs.step_budget = step_budget; rs.run_exit = RUN_EXIT_POST; rs.cur = cur; rs.fo = fo;
+                    rs = fast_run(rs, corner, block_size, min_size, max_size);
+                    si = rs.si; sj = rs.sj; dir = rs.dir; prev_dir = rs.prev_dir; off = rs.off; prev_off = rs.prev_off; off_max = rs.off_max;
+                    off_add = rs.off_add; best_max = rs.best_max; y_drop_iter = rs.y_drop_iter; x_drop_iter = rs.x_drop_iter; D_corner = rs.D_corner;
+                    step_budget = rs.step_budget; run_exit = rs.run_exit; cur = rs.cur; fo = rs.fo;
+                    right = dir == DIR_RIGHT;
+                    if (run_exit == RUN_EXIT_TOP) continue;     // the next step is not a fast one: back to the top with dir / si / sj set
+                    if (run_exit == RUN_EXIT_FATAL) break;
                 }
             }
             else if (rh <= 128) BA_PLACE(1);
@@ -725,9 +837,9 @@ struct Aligner {
             // ---- the rest of the driver step
             int right_max, down_max;
             if (fast) {
-                right_max = right ? fs.act_max8 : fs.pas_max8;
-                down_max = right ? fs.pas_max8 : fs.act_max8;
-                D_corner = fs.corner_new;
+                right_max = right ? fo.act_max8 : fo.pas_max8;
+                down_max = right ? fo.pas_max8 : fo.act_max8;
+                D_corner = fo.corner_new;
             } else if (dir == DIR_RIGHT) {
                 right_max = lds_prefix_max8(L.D_col);
                 D_corner = lds_shift_and_offset(block_size, L.D_row, L.R_row, temp1, temp2, off_add);
@@ -771,8 +883,7 @@ struct Aligner {
                 }
                 if (block_size < max_size) {
                     park<0>(parked, (int)si); park<1>(parked, (int)sj); park<2>(parked, off);
-                    if (fast) save_ckpt_regs(this_dir == DIR_RIGHT);
-                    else save_ckpt_borders(block_size);
+                    save_ckpt_borders(block_size);   // (a fast run has put the borders back into LDS before handing its last step over)
                     if (TRACE) { park<3>(parked, (int)trace_top); park<4>(parked, (int)nblocks); }
                     grow_no_max = false;
                 }
