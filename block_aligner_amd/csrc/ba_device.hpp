@@ -120,6 +120,12 @@ __device__ __forceinline__ int eq01(int a, int b, int ones) {
     asm("v_pk_sub_u16 %0, %1, %2\n\tv_pk_sub_u16 %0, 1, %0 op_sel_hi:[0,1] clamp" : "=&v"(t) : "v"(a), "v"(b));
     return t;
 }
+// bit 15 of each half (the sign of a 16-bit lane), everything else cleared; the literal form keeps it a 2-cycle VOP2
+__device__ __forceinline__ int sign_bits(int x) {
+    int t;
+    asm("v_and_b32_e32 %0, 0x80008000, %1" : "=v"(t) : "v"(x));
+    return t;
+}
 __device__ __forceinline__ int pk_mul(int a, int m) {
     int t;
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(a), "s"(m));
@@ -171,13 +177,25 @@ __device__ __forceinline__ int first8_max(int v) {
     return __builtin_amdgcn_readlane(m, 0);
 }   // rect max (i16 value) and, for X-drop, its resolved location
 
+// max of the first 8 entries of two packed border registers at once (scan_block.rs:1020-1022 for both borders): the two
+// per-lane maxima share one register (a: low half, b: high half) for the reduction over lanes 0..3
+__device__ __forceinline__ void first8_max2(int a, int b, int& ma, int& mb) {
+    const s16x2 sa = as_s(a), sb = as_s(b);
+    const int xa = vmax(a, as_i(s16x2{sa.y, sa.x})), xb = vmax(b, as_i(s16x2{sb.y, sb.x}));   // both halves = max(lo, hi)
+    int m = __builtin_amdgcn_perm(xb, xa, 0x05040100);        // {xa.lo, xb.lo}
+    m = vmax(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+    m = vmax(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+    const s16x2 r = as_s(__builtin_amdgcn_readlane(m, 0));
+    ma = r.x; mb = r.y;
+}
 // loop-invariant per-lane / per-kernel values
 struct FillConsts {
     int go2, ge2, ome2;       // splat(gap_open), splat(gap_extend), splat(open (-) extend)
     int g12;                  // {g, 2g}
     int ones;                 // 0x00010001
-    int laneKG, lanem1KG;     // lane * 2g; (lane - 1) * 2g, except lane 0 which holds a large negative (no lane above)
+    int laneKG, lanem1KG;     // lane * 2g; (lane - 1) * 2g, except lane 0 which holds -32768 (no lane above: a candidate that never wins)
     int vconst;               // scan artefact constants of this lane's two cells (avx2.rs:315-338)
+    int vconst_top;           // single-chunk columns: max(vconst, (cell + 1) g), i.e. with the MIN = 0 carry above the column folded in
     int gap_extend;
 };
 
@@ -265,20 +283,21 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
         const s16x2 t2 = as_s(adds(x, fc.ge2));
         int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
         const int pm = wave_prefix_max((int)as_s(r).y - fc.laneKG);
-        int cin = add_shr1(pm, fc.lanem1KG);
-        cin = max(max(cin, fc.laneKG), -32768);      // the carry above the column is MIN = 0
-        const s16x2 cs = as_s(cin);
-        r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst);
+        // what the lanes above contribute. No clamp: lane l >= 1 receives pm[l-1] + (l-1) 2g >= R(lane l-1) >= -32768, lane 0 the
+        // filler -32768; the carry from above the column (MIN = 0, decaying by g per cell) is folded into the per-cell constant
+        const s16x2 cs = as_s(add_shr1(pm, fc.lanem1KG));
+        r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst_top);
         const int dn = vmax(d11, r);
         if (TRACE) {
-            const int nC = neq01(dn, cn, fc.ones), nR = neq01(dn, r, fc.ones);
-            const int nCo = neq01(cn, copen, fc.ones), eRo = eq01(r, x, fc.ones);
-            int nib = pk_mad_k<2>(nR, nC);
-            nib = pk_mad_k<4>(nCo, nib);
-            nib = pk_mad_k<8>(eRo, nib);
-            tacc |= nib << ((j & 3) * 4);
+            // the four flags of a cell (D != C, D != R, C != C_open, R != D_open): each is "left side greater", i.e. the sign of
+            // a saturating difference; the sign bits of both halves go into the step's trace word with 32-bit logic ops
+            // (2-cycle VOP2 forms on gfx950, profiles/r02_valu_rate.md): nibble = nC | nR << 1 | nCo << 2 | nRo << 3
+            const int fC = sign_bits(subs(cn, dn)), fR = sign_bits(subs(r, dn));
+            const int fCo = sign_bits(subs(copen, cn)), fRo = sign_bits(subs(x, r));
+            const uint32_t nib = (uint32_t)fRo | ((uint32_t)fCo >> 1) | ((uint32_t)fR >> 2) | ((uint32_t)fC >> 3);   // bits 15..12 / 31..28
+            tacc = (int)(((uint32_t)tacc >> 4) | nib);                                                               // column j ends up in bits 4j .. 4j+3
             if ((j & 3) == 3) {   // (unpredicated: lanes beyond a small block write words that a later store covers, or the slot's slack)
-                trace_out[(j >> 2) * nl + lane] = (uint32_t)tacc;
+                trace_out[(uint32_t)((j >> 2) * nl + lane)] = (uint32_t)tacc;
                 tacc = 0;
             }
         }
@@ -291,8 +310,7 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
     lds_fence();
     Pd = *(const int*)(Pl + 2 * lane + STEP); Pr = *(const int*)(Pl + PR_DIST + 2 * lane + STEP);   // shift_and_offset (scan_block.rs:1040-1061)
     Ad = d; Ac = c;
-    o.act_max8 = first8_max(d);
-    o.pas_max8 = first8_max(Pd);
+    first8_max2(d, Pd, o.act_max8, o.pas_max8);
     if (XDROP) {
         // one reduction for value and location: value (>= 0: D_max starts at MIN = 0) | 15 - row % 16 | last column + 1 | row
         int best = 0;
@@ -525,13 +543,13 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             const int dn = vmax(d11, rend);
             if (TRACE) {
                 const int nC = neq01(dn, cend, fc.ones), nR = neq01(dn, rend, fc.ones);
-                const int nCo = neq01(cn, copen, fc.ones), eRo = eq01(r, x, fc.ones);
-                // "R opened" (R == D_open) is stored with the cell it was computed in; the reference shifts it to the cell
+                const int nCo = neq01(cn, copen, fc.ones), nRo = neq01(r, x, fc.ones);
+                // "R opened" (R == D_open; stored as "differs" like the other three) stays with the cell it was computed in; the reference shifts it to the cell
                 // below (scan_block.rs:1179-1182) -- the traceback resolves it at the destination of the gap move instead,
                 // which saves the lane shift here and the carry between chunks
                 int nib = pk_mad_k<2>(nR, nC);
                 nib = pk_mad_k<4>(nCo, nib);
-                nib = pk_mad_k<8>(eRo, nib);
+                nib = pk_mad_k<8>(nRo, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
                 if (!FAST && (sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
                     trace_out[zwords + (j * NCH + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);

@@ -125,7 +125,7 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             const uint32_t chunk = v >> 7, lane = (v & 127) >> 1;
             if (right_blk && fqs && i == 0) { stop = true; break; }                     // scan_block.rs:1597-1599
             const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
-            const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;   // bits 0-2 stored as "differs", bit 3 as "equal"
+            const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;   // all four bits are stored as "differs"
             table = tb_resolve(right_blk, table, nib);
             if (local && table == 0) {                                                   // scan_block.rs:1604-1611
                 const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
@@ -279,7 +279,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
             const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
             const uint32_t byte = lrec[alive ? gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1) : 0u];
             const uint32_t qb = lrec[40 + (qo & 15u)], rb = lrec[56 + (ro & 15u)];          // for a match at this cell (read alongside, used if needed)
-            const uint32_t nib = ((byte >> ((w & 1) * 4)) ^ 7u) & 15u;                      // bits 0-2 "differs", bit 3 "equal"
+            const uint32_t nib = ((byte >> ((w & 1) * 4)) ^ 15u) & 15u;                      // all four bits stored as "differs"
             const uint32_t table = tb_resolve(t.right, t.table, nib);
             const uint32_t m = lut[((uint32_t)t.right << 6) | (table << 4) | nib];          // op | di << 3 | dj << 4 | next << 5
             uint32_t op = m & 7u;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         if (local) {   // no window in this mode: one cell per call
             if (!(s == 0 && fresh)) break;
             const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
-            nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 7u) & 15u;
+            nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;
             t.table = tb_resolve(t.right, t.table, nib);
             if (t.table == 0) {   // zero mask (scan_block.rs:1604-1611)
                 const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
@@ -320,7 +320,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
             const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
             if ((v >> 7) != t.tw_chunk || gi > 1u || k > 4u) break;                     // left the window: next call reloads it
             const uint32_t byte = lrec[gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1)];
-            nib = ((byte >> ((w & 1) * 4)) ^ 7u) & 15u;                                 // bits 0-2 "differs", bit 3 "equal"
+            nib = ((byte >> ((w & 1) * 4)) ^ 15u) & 15u;                                 // all four bits stored as "differs"
             t.table = tb_resolve(t.right, t.table, nib);
         }
         const uint32_t m = lut[((uint32_t)t.right << 6) | (t.table << 4) | nib];        // op | di << 3 | dj << 4 | next << 5
@@ -1025,7 +1025,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
         fc.go2 = splat(bp.gap_open); fc.ge2 = splat(g); fc.ome2 = splat(clamp16(bp.gap_open - g));   // (scalar arithmetic: stays in an SGPR)
         fc.g12 = pk(g, 2 * g);
         fc.ones = 0x00010001;
-        fc.laneKG = lane * 2 * g; fc.lanem1KG = lane ? (lane - 1) * 2 * g : -(1 << 29);
+        fc.laneKG = lane * 2 * g; fc.lanem1KG = lane ? (lane - 1) * 2 * g : -32768;
         // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 of each
         // 16-cell vector see a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
         int v[2];
@@ -1035,6 +1035,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             v[h] = mult ? max(-32768, mult * g) : -32768;
         }
         fc.vconst = pk(v[0], v[1]);
+        fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * g)), max(v[1], max(-32768, (2 * lane + 2) * g)));
     }
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;

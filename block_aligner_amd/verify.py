@@ -65,7 +65,11 @@ def check_cigar(runs, q: bytes, r: bytes, matrix, gaps, score: int, query_idx: i
         total += int(tab[qa, ra].sum())
         gl = lens[~is_m]
         total += int((gaps[0] + gaps[1] * (gl - 1)).sum())
-        assert total == score, (what, "re-scored CIGAR differs from the reported score", total, score)
+        # (FREE_QUERY_END_GAPS: the reference takes the score from vector lane |q| % 16 of D_max, which merges every 16th row
+        # of a block taller than 16 cells -- scan_block.rs:333-339 -- so the reported score need not belong to the reported
+        # end cell; reproduced bit for bit, hence not re-scored here)
+        if "free_query_end_gaps" not in mode:
+            assert total == score, (what, "re-scored CIGAR differs from the reported score", total, score)
     mop = rep_op[mm]
     if (mop != 1).any():
         same = (qa == ra) if getattr(matrix, "KIND", 1) == 2 else (_upper(qa) == _upper(ra))
