@@ -92,7 +92,33 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
         : "+v"(v));
     return v;
 }
+// the same scan when only the first 16 / 32 lanes hold cells (blocks of 32 / 64 cells): four / five steps
+__device__ __forceinline__ int wave_prefix_max16(int v) {
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int wave_prefix_max32(int v) {
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+template <int LANES>   // 16, 32 or 64 lanes hold cells
+__device__ __forceinline__ int prefix_max_lanes(int v) { return LANES == 16 ? wave_prefix_max16(v) : (LANES == 32 ? wave_prefix_max32(v) : wave_prefix_max(v)); }
 __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_prefix_max(v), 63); }
+template <int LANES>
+__device__ __forceinline__ int max_lanes(int v) { return __builtin_amdgcn_readlane(prefix_max_lanes<LANES>(v), LANES - 1); }
 __device__ __forceinline__ int wave_min(int v) { return -wave_max(-v); }
 
 __device__ __forceinline__ s16x2 as_s(int x) { return __builtin_bit_cast(s16x2, x); }
@@ -248,12 +274,16 @@ __device__ __forceinline__ int load_pair_i16(const short* p) { int v; __builtin_
 // column's last cell unpredicated; only the last lane's address is the real one).
 struct FastOut { int mx, row, col; int act_max8, pas_max8, corner_new; };
 
-template <int KIND, bool TRACE, bool XDROP, bool FULL128, int PR_DIST>
+// LANES: 64 / 32 / 16 = the block is exactly 128 / 64 / 32 cells (lane count, activity tests, trace indices and the depth of
+// the scan are then compile-time); 0 = any single-chunk size (nl_in lanes).
+template <int KIND, bool TRACE, bool XDROP, int LANES, int PR_DIST>
 __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& fc, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
-                                          int vec_a, int vec_b, unsigned long long colbytes, int nl_in, int corner, int off_add,
+                                          int vec_a, int vec_b, unsigned long long colbytes, int nl_in, int corner, int off_add, int loc_thr,
                                           uint32_t* __restrict__ trace_out, FastOut& o) {
     const int lane = lane_id();
-    const int nl = FULL128 ? 64 : nl_in;             // active lanes = block size / 2
+    constexpr bool FULL128 = LANES == 64;
+    constexpr int SCAN = LANES ? LANES : 64;
+    const int nl = LANES ? LANES : nl_in;            // active lanes = block size / 2
     const bool active = FULL128 ? true : lane < nl;
     const int offa = splat(off_add);
     int d = adds(Ad, offa), c = adds(Ac, offa);      // just_offset (scan_block.rs:1003-1012)
@@ -263,7 +293,8 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
     // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based (scan_block.rs:1042)
     o.corner_new = __builtin_amdgcn_readlane(pd, 3) >> 16;
     const ScoreKey<KIND> key = make_key<KIND>(vec_a, vec_b);
-    int dmax = 0, jlast = 0, tacc = 0;
+    int dmax = 0, tacc = 0;
+    int dcol[STEP];                                  // X-drop: D of every column, kept for the (lazy) location of the maximum
     const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
     short* last_base = last_lane ? Pl + 2 * nl : sink + lane;
     int sc_next = fetch_score<KIND>(table, key, (int)(colbytes & 0xff));
@@ -282,7 +313,7 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
         const int x = adds(d11, fc.ome2);            // D11_open
         const s16x2 t2 = as_s(adds(x, fc.ge2));
         int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
-        const int pm = wave_prefix_max((int)as_s(r).y - fc.laneKG);
+        const int pm = prefix_max_lanes<SCAN>((int)as_s(r).y - fc.laneKG);
         // what the lanes above contribute. No clamp: lane l >= 1 receives pm[l-1] + (l-1) 2g >= R(lane l-1) >= -32768, lane 0 the
         // filler -32768; the carry from above the column (MIN = 0, decaying by g per cell) is folded into the per-cell constant
         const s16x2 cs = as_s(add_shr1(pm, fc.lanem1KG));
@@ -302,7 +333,7 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
             }
         }
         dmax = vmax(dmax, dn);
-        if (XDROP) jlast = vmaxu(jlast, pk_mul(eq01(dmax, dn, fc.ones), splat(j + 1)));
+        dcol[j] = dn;
         d = dn; c = cn;
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
         last_base[j] = (short)(d >> 16); last_base[PR_DIST + j] = (short)(r >> 16);
@@ -312,26 +343,36 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
     Ad = d; Ac = c;
     first8_max2(d, Pd, o.act_max8, o.pas_max8);
     if (XDROP) {
-        // one reduction for value and location: value (>= 0: D_max starts at MIN = 0) | 15 - row % 16 | last column + 1 | row
-        int best = 0;
+        // Rectangle maximum (every half of dmax is >= 0: D_max starts at MIN = 0). Its location -- among the cells equal to
+        // the maximum: smallest row % 16, then largest column, then largest row (avx2.rs:271-274 with the last-writer-wins
+        // bookkeeping of scan_block.rs:1198-1200) -- only matters if the step raises the best score (loc_thr = the
+        // rectangle maximum that ties it), and is then found from the kept columns with lane masks on the scalar side.
+        int m32 = max(dmax & 0xffff, (int)((uint32_t)dmax >> 16));
+        if (!active) m32 = 0;
+        const int M = max_lanes<SCAN>(m32);
+        o.mx = M; o.row = 0; o.col = 0;
+        if (M > loc_thr) {
+            const unsigned long long act = FULL128 ? ~0ull : ((1ull << nl) - 1ull);
+            const unsigned long long RL = __ballot((dmax & 0xffff) == M) & act, RH = __ballot((int)((uint32_t)dmax >> 16) == M) & act;
+            auto fold8 = [](unsigned long long x) { uint32_t f = (uint32_t)x | (uint32_t)(x >> 32); f |= f >> 16; f |= f >> 8; return f & 0xffu; };
+            const uint32_t fL = fold8(RL), fH = fold8(RH);   // bit c: a row 2 (c + 8 m) [+ 1] reaches the maximum
+            const uint32_t kL = fL ? 2u * (uint32_t)__builtin_ctz(fL) : 99u, kH = fH ? 2u * (uint32_t)__builtin_ctz(fH) + 1u : 99u;
+            const uint32_t k = min(kL, kH);                  // smallest row % 16 among the rows that reach the maximum
+            const uint32_t h = k & 1u;
+            const unsigned long long rows = (h ? RH : RL) & (0x0101010101010101ull << (k >> 1));
+            bool found = false;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int v = h ? (int)as_s(dmax).y : (int)as_s(dmax).x;
-            const int jl1 = h ? (jlast >> 16) & 0xffff : jlast & 0xffff;
-            const int row = 2 * lane + h;
-            best = max(best, (v << 15) | ((15 - (row & 15)) << 11) | (jl1 << 7) | row);
+            for (int j = STEP - 1; j >= 0; j--) {            // the last column in which one of those rows holds the maximum; its largest row
+                if (!found) {
+                    const unsigned long long cm = (h ? __ballot((int)((uint32_t)dcol[j] >> 16) == M) : __ballot((dcol[j] & 0xffff) == M)) & rows;
+                    if (cm) { o.col = j; o.row = 2 * (63 - __builtin_clzll(cm)) + (int)h; found = true; }
+                }
+            }
         }
-        if (!active) best = 0;
-        best = wave_max(best);
-        o.mx = best >> 15;
-        const int jl1 = (best >> 7) & 15;
-        o.col = jl1 ? jl1 - 1 : 0;
-        o.row = best & 127;
-        if (o.mx == 0 && jl1 == 0) o.row = 0;   // no cell equalled the max (the initial MIN): lane 0 / column 0 / vector 0
     } else {
         int lm = max((int)as_s(dmax).x, (int)as_s(dmax).y);
         if (!active) lm = -32768;
-        o.mx = wave_max(lm); o.row = 0; o.col = 0;
+        o.mx = max_lanes<SCAN>(lm); o.row = 0; o.col = 0;
     }
 }
 

@@ -547,9 +547,10 @@ struct Aligner {
                 if (status) { run_exit = RUN_EXIT_FATAL; break; }
             }
             uint32_t* tout = TRACE ? trace + tb : nullptr;
-#define BA_FAST(FULL) do { if (right) fast_rect<KIND, TRACE, XDROP, FULL, PR_DIST>(L.table, fc, Dcol, Ccol, Drow, Rrow, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, tout, fo); \
-                           else fast_rect<KIND, TRACE, XDROP, FULL, PR_DIST>(L.table, fc, Drow, Rrow, Dcol, Ccol, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, tout, fo); } while (0)
-            if (B == 128) BA_FAST(true); else BA_FAST(false);
+            const int loc_thr = best_max - off + ZERO;   // a rectangle maximum above this raises the best score: its location is needed
+#define BA_FAST(LANES) do { if (right) fast_rect<KIND, TRACE, XDROP, LANES, PR_DIST>(L.table, fc, Dcol, Ccol, Drow, Rrow, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, loc_thr, tout, fo); \
+                           else fast_rect<KIND, TRACE, XDROP, LANES, PR_DIST>(L.table, fc, Drow, Rrow, Dcol, Ccol, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, loc_thr, tout, fo); } while (0)
+            if (B == 128) BA_FAST(64); else if (B == 32) BA_FAST(16); else if (B == 64) BA_FAST(32); else BA_FAST(0);
 #undef BA_FAST
             cells += (unsigned long long)(STEP * B);
             prefetch_seq(si, sj, B);   // for the next step, behind this step's stores
