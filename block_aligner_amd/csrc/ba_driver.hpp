@@ -683,18 +683,27 @@ struct Aligner {
         lds_sync();
     }
 
-    // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done).
+    // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done). The wait only
+    // gives up when the traceback side as a whole has stopped making progress: no task claimed for ~2 s, scaled by the
+    // batch's longest pair (a walk over a multi-Mbp pair alone takes seconds).
     __device__ __forceinline__ bool acquire_slot(uint32_t slot) {
-        for (uint32_t spins = 0; spins < (1u << 21); spins++) {   // ~4 s
-            uint32_t f = 0;
-            if (is_lane(0)) f = __hip_atomic_load(coldp()->slot_free + slot, BA_RLX_AGENT);
+        uint32_t seen = 0, idle = 0;
+        const uint32_t limit = (1u << 20) * (1u + (uint32_t)(coldp()->blocks_stride >> 15));
+        for (;;) {
+            uint32_t f = 0, head = 0;
+            if (is_lane(0)) {
+                f = __hip_atomic_load(coldp()->slot_free + slot, BA_RLX_AGENT);
+                head = __hip_atomic_load(coldp()->tb_ctrl + 32, BA_RLX_AGENT);
+            }
             if (uni((int)f)) {
                 if (is_lane(0)) __hip_atomic_store(coldp()->slot_free + slot, 0u, BA_RLX_AGENT);
                 return true;
             }
+            head = (uint32_t)uni((int)head);
+            if (head != seen) { seen = head; idle = 0; }
+            else if (++idle > limit) return false;
             __builtin_amdgcn_s_sleep(64);
         }
-        return false;
     }
     // Publish a finished trace stack: plain stores -> release fence -> drained -> queue entry (guide G16 flag form).
     __device__ __forceinline__ void hand_off(uint32_t slot, uint32_t pair, uint32_t end_i, uint32_t end_j, bool null_task = false) {

@@ -150,15 +150,18 @@ struct AAProfile {     // scores.rs:452-468
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool owned = true;
+    void view(void* q, size_t n) { free_(); p = q; bytes = n; owned = false; }   // a window into another buffer
     int alloc(size_t n) {
         free_();
+        owned = true;
         if (n == 0) n = 4;
         hipError_t e = hipMalloc(&p, n);
         if (e != hipSuccess) { p = nullptr; return fail("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e)); }
         bytes = n;
         return 0;
     }
-    void free_() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void free_() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; }
     ~DevBuf() { free_(); }
     template <class T> T* as() const { return (T*)p; }
 };
@@ -179,6 +182,8 @@ struct BaBatch {
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1, tb_reserve = 0;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false, in_flight = false;
+    bool handle_mode = false;   // the device state of one Block handle: one pair per launch, CIGARs only on request (k_traceback)
+    DevBuf hblk, rblk;          // handle mode: everything uploaded per align / everything read back, one buffer each
     BatchParams params() const {
         BatchParams bp{};
         bp.pool = pool.as<uint8_t>();
@@ -188,7 +193,7 @@ struct BaBatch {
         bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (getenv("BA_NO_FAST") ? 0x100u : 0u) | (getenv("BA_SKIP_WALK") ? 0x200u : 0u);
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
-        bp.cig_ops = ((mode & BA_TRACE) && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
+        bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
         bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
         bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>(); bp.trace_words_out = trace_words.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
@@ -224,6 +229,7 @@ static int check_align_params(bool profile, Gaps g, size_t min_size, size_t max_
     return 0;
 }
 
+constexpr size_t BA_MAX_BLOCK = 2048;
 static int pclass_of(size_t max_size) {   // index into {1,2,4,8,16} packed registers per lane
     if (max_size <= 128) return 0;
     if (max_size == 256) return 1;
@@ -252,6 +258,7 @@ static void profile_image(const AAProfile* pr, uint32_t P, uint8_t* dst) {
 }
 struct NoProfiles { const AAProfile* operator()(size_t) const { return nullptr; } };
 
+constexpr size_t POOL_SLACK = 256;
 struct Packed {   // host-side packing of a set of pairs: padded images + the per-pair arrays the kernels read
     std::vector<uint64_t> qo, ro, cig_off;
     std::vector<uint32_t> ql, rl;
@@ -315,7 +322,7 @@ static int pack_pairs_in_order(int kind, Gaps gaps, size_t min_size, size_t max_
         cig_total += (uint64_t)ql[p] + rl[p] + 1;
     }
     cig_off[n] = cig_total;
-    total += 64;
+    total += POOL_SLACK;   // behind the last image: the kernels read whole 128-byte rows of a block unpredicated (prefetch_seq)
     lap("offsets");
     P.total = total; P.maxlen2 = maxlen2; P.cig_total = cig_total; P.pad = (uint32_t)pad;
     // One dense host buffer (the pooled batch calls): ship it as it is, pad and convert on the device. Scattered or
@@ -399,7 +406,7 @@ static int upload_images(BaBatch* b, const Packed& P, size_t n) {
     HIP_TRY(hipMemcpy(raw_q.p, P.raw_qo.data(), n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(raw_r.p, P.raw_ro.data(), n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(err.p, 0xff, 8));
-    HIP_TRY(hipMemset((uint8_t*)b->pool.p + P.total - 64, null_byte(b->kind), 64));   // slack behind the last image
+    HIP_TRY(hipMemset((uint8_t*)b->pool.p + P.total - POOL_SLACK, null_byte(b->kind), POOL_SLACK));   // slack behind the last image
     HIP_TRY(ba_launch_pack_sequences(b->stream, seq_kind(b->kind), raw.as<uint8_t>(), raw_q.as<uint64_t>(), raw_r.as<uint64_t>(),
                                      b->q_off.as<uint64_t>(), b->q_len.as<uint32_t>(), b->r_off.as<uint64_t>(), b->r_len.as<uint32_t>(),
                                      b->pool.as<uint8_t>(), P.pad, (uint32_t)n, err.as<unsigned long long>()));
@@ -433,7 +440,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (profile && (mode & BA_CIGAR_EQ)) { fail("=/X CIGARs need two sequences; a profile alignment has none to compare"); return nullptr; }
     if (kind == BA_KIND_BYTES && (mode & BA_X_DROP)) { /* allowed by the reference, documented as inaccurate (scores.rs:235-239) */ }
     const int pc = pclass_of(max_size);
-    if (pc < 0) { fail("max block size %zu not supported by the HIP backend (16..2048)", max_size); return nullptr; }
+    if (pc < 0) { fail("max block size %zu not supported by the HIP backend (16..%zu)", max_size, (size_t)BA_MAX_BLOCK); return nullptr; }
     if (n == 0 || n > 0x7fffffffu) { fail("batch must hold between 1 and 2^31-1 pairs"); return nullptr; }
 
     std::unique_ptr<BaBatch> b(new BaBatch);
@@ -599,11 +606,13 @@ static int batch_launch(BaBatch* b) {
     if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");
     if (b->n == 0) return fail("the batch holds no pairs (its last reload failed)");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
-    HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
-    HIP_TRY(hipMemsetAsync(b->prof.p, 0, 512, b->stream));
-    HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
-    HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
+    if (!b->handle_mode) {   // (a handle's work counter arrives zeroed with its upload; it has no hand-off structures)
+        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+        HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
+        HIP_TRY(hipMemsetAsync(b->prof.p, 0, 512, b->stream));
+        HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
+        HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
+    }
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     HIP_TRY(g_launch[special_of(b->mode)][b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
@@ -654,6 +663,14 @@ int ba_set_device(int device) {
     if (device < 0 || device >= n) return fail("device %d out of range (%d devices)", device, n);
     g_device = device;
     HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+int ba_device_memory(uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (ensure_device()) return 1;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return 0;
 }
 uintptr_t block_percent_len(uintptr_t len, float p) {   // lib.rs:109-111
@@ -976,17 +993,138 @@ int block_batch_align_profile_exp(const AAProfile* const* profiles, SizeRange si
 }  // extern "C"
 
 // ------------------------------------------------------------------ Block handles (Part 1 + generic)
+// Like the reference's Block (scan_block.rs:798-805, 1280-1340: Block::new allocates, align never does), a handle owns its
+// device state from creation: stream, events, the two image slots, one trace slot, the rectangle list, the CIGAR buffer
+// and the checkpoint scratch, sized for any pair with |q| + |r| <= query_len + reference_len and any block size up to
+// max_size. An align uploads one buffer (images + the per-pair words), launches one workgroup and reads one 64-byte
+// record back; nothing is allocated or freed.
+struct HandleUpload {   // head of BaBatch::hblk; the images follow at `images`
+    uint64_t q_off, r_off, cig_off[2];
+    uint32_t q_len, r_len, work_counter, pad_;
+    static constexpr size_t images = 64;
+};
+struct HandleResult {   // BaBatch::rblk
+    int32_t score; uint32_t query_idx, reference_idx, cig_len, status, nblocks, slot, trace_words;
+    unsigned long long cells; uint32_t pad_[6];
+};
+static_assert(sizeof(HandleUpload) <= HandleUpload::images && sizeof(HandleResult) == 64, "handle records");
+
 struct BlockImpl {
     uint32_t mode;                 // BA_TRACE | BA_X_DROP | ...
     size_t query_len, reference_len, max_size;   // upper bounds from Block::new (scan_block.rs:798-805)
     AlignResult res{0, 0, 0};
-    std::unique_ptr<BaBatch> last;               // device state of the latest align (trace stack for later cigar calls)
+    std::unique_ptr<BaBatch> dev;                // persistent device state (created with the handle when a device is usable)
+    std::vector<uint8_t> staging;                // host image of hblk
+    uint32_t last_ql = 0, last_rl = 0, last_nblocks = 0, last_slot = 0;
+    bool aligned = false;
 };
+
+static uint64_t handle_trace_stride(size_t max_size, uint64_t maxlen2, uint32_t mode) {   // Trace::new's bound, scan_block.rs:1363-1366 (+ zero mask, + slack)
+    return (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) + 64;
+}
+
+// Allocate a handle's device state. Returns 0, or non-zero with the message in g_err (the caller decides whether that is fatal).
+static int handle_prepare(BlockImpl* h) {
+    if (ensure_device()) return 1;
+    std::unique_ptr<BaBatch> b(new BaBatch);
+    b->device = g_device; b->handle_mode = true; b->n = 1;
+    const size_t max_size = h->max_size < 16 ? 16 : h->max_size, sum = h->query_len + h->reference_len;
+    if (sum > 0x3fffffffu) return fail("sequences too long");
+    const bool trace = h->mode & BA_TRACE;
+    const size_t pad = max_size + 16;
+    // either sequence may be as long as the sum; the reference side may be an AAProfile image instead
+    const uint64_t seq_img = (1 + sum + pad + 3 + 8) & ~(size_t)7;
+    const uint64_t ref_img = std::max<uint64_t>(seq_img, (ba::profile_image_bytes((uint32_t)sum, (uint32_t)max_size) + 7) & ~7ull);
+    b->cap_pool = HandleUpload::images + seq_img + ref_img + POOL_SLACK;
+    b->cap_maxlen2 = sum + 2; b->cap_n = 1; b->cap_cig = sum + 1;
+    b->trace_stride = trace ? handle_trace_stride(max_size, b->cap_maxlen2, h->mode) : 0;
+    b->blocks_stride = trace ? b->cap_maxlen2 : 0;
+    if (b->trace_stride >= (1ull << 31)) return fail("trace stack of %llu words exceeds the 2^31 limit", (unsigned long long)b->trace_stride);
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail("hipEventCreate failed");
+    if (b->hblk.alloc(b->cap_pool) || b->rblk.alloc(sizeof(HandleResult)) || b->matrix.alloc(1024) || b->cig_ops.alloc((trace ? b->cap_cig : 1) * 4) ||
+        b->trace.alloc(b->trace_stride * 4) || b->blocks.alloc(b->blocks_stride * sizeof(BlockRec)) ||
+        b->ckpt.alloc((size_t)ba::WAVES_PER_WG * 4 * max_size * sizeof(short)) || b->prof.alloc(512) || b->tb_ctrl.alloc(256) ||
+        b->tb_queue.alloc(4) || b->slot_free.alloc(4) || b->slot_info.alloc(sizeof(ba::SlotInfo))) return 1;
+    uint8_t* hb = b->hblk.as<uint8_t>(); uint8_t* rb = b->rblk.as<uint8_t>();
+    b->pool.view(hb, b->cap_pool);   // the images' offsets are relative to the start of hblk
+    b->q_off.view(hb + offsetof(HandleUpload, q_off), 8); b->r_off.view(hb + offsetof(HandleUpload, r_off), 8);
+    b->cig_off.view(hb + offsetof(HandleUpload, cig_off), 16);
+    b->q_len.view(hb + offsetof(HandleUpload, q_len), 4); b->r_len.view(hb + offsetof(HandleUpload, r_len), 4);
+    b->counter.view(hb + offsetof(HandleUpload, work_counter), 4);
+    b->score.view(rb + offsetof(HandleResult, score), 4); b->qidx.view(rb + offsetof(HandleResult, query_idx), 4);
+    b->ridx.view(rb + offsetof(HandleResult, reference_idx), 4); b->cig_len.view(rb + offsetof(HandleResult, cig_len), 4);
+    b->status.view(rb + offsetof(HandleResult, status), 4); b->nblocks.view(rb + offsetof(HandleResult, nblocks), 4);
+    b->pair_slot.view(rb + offsetof(HandleResult, slot), 4); b->trace_words.view(rb + offsetof(HandleResult, trace_words), 4);
+    b->cells.view(rb + offsetof(HandleResult, cells), 8);
+    b->grid = 1; b->slots = 1; b->slots_per_wave = 0; b->tb_stride = 0;   // (slots_per_wave 0: whichever wave takes the pair uses slot 0)
+    b->n_fill_waves = ba::WAVES_PER_WG; b->tb_qsize = 1;
+    h->staging.assign(b->cap_pool, 0);
+    h->dev = std::move(b);
+    return 0;
+}
+
+// One alignment through a handle's persistent state. `profile` non-null: sequence-to-profile (kind PROFILE).
+static void handle_align(BlockImpl* h, int kind, const PaddedBytes* q, const PaddedBytes* r, const AAProfile* profile, const void* matrix,
+                         Gaps g, size_t min_size, size_t max_size, int32_t x) {
+    if (!h->dev && handle_prepare(h)) die("%s", g_err.c_str());
+    BaBatch* b = h->dev.get();
+    if (hipSetDevice(b->device) != hipSuccess) die("hipSetDevice failed");
+    const int pc = pclass_of(max_size);
+    if (pc < 0) die("max block size %zu not supported by the HIP backend (16..%zu)", max_size, (size_t)BA_MAX_BLOCK);
+    const uint32_t mode = h->mode & ~(uint32_t)BA_CIGAR_EQ;
+    const bool trace = mode & BA_TRACE;
+    if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > q->len)) die("Min block size must be larger than the query length for FREE_QUERY_END_GAPS!");   // scan_block.rs:860-862
+    b->kind = kind; b->mode = mode; b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
+    b->gap_open = g.open; b->gap_extend = g.extend; b->x_drop = x;
+    b->lds = ba::lds_wg_bytes_h(kind, 128u << pc) + (trace ? ba::TB_LDS_BYTES : 0u);
+    // ---- the upload: per-pair words + the two padded images (scan_block.rs:1798-1812), built in the handle's staging buffer
+    const size_t pad = max_size + 16;
+    const uint32_t ql = (uint32_t)q->len, rl = (uint32_t)(profile ? profile->str_len : r->len);
+    HandleUpload hu{};
+    hu.q_off = HandleUpload::images; hu.q_len = ql; hu.r_len = rl; hu.work_counter = 0;
+    const size_t q_img = (1 + (size_t)ql + pad + 3 + 8) & ~(size_t)7;
+    hu.r_off = hu.q_off + q_img;
+    const size_t r_img = profile ? (size_t)ba::profile_image_bytes(rl, (uint32_t)max_size) : ((1 + (size_t)rl + pad + 3) & ~(size_t)3);
+    const size_t used = (size_t)hu.r_off + r_img + POOL_SLACK;
+    if (used > b->cap_pool) die("sequence lengths exceed the bounds this Block was created with");
+    hu.cig_off[0] = 0; hu.cig_off[1] = (uint64_t)ql + rl + 1;
+    uint8_t* st = h->staging.data();
+    memcpy(st, &hu, sizeof hu);
+    const uint8_t nb = null_byte(kind);
+    uint8_t* qi = st + hu.q_off;
+    qi[0] = nb; memcpy(qi + 1, q->s.data() + 1, ql); memset(qi + 1 + ql, nb, q_img - 1 - ql);
+    uint8_t* ri = st + hu.r_off;
+    if (profile) profile_image(profile, ba::profile_positions(rl, (uint32_t)max_size), ri);
+    else { ri[0] = nb; memcpy(ri + 1, r->s.data() + 1, rl); memset(ri + 1 + rl, nb, r_img - 1 - rl); }
+    memset(st + hu.r_off + r_img, nb, POOL_SLACK);
+    b->pool_bytes = used; b->cig_total = trace ? hu.cig_off[1] : 0;
+    b->h_q_off.assign(1, hu.q_off); b->h_r_off.assign(1, hu.r_off);
+    hipError_t e = hipMemcpyAsync(b->hblk.p, st, used, hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess && b->matrix.p) {
+        const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : (kind == BA_KIND_BYTES ? 2 : 0));
+        int8_t tmp[1024] = {0};
+        if (kind == BA_KIND_BYTES) { const ByteMatrix* bm = (const ByteMatrix*)matrix; tmp[0] = bm->match_score; tmp[1] = bm->mismatch_score; }
+        else if (mat_bytes) memcpy(tmp, matrix, mat_bytes);
+        if (mat_bytes) e = hipMemcpyAsync(b->matrix.p, tmp, 1024, hipMemcpyHostToDevice, b->stream);   // (pageable source: staged before the call returns)
+    }
+    if (e != hipSuccess) die("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    b->in_flight = false; b->ran = false;
+    if (batch_run(b, nullptr)) die("%s", g_err.c_str());
+    HandleResult hr;
+    if (hipMemcpy(&hr, b->rblk.p, sizeof hr, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy D2H failed");
+    if (hr.status) die("device alignment failed (status 0x%x)", hr.status);
+    h->res = AlignResult{hr.score, hr.query_idx, hr.reference_idx};
+    h->last_ql = ql; h->last_rl = rl; h->last_nblocks = hr.nblocks; h->last_slot = hr.slot; h->aligned = true;
+}
 
 static BlockImpl* block_new_impl(uint32_t mode, size_t query_len, size_t reference_len, size_t max_size) {
     if (max_size == 0 || (max_size & (max_size - 1))) die("Block size must be a power of two!");
     BlockImpl* b = new BlockImpl;
     b->mode = mode; b->query_len = query_len; b->reference_len = reference_len; b->max_size = max_size;
+    // Block::new allocates (scan_block.rs:798-805). Without a usable device the handle still exists -- precondition checks
+    // work anywhere -- and the first align reports the missing device.
+    if (pclass_of(max_size < 16 ? 16 : max_size) >= 0) (void)handle_prepare(b);
     return b;
 }
 
@@ -995,20 +1133,11 @@ static void block_align_impl(BlockImpl* b, int kind, const PaddedBytes* q, const
     const size_t min_size = s.min < 16 ? 16 : s.min, max_size = s.max < 16 ? 16 : s.max;
     std::string why;
     if (check_align_params(false, g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    if (min_size > max_size) die("min block size exceeds max block size");
     // Allocated::clear (scan_block.rs:1324-1326)
     if (q->len + r->len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
     if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
-    b->last.reset(batch_build(kind, matrix, g, SizeRange{min_size, max_size}, x, b->mode & ~(uint32_t)BA_CIGAR_EQ, 1, true,
-                              [&](size_t, int w, const uint8_t** ptr, size_t* len) {
-                                  const PaddedBytes* p = w ? r : q;
-                                  *ptr = p->s.data() + 1; *len = p->len;
-                              }));
-    if (!b->last) die("%s", g_err.c_str());
-    if (batch_run(b->last.get(), nullptr)) die("%s", g_err.c_str());
-    int32_t sc; uint32_t qi, ri, st;
-    if (ba_batch_results(b->last.get(), &sc, &qi, &ri, nullptr, nullptr, &st)) die("%s", g_err.c_str());
-    if (st) die("device alignment failed (status 0x%x)", st);
-    b->res = AlignResult{sc, qi, ri};
+    handle_align(b, kind, q, r, nullptr, matrix, g, min_size, max_size, x);
 }
 
 static void block_align_profile_impl(BlockImpl* b, const PaddedBytes* q, const AAProfile* pr, SizeRange s, int32_t x) {   // scan_block.rs:942-968
@@ -1017,37 +1146,30 @@ static void block_align_profile_impl(BlockImpl* b, const PaddedBytes* q, const A
     const Gaps g{0, pr->gap_extend};
     std::string why;
     if (check_align_params(true, g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    if (min_size > max_size) die("min block size exceeds max block size");
     if (q->len + pr->str_len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
     if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
-    b->last.reset(batch_build(BA_KIND_PROFILE_, nullptr, g, SizeRange{min_size, max_size}, x, b->mode & ~(uint32_t)BA_CIGAR_EQ, 1, true,
-                              [&](size_t, int, const uint8_t** ptr, size_t* len) { *ptr = q->s.data() + 1; *len = q->len; },
-                              [&](size_t) { return pr; }));
-    if (!b->last) die("%s", g_err.c_str());
-    if (batch_run(b->last.get(), nullptr)) die("%s", g_err.c_str());
-    int32_t sc; uint32_t qi, ri, st;
-    if (ba_batch_results(b->last.get(), &sc, &qi, &ri, nullptr, nullptr, &st)) die("%s", g_err.c_str());
-    if (st) die("device alignment failed (status 0x%x)", st);
-    b->res = AlignResult{sc, qi, ri};
+    handle_align(b, BA_KIND_PROFILE_, q, nullptr, pr, nullptr, g, min_size, max_size, x);
 }
 
 static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const PaddedBytes* r, size_t i, size_t j, Cigar* cigar) {
     if (!(b->mode & BA_TRACE)) die("trace() requires a Block created with TRACE");   // scan_block.rs:1241-1243
-    BaBatch* d = b->last.get();
-    if (!d) die("cigar requested before any alignment");
+    BaBatch* d = b->dev.get();
+    if (!d || !b->aligned) die("cigar requested before any alignment");
     if (eq && d->kind == BA_KIND_PROFILE_) die("cigar_eq needs two sequences; the last alignment was against a profile");
-    uint32_t ql, rl, nb, slot;
-    if (d2h(d->q_len, &ql, 1) || d2h(d->r_len, &rl, 1) || d2h(d->nblocks, &nb, 1) || d2h(d->pair_slot, &slot, 1)) die("%s", g_err.c_str());
-    if (!(i <= ql && j <= rl)) die("Traceback cigar end position must be in bounds!");   // scan_block.rs:1483
+    if (!(i <= b->last_ql && j <= b->last_rl)) die("Traceback cigar end position must be in bounds!");   // scan_block.rs:1483
     if (i + j + 5 > cigar->capacity) die("Cigar was created for shorter sequences than this traceback needs");   // cigar.rs:58-60 slice bound
     (void)q; (void)r;   // the padded images of the aligned pair are already resident on the device
     BatchParams bp = d->params();
+    bp.cig_ops = d->cig_ops.as<uint32_t>();
     bp.flags = eq ? (bp.flags | ba::F_CIGAR_EQ) : (bp.flags & ~ba::F_CIGAR_EQ);
-    bp.tb_i = (uint32_t)i; bp.tb_j = (uint32_t)j; bp.tb_nblocks = nb; bp.tb_slot = slot;
+    bp.tb_i = (uint32_t)i; bp.tb_j = (uint32_t)j; bp.tb_nblocks = b->last_nblocks; bp.tb_slot = b->last_slot;
     if (hipSetDevice(d->device) != hipSuccess || ba_launch_traceback(d->stream, &bp) != hipSuccess ||
         hipStreamSynchronize(d->stream) != hipSuccess) die("traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
-    uint32_t n, st;
-    if (d2h(d->cig_len, &n, 1) || d2h(d->status, &st, 1)) die("%s", g_err.c_str());
-    if (st) die("device traceback failed (status 0x%x)", st);
+    HandleResult hr;
+    if (hipMemcpy(&hr, d->rblk.p, sizeof hr, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy D2H failed");
+    if (hr.status) die("device traceback failed (status 0x%x)", hr.status);
+    const uint32_t n = hr.cig_len;
     std::vector<uint32_t> runs(n);
     if (n && hipMemcpy(runs.data(), d->cig_ops.as<uint32_t>() + (d->cig_total - n), (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
         die("hipMemcpy of cigar runs failed");
@@ -1058,10 +1180,9 @@ static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const 
 // Trace::blocks() (scan_block.rs:1676-1691): the rectangles on the trace stack of the last alignment, in fill order
 static size_t block_trace_blocks_impl(BlockImpl* b, Rectangle* out, size_t capacity) {
     if (!(b->mode & BA_TRACE)) die("trace() requires a Block created with TRACE");
-    BaBatch* d = b->last.get();
-    if (!d) die("blocks requested before any alignment");
-    uint32_t nb, slot;
-    if (d2h(d->nblocks, &nb, 1) || d2h(d->pair_slot, &slot, 1)) die("%s", g_err.c_str());
+    BaBatch* d = b->dev.get();
+    if (!d || !b->aligned) die("blocks requested before any alignment");
+    const uint32_t nb = b->last_nblocks, slot = b->last_slot;
     if (!out) return nb;
     std::vector<BlockRec> recs(nb);
     if (nb && hipMemcpy(recs.data(), d->blocks.as<BlockRec>() + (size_t)slot * d->blocks_stride, (size_t)nb * sizeof(BlockRec), hipMemcpyDeviceToHost) != hipSuccess)

@@ -127,6 +127,14 @@ def set_device(d: int) -> None:
         raise RuntimeError(last_error())
 
 
+def device_memory():
+    """(free, total) bytes of the selected device."""
+    f, t = C.c_uint64(), C.c_uint64()
+    if lib().ba_device_memory(C.byref(f), C.byref(t)):
+        raise RuntimeError(last_error())
+    return f.value, t.value
+
+
 def percent_len(length: int, p: float) -> int:
     """lib.rs:109-111"""
     return lib().block_percent_len(length, p)

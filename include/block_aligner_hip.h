@@ -3,7 +3,7 @@
  *
  * Part 1 is, symbol for symbol, the reference's C API (/root/reference/c/block_aligner.h, generated from
  * /root/reference/src/ffi.rs): a program written against that header links against libblock_aligner_hip.so
- * unchanged (see tests/c/example_ref.c, the counterpart of /root/reference/c/example.c). Every alignment is
+ * unchanged (see tests/c_abi/abi_check.c, a gcc-compiled caller in the style of /root/reference/c/example.c). Every alignment is
  * executed by the HIP kernels in block_aligner_amd/csrc; there is no CPU fallback — if no gfx950 device or
  * HIP runtime is usable the call aborts with a message, like the reference's panic=abort.
  *
@@ -30,9 +30,15 @@ extern "C" {
 /* Part 1 — the reference C API                                                                           */
 /* ------------------------------------------------------------------------------------------------------ */
 
-/* cigar.rs:10-31, c/block_aligner.h:17-57 */
-enum BaOperation { Sentinel = 0, M = 1, Eq = 2, X = 3, I = 4, D = 5 };
+/* cigar.rs:10-31, c/block_aligner.h:17-57: `enum Operation` with a one-byte representation */
+enum Operation
+#ifdef __cplusplus
+    : uint8_t
+#endif
+{ Sentinel = 0, M = 1, Eq = 2, X = 3, I = 4, D = 5 };
+#ifndef __cplusplus
 typedef uint8_t Operation;
+#endif
 
 typedef struct AAMatrix AAMatrix;       /* scores.rs:40-44: 27 x 32 int8, 32-byte aligned, 864 bytes */
 typedef struct NucMatrix NucMatrix;     /* scores.rs:142-146: 8 x 16 int8, 32-byte aligned, 128 bytes */
@@ -116,6 +122,8 @@ const char* ba_last_error(void);
 /* number of usable HIP devices (0 if the runtime is unusable); ba_set_device selects the one later calls use */
 int ba_device_count(void);
 int ba_set_device(int device);
+/* free / total bytes of the selected device's memory (hipMemGetInfo) */
+int ba_device_memory(uint64_t* free_bytes, uint64_t* total_bytes);
 /* lib.rs:109-111 */
 uintptr_t block_percent_len(uintptr_t len, float p);
 

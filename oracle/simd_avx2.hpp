@@ -5,7 +5,7 @@
 // alignr, shufflehi, permute4x64) are reproduced by the hardware itself rather than modelled.
 //
 // Follows /root/reference/src/avx2.rs (file:line cited per function).
-// Parity status: see oracle/README.md ("pinned by the reference's own known-answer tests").
+// Parity status: see DESIGN.md section 2 ("pinned by the reference's own known-answer tests").
 #pragma once
 #include <immintrin.h>
 #include <cstdint>

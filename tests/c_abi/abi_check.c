@@ -117,6 +117,9 @@ int main(int argc, char** argv) {
         printf("sizeof AlignResult=%zu OpLen=%zu Gaps=%zu SizeRange=%zu\n", sizeof(AlignResult), sizeof(OpLen), sizeof(Gaps), sizeof(SizeRange));
         printf("percent_len %lu %lu\n", (unsigned long)block_percent_len(10000, 0.01f), (unsigned long)block_percent_len(10000, 0.1f));
         printf("statics %p %p %p\n", (const void*)&BLOSUM62, (const void*)&NW1, (const void*)&BYTES1);
+        enum Operation e = Eq;   /* the tag name a caller of the reference header uses (c/block_aligner.h:17-57) */
+        Operation o = e;
+        printf("operation %d %zu\n", (int)o, sizeof(Operation));
         return 0;
     }
     if (ba_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }

@@ -24,6 +24,7 @@ def test_c_program_compiles_and_links(tmp_path):
     out = subprocess.check_output([exe, "--link-only"], text=True)
     assert "sizeof AlignResult=24 OpLen=16 Gaps=2 SizeRange=16" in out      # c/block_aligner.h:90-126 layouts
     assert "percent_len 128 1024" in out                                     # lib.rs:109-111
+    assert "operation 2 1" in out                                            # `enum Operation` / one-byte `Operation` (c/block_aligner.h:17-57)
 
 
 @pytest.mark.gpu

@@ -91,3 +91,45 @@ def test_c_example_flow(hip):
     ops = [L.block_get_cigar(cig, i) for i in range(n)]
     assert sum(o.len for o in ops if o.op in (1, 4)) == 8 and sum(o.len for o in ops if o.op in (1, 5)) == 7
     L.block_free_cigar(cig); L.block_free_aa_trace(blk); L.block_free_padded_aa(a); L.block_free_padded_aa(b)
+
+
+def test_handle_state_is_allocated_once(hip):
+    """Block::new allocates, align never does (scan_block.rs:798-805, 1280-1340): 1000 sequential align + cigar calls on one
+    handle -- the serial loop every reference example runs (examples/nanopore_bench.rs:83-93) -- leave the device's free
+    memory exactly where it was after the second call, and give the same answer every time."""
+    import time
+    import numpy as np
+    from block_aligner_amd import scores as S, synth
+    rng = np.random.default_rng(3)
+    r = synth.rand_str(rng, 900, synth.AMINO)
+    q = synth.mutate(rng, r, 120, synth.AMINO)
+    qb, rb = q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()
+    blk = hip.Block(len(qb), len(rb), 256, trace=True, x_drop=True)
+    pq = hip.PaddedBytes.from_bytes(qb, 256, S.AAMatrix); pr = hip.PaddedBytes.from_bytes(rb, 256, S.AAMatrix)
+    cig = hip.Cigar(len(qb), len(rb))
+    first = None
+    free2 = None
+    t0 = None
+    for it in range(1000):
+        if it == 2:
+            free2 = hip.device_memory()[0]
+            t0 = time.perf_counter()
+        blk.align(pq, pr, S.BLOSUM62, S.Gaps(-11, -1), (32, 256), 50)
+        res = blk.res()
+        blk.trace().cigar_eq(pq, pr, res.query_idx, res.reference_idx, cig)
+        got = (res.score, res.query_idx, res.reference_idx, str(cig) if it % 100 == 0 else None)
+        if first is None:
+            first = got
+        assert got[:3] == first[:3] and (got[3] is None or got[3] == first[3])
+    per_call = (time.perf_counter() - t0) / 998 * 1e6
+    assert hip.device_memory()[0] == free2
+    # the floor of one call: a pair that fits one 32-cell block (upload, one launch, one 64-byte read-back)
+    tq = hip.PaddedBytes.from_bytes(b"MKVLAARNDCEQ", 256, S.AAMatrix); tr = hip.PaddedBytes.from_bytes(b"MKVLARNDCEQ", 256, S.AAMatrix)
+    blk.align(tq, tr, S.BLOSUM62, S.Gaps(-11, -1), (32, 256), 50)
+    t1 = time.perf_counter()
+    for _ in range(300):
+        blk.align(tq, tr, S.BLOSUM62, S.Gaps(-11, -1), (32, 256), 50)
+    floor = (time.perf_counter() - t1) / 300 * 1e6
+    assert hip.device_memory()[0] == free2
+    print(f"\nhandle API: {per_call:.1f} us per align + cigar_eq call pair (900 aa, block 32..256); {floor:.1f} us per align of a 12-residue pair")
+    assert per_call < 5000
