@@ -33,6 +33,7 @@ using ba::BlockRec;
 BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_merge_retry(hipStream_t, const uint32_t*, uint32_t, const BatchParams*, const BatchParams*, const uint32_t*, uint32_t*);
 extern "C" hipError_t ba_launch_pack_sequences(hipStream_t, int, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint32_t*,
                                                const uint64_t*, const uint32_t*, uint8_t*, uint32_t, uint32_t, unsigned long long*);
 
@@ -175,6 +176,9 @@ struct BaBatch {
     int gap_open = 0, gap_extend = 0, x_drop = 0;
     uint32_t grid = 0, lds = 0, slots = 0;   // grid = workgroups of WAVES_PER_WG waves; slots = resident waves
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
+    uint64_t trace_full = 0;    // trace words per slot by the reference's worst-case bound (Trace::new)
+    bool adaptive = false;      // trace_stride < trace_full: pairs that overflow their slot are re-run by batch_wait
+    uint32_t retried = 0;       // pairs the last run had to re-run with full-size slots
     uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace_words, trace, blocks, ckpt, counter,
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
@@ -397,6 +401,114 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
                                [&](size_t s) { return getp(order[s]); }, P, lap);
 }
 
+// Launch geometry and scratch sizes of a batch whose inputs are known: workgroups, LDS, trace slot size, traceback waves,
+// slots per wave, hand-off ring. fixed_bytes = device memory the batch needs besides its per-wave scratch.
+static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxlen2, bool full_trace) {
+    const int kind = b->kind; const uint32_t mode = b->mode; const int pc = (int)b->pclass; const size_t max_size = b->max_size;
+    const bool trace = mode & BA_TRACE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
+    // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
+    b->lds = ba::lds_wg_bytes_h(kind, 128u << pc) + (trace ? ba::TB_LDS_BYTES : 0u);
+    if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
+    if (b->lds > 64 * 1024) {
+        // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
+    }
+    int per_cu = 0;
+    if (g_occ[special_of(mode)][kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
+        fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
+    }
+    if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
+    if (const char* env = getenv("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
+    uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
+    const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
+    if (grid > need) grid = need;
+    // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
+    // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
+    const uint64_t zm = (mode & BA_LOCAL_START) ? 5 : 1;
+    b->trace_full = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * zm + 64 : 0;   // (+ 64 words of slack: unpredicated stores of the fast path)
+    b->trace_stride = b->trace_full;
+    // That bound assumes the block sits at its maximum size for the whole alignment (11.9 MB per 10 kbp pair at 1024, of
+    // which config 3 uses 1.8 MB). Large batches get slots sized for the expected stack instead -- every step at the minimum
+    // size, one full grow sequence to the maximum, a few steps there -- times a margin; the few pairs that outgrow
+    // their slot report BA_ST_TRACE_OVERFLOW on the device and are re-run with full-size slots by batch_wait.
+    b->adaptive = false;
+    if (trace && !full_trace && !getenv("BA_FULL_TRACE_SLOTS") && (n >= 4096 || getenv("BA_ADAPTIVE_TRACE"))) {
+        const uint64_t est = (maxlen2 * b->min_size / 8 + (uint64_t)max_size * max_size / 8 + 16ull * max_size) * zm;
+        uint64_t pct = 175;   // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT)
+        if (const char* env = getenv("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
+        const uint64_t want = est * pct / 100 + 4096;
+        if (want < b->trace_full) { b->trace_stride = want; b->adaptive = true; }
+    }
+    b->blocks_stride = trace ? maxlen2 : 0;
+    if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return 1; }
+    if (trace) {
+        // very long pairs: a trace slot can be hundreds of MB, so fewer waves may be resident than the chip could hold --
+        // shrink the launch until one slot per wave fits in device memory (a long pair keeps its wave busy for long anyway)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
+        const uint64_t fixed = fixed_bytes + (1ull << 30);
+        const uint64_t budget = free_b * 9 / 10 > fixed ? free_b * 9 / 10 - fixed : 0;
+        const uint64_t max_waves = per_slot ? budget / per_slot : ~0ull;
+        if (max_waves < ba::WAVES_PER_WG) { fail("device memory: one workgroup's trace slots need %llu MB, %llu MB are free", (unsigned long long)(per_slot * ba::WAVES_PER_WG >> 20), (unsigned long long)(budget >> 20)); return 1; }
+        if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
+    }
+    b->grid = (uint32_t)grid;
+    // TRACE batches big enough to keep them busy get dedicated traceback waves (ba_driver.hpp traceback_consumer)
+    // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
+    b->tb_stride = 0; b->slots_per_wave = 1;
+    b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
+    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
+        // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
+        // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
+        // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
+        // no difference now that a walk runs out of LDS.)
+        uint32_t stride = b->grid >= 32 ? 4 : 2;
+        if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
+        b->tb_stride = stride;
+        b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
+        const uint64_t fixed = fixed_bytes + (1ull << 30);
+        uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
+        if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
+        while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
+        b->slots_per_wave = spw;
+        // The last hand-offs of the batch go to fill waves that have run out of pairs (one walking lane per wave, on
+        // SIMDs with nothing else left to do): a walk alone is much shorter than one among 40 in lockstep, and the
+        // batch ends one walk after its last fill. Three quarters of the fill waves (measured at config 3: flat between
+        // 3000 and 3500 of 3968, 1 % slower at 2000 or 6000); fewer than all of them, so the fill waves can never all be
+        // waiting for trace slots whose walks are reserved for helpers that do not exist yet.
+        b->tb_reserve = b->n_fill_waves / 4 * 3;
+        // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
+        // less of the batch to walkers that only exist once the first wave has run out of pairs
+        if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
+        if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
+    }
+    b->slots = b->n_fill_waves * b->slots_per_wave;
+    {
+        const uint64_t lanes = b->tb_stride ? (uint64_t)((b->grid + b->tb_stride - 1) / b->tb_stride) * 64 + b->n_fill_waves : 0;   // + one helper lane per fill wave
+        uint64_t need_q = std::max<uint64_t>(lanes, b->slots);
+        uint32_t qs = 1;
+        while (qs < need_q) qs <<= 1;
+        b->tb_qsize = qs;
+    }
+
+    return 0;
+}
+static int batch_alloc_scratch(BaBatch* b) {
+#define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return 1
+    BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
+    BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
+    BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * b->max_size * sizeof(short));
+    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams));
+    BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
+#undef BA_ALLOC
+    return 0;
+}
+
 // Sequence images into b->pool; the per-pair offset / length arrays must already be on the device.
 static int upload_images(BaBatch* b, const Packed& P, size_t n) {
     if (!P.on_device) { HIP_TRY(hipMemcpy(b->pool.p, P.image.data(), P.total, hipMemcpyHostToDevice)); return 0; }
@@ -463,81 +575,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     const bool trace = mode & BA_TRACE;
     const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : (profile ? 0 : 2));
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return nullptr; }
-    // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
-    b->lds = ba::lds_wg_bytes_h(kind, 128u << pc) + (trace ? ba::TB_LDS_BYTES : 0u);
-    if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return nullptr; }
-    if (b->lds > 64 * 1024) {
-        // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
-    }
-    int per_cu = 0;
-    if (g_occ[special_of(mode)][kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
-        fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return nullptr;
-    }
-    if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
-    if (const char* env = getenv("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
-    uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
-    const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
-    if (grid > need) grid = need;
-    // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
-    // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
-    b->trace_stride = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) + 64 : 0;   // (+ 64 words of slack: unpredicated stores of the fast path)
-    b->blocks_stride = trace ? maxlen2 : 0;
-    if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return nullptr; }
-    if (trace) {
-        // very long pairs: a trace slot can be hundreds of MB, so fewer waves may be resident than the chip could hold --
-        // shrink the launch until one slot per wave fits in device memory (a long pair keeps its wave busy for long anyway)
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
-        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
-        const uint64_t budget = free_b * 9 / 10 > fixed ? free_b * 9 / 10 - fixed : 0;
-        const uint64_t max_waves = per_slot ? budget / per_slot : ~0ull;
-        if (max_waves < ba::WAVES_PER_WG) { fail("device memory: one workgroup's trace slots need %llu MB, %llu MB are free", (unsigned long long)(per_slot * ba::WAVES_PER_WG >> 20), (unsigned long long)(budget >> 20)); return nullptr; }
-        if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
-    }
-    b->grid = (uint32_t)grid;
-    // TRACE batches big enough to keep them busy get dedicated traceback waves (ba_driver.hpp traceback_consumer)
-    // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
-    b->tb_stride = 0; b->slots_per_wave = 1;
-    b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
-    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
-        // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
-        // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
-        // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
-        // no difference now that a walk runs out of LDS.)
-        uint32_t stride = b->grid >= 32 ? 4 : 2;
-        if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
-        b->tb_stride = stride;
-        b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
-        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * 64 + (1ull << 30);
-        uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
-        if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
-        while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
-        b->slots_per_wave = spw;
-        // The last hand-offs of the batch go to fill waves that have run out of pairs (one walking lane per wave, on
-        // SIMDs with nothing else left to do): a walk alone is much shorter than one among 40 in lockstep, and the
-        // batch ends one walk after its last fill. Three quarters of the fill waves (measured at config 3: flat between
-        // 3000 and 3500 of 3968, 1 % slower at 2000 or 6000); fewer than all of them, so the fill waves can never all be
-        // waiting for trace slots whose walks are reserved for helpers that do not exist yet.
-        b->tb_reserve = b->n_fill_waves / 4 * 3;
-        // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
-        // less of the batch to walkers that only exist once the first wave has run out of pairs
-        if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
-        if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
-    }
-    b->slots = b->n_fill_waves * b->slots_per_wave;
-    {
-        const uint64_t lanes = b->tb_stride ? (uint64_t)((b->grid + b->tb_stride - 1) / b->tb_stride) * 64 + b->n_fill_waves : 0;   // + one helper lane per fill wave
-        uint64_t need_q = std::max<uint64_t>(lanes, b->slots);
-        uint32_t qs = 1;
-        while (qs < need_q) qs <<= 1;
-        b->tb_qsize = qs;
-    }
+    if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false)) return nullptr;
     b->cig_total = trace ? cig_total : 0;
 
     lap("launch geometry");
@@ -545,14 +583,11 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(pool, total); BA_ALLOC(q_off, n * 8); BA_ALLOC(q_len, n * 4); BA_ALLOC(r_off, n * 8); BA_ALLOC(r_len, n * 4);
     BA_ALLOC(matrix, 1024);
     BA_ALLOC(score, n * 4); BA_ALLOC(qidx, n * 4); BA_ALLOC(ridx, n * 4); BA_ALLOC(cig_len, n * 4); BA_ALLOC(cells, n * 8);
-    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(pair_slot, n * 4); BA_ALLOC(trace_words, n * 4); BA_ALLOC(counter, 64);
+    BA_ALLOC(status, n * 4); BA_ALLOC(nblocks, n * 4); BA_ALLOC(pair_slot, n * 4); BA_ALLOC(trace_words, n * 4);
     BA_ALLOC(cig_off, (n + 1) * 8);
     BA_ALLOC(cig_ops, b->cig_total * 4);
-    BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
-    BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
-    BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * max_size * sizeof(short));
-    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams)); BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo));
 #undef BA_ALLOC
+    if (batch_alloc_scratch(b.get())) return nullptr;
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -620,12 +655,69 @@ static int batch_launch(BaBatch* b) {
     b->in_flight = true;
     return 0;
 }
+template <class T>
+static int d2h(const DevBuf& buf, T* dst, size_t count) {
+    if (!dst) return 0;
+    HIP_TRY(hipMemcpy(dst, buf.p, count * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+// Re-run the pairs `idx` (device order) of a TRACE batch with trace slots of the reference's full bound and put their results
+// where the first pass left BA_ST_TRACE_OVERFLOW. The sub-batch reads the parent's resident images and matrix.
+static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx) {
+    const size_t k = idx.size(), n = b->n;
+    std::vector<uint32_t> ql(n), rl(n);
+    if (d2h(b->q_len, ql.data(), n) || d2h(b->r_len, rl.data(), n)) return 1;
+    BaBatch sub;
+    sub.device = b->device; sub.kind = b->kind; sub.mode = b->mode; sub.n = (uint32_t)k; sub.min_size = b->min_size; sub.max_size = b->max_size;
+    sub.pclass = b->pclass; sub.gap_open = b->gap_open; sub.gap_extend = b->gap_extend; sub.x_drop = b->x_drop;
+    std::vector<uint64_t> qo(k), ro(k), co(k + 1);
+    std::vector<uint32_t> sql(k), srl(k);
+    uint64_t maxlen2 = 0, cig_total = 0;
+    for (size_t t = 0; t < k; t++) {
+        const uint32_t p = idx[t];
+        qo[t] = b->h_q_off[p]; ro[t] = b->h_r_off[p]; sql[t] = ql[p]; srl[t] = rl[p];
+        maxlen2 = std::max<uint64_t>(maxlen2, (uint64_t)ql[p] + rl[p] + 2);
+        co[t] = cig_total; cig_total += (uint64_t)ql[p] + rl[p] + 1;
+    }
+    co[k] = cig_total;
+    if (hipStreamCreateWithFlags(&sub.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipEventCreate(&sub.ev0) != hipSuccess || hipEventCreate(&sub.ev1) != hipSuccess) return fail("hipEventCreate failed");
+    if (batch_plan(&sub, k, cig_total * 4 + (uint64_t)k * 64, maxlen2, true)) return 1;
+    sub.cig_total = cig_total;
+    sub.pool.view(b->pool.p, b->pool.bytes); sub.matrix.view(b->matrix.p, b->matrix.bytes);
+    DevBuf d_idx;
+    if (sub.q_off.alloc(k * 8) || sub.q_len.alloc(k * 4) || sub.r_off.alloc(k * 8) || sub.r_len.alloc(k * 4) || sub.cig_off.alloc((k + 1) * 8) ||
+        sub.score.alloc(k * 4) || sub.qidx.alloc(k * 4) || sub.ridx.alloc(k * 4) || sub.cig_len.alloc(k * 4) || sub.cells.alloc(k * 8) ||
+        sub.status.alloc(k * 4) || sub.nblocks.alloc(k * 4) || sub.pair_slot.alloc(k * 4) || sub.trace_words.alloc(k * 4) ||
+        sub.cig_ops.alloc(cig_total * 4) || d_idx.alloc(k * 4) || batch_alloc_scratch(&sub)) return 1;
+    HIP_TRY(hipMemcpy(sub.q_off.p, qo.data(), k * 8, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(sub.q_len.p, sql.data(), k * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sub.r_off.p, ro.data(), k * 8, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(sub.r_len.p, srl.data(), k * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sub.cig_off.p, co.data(), (k + 1) * 8, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(d_idx.p, idx.data(), k * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(sub.cig_len.p, 0, k * 4)); HIP_TRY(hipMemset(sub.status.p, 0, k * 4));
+    if (batch_launch(&sub)) return 1;
+    HIP_TRY(hipStreamSynchronize(sub.stream));
+    sub.in_flight = false;
+    const BatchParams sp = sub.params(), dp = b->params();
+    HIP_TRY(ba_launch_merge_retry(sub.stream, d_idx.as<uint32_t>(), (uint32_t)k, &sp, &dp, sub.trace_words.as<uint32_t>(), b->trace_words.as<uint32_t>()));
+    HIP_TRY(hipStreamSynchronize(sub.stream));
+    return 0;
+}
 static int batch_wait(BaBatch* b, float* kernel_ms) {
     if (!b->in_flight) return fail("nothing was launched on this batch");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));
     b->in_flight = false;
+    b->retried = 0;
+    if (b->adaptive) {   // pairs whose trace stack outgrew the expected size: once more, with the reference's full bound
+        std::vector<uint32_t> st(b->n), again;
+        if (d2h(b->status, st.data(), b->n)) return 1;
+        for (uint32_t p = 0; p < b->n; p++) if (st[p] & BA_ST_TRACE_OVERFLOW) again.push_back(p);
+        if (!again.empty()) {
+            if (batch_retry(b, again)) return 1;
+            b->retried = (uint32_t)again.size();
+        }
+    }
     b->ran = true;
     return 0;
 }
@@ -634,12 +726,6 @@ static int batch_run(BaBatch* b, float* kernel_ms) {
     return batch_wait(b, kernel_ms);
 }
 
-template <class T>
-static int d2h(const DevBuf& buf, T* dst, size_t count) {
-    if (!dst) return 0;
-    HIP_TRY(hipMemcpy(dst, buf.p, count * sizeof(T), hipMemcpyDeviceToHost));
-    return 0;
-}
 
 // dst holds one value per pair in device order: rearrange to the caller's order (dst[order[s]] = value of device entry s)
 template <class T>
@@ -773,6 +859,7 @@ int ba_batch_info(BaBatch* b, uint64_t out[4]) {
     out[0] = (uint64_t)b->grid * ba::WAVES_PER_WG; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
     return 0;
 }
+int ba_batch_retried(BaBatch* b) { return b ? (int)b->retried : -1; }
 void ba_batch_destroy(BaBatch* b) { delete b; }
 
 int block_batch_align(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, const uint8_t* pool,

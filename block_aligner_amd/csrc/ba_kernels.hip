@@ -121,6 +121,26 @@ extern "C" hipError_t ba_launch_pack_sequences(hipStream_t s, int kind, const ui
     k_pack_sequences<<<dim3(2 * n), dim3(256), 0, s>>>(kind, raw, raw_q, raw_r, q_off, q_len, r_off, r_len, image, pad, err);
     return hipGetLastError();
 }
+// Results of a re-run (pairs whose trace stack outgrew an adaptively sized slot, see batch_plan) back into the batch's own
+// arrays: one workgroup per pair; sub-batch entry k belongs to the batch's (device-order) pair idx[k].
+__global__ void __launch_bounds__(256) k_merge_retry(const uint32_t* __restrict__ idx, const ba::BatchParams sub, const ba::BatchParams dst,
+                                                     const uint32_t* __restrict__ sub_trace_words, uint32_t* __restrict__ dst_trace_words) {
+    const uint32_t k = blockIdx.x, p = idx[k];
+    const uint32_t len = sub.cig_len[k];
+    if (threadIdx.x == 0) {
+        dst.score[p] = sub.score[k]; dst.query_idx[p] = sub.query_idx[k]; dst.reference_idx[p] = sub.reference_idx[k];
+        dst.cig_len[p] = len; dst.status[p] = sub.status[k]; dst.cells[p] = sub.cells[k];
+        dst_trace_words[p] = sub_trace_words[k];
+    }
+    if (!sub.cig_ops || !dst.cig_ops) return;
+    const uint64_t src = sub.cig_off[k + 1] - len, to = dst.cig_off[p + 1] - len;   // runs are right-aligned in a pair's range
+    for (uint32_t t = threadIdx.x; t < len; t += blockDim.x) dst.cig_ops[to + t] = sub.cig_ops[src + t];
+}
+extern "C" hipError_t ba_launch_merge_retry(hipStream_t s, const uint32_t* idx, uint32_t k, const ba::BatchParams* sub, const ba::BatchParams* dst,
+                                            const uint32_t* sub_tw, uint32_t* dst_tw) {
+    k_merge_retry<<<dim3(k), dim3(256), 0, s>>>(idx, *sub, *dst, sub_tw, dst_tw);
+    return hipGetLastError();
+}
 extern "C" hipError_t ba_launch_traceback(hipStream_t s, const ba::BatchParams* bp) {
     k_traceback<<<dim3(1), dim3(64), 0, s>>>(*bp);
     return hipGetLastError();

@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
         L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
         L.ba_batch_surviving_cells.argtypes = [vp, vp]
+        L.ba_batch_retried.argtypes = [vp]
+        L.ba_device_memory.argtypes = [vp, vp]
         L.ba_batch_info.argtypes = [vp, vp]
         L.ba_batch_destroy.argtypes = [vp]
         _lib = L
@@ -396,6 +398,10 @@ class BatchAligner:
         if lib().ba_batch_surviving_cells(self._h, out.ctypes.data):
             raise RuntimeError(last_error())
         return out
+
+    def retried(self) -> int:
+        """Pairs the last run re-ran with full-size trace slots (ba_batch_retried)."""
+        return lib().ba_batch_retried(self._h)
 
     def info(self):
         o = np.zeros(4, np.uint64)

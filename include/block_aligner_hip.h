@@ -221,6 +221,10 @@ int ba_batch_cigars(BaBatch* batch, uint32_t* runs, uint64_t capacity);
 int ba_batch_surviving_cells(BaBatch* batch, uint64_t* cells);
 /* Facts about the launch: out[0] grid (resident waves), [1] LDS bytes per wave, [2] trace arena bytes, [3] padded pool bytes */
 int ba_batch_info(BaBatch* batch, uint64_t out[4]);
+/* Large TRACE batches size their trace slots for the expected stack, not for the reference's worst case (Trace::new,
+ * scan_block.rs:1363-1366); pairs that outgrow a slot are re-run with full-size slots inside ba_batch_run / ba_batch_wait.
+ * Number of pairs the last run re-ran (results are identical either way; -1 for a null batch). */
+int ba_batch_retried(BaBatch* batch);
 void ba_batch_destroy(BaBatch* batch);
 
 enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16,

@@ -526,3 +526,33 @@ def test_batch_api_errors_and_coexisting_batches(hip, oracle):
         ref = oracle.batch_align(NUC, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len, (-5, -1), (32, 256), 50, ("trace", "x_drop"), cigar_eq=True, threads=4)
         assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["cigar_len"], ref["cig_len"])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("margin", ["3", "40", "175"])
+def test_adaptive_trace_slots_rerun_overflows(hip, oracle, monkeypatch, margin):
+    """Large TRACE batches size their trace slots for the expected stack (block at its minimum size, one grow sequence);
+    pairs that outgrow a slot come back with BA_ST_TRACE_OVERFLOW and are re-run with the reference's full bound inside
+    the same ba_batch_run. Forced here on a small batch with long indels and artificially small margins: whatever share
+    of the pairs overflows, every result is the oracle's."""
+    monkeypatch.setenv("BA_ADAPTIVE_TRACE", "1")
+    monkeypatch.setenv("BA_TRACE_MARGIN_PCT", margin)
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    pairs = synth.make_pairs(400, (800, 2500), (50, 250), 60, synth.DNA, seed=31 + int(margin), indels=3, indel_len=(30, 300))
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    b = hip.BatchAligner(NUC, (-5, -1), (32, 512), 80, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    for rnd in range(2):      # the second run re-uses the slots and re-runs the same pairs again
+        b.run()
+        res = b.results()
+        assert not res["status"].any()
+        retried = b.retried()
+        assert retried > 0 if margin == "3" else retried >= 0
+        ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 512), 80, ("trace", "x_drop"), cigar_eq=True, threads=8)
+        assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["query_idx"], ref["query_idx"]) and np.array_equal(res["reference_idx"], ref["reference_idx"])
+        assert np.array_equal(res["cigar_len"], ref["cig_len"]) and int(res["cells"].sum()) == ref["cells"]
+        runs, off = b.cigars(res["cigar_len"])
+        for p in range(len(pairs)):
+            want = ref["cig_ops"][int(ref["cig_off"][p]): int(ref["cig_off"][p]) + int(ref["cig_len"][p])]
+            assert np.array_equal(runs[int(off[p]): int(off[p + 1])], want), (margin, rnd, p)
+        assert int(b.surviving_cells().sum()) > 0
+    print(f"\nmargin {margin} %: {retried} of {len(pairs)} pairs re-run")
+    b.close()
