@@ -65,7 +65,7 @@ static int fail(const char* fmt, ...) {
 }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 
-static int g_device = -1;
+static thread_local int g_device = -1;   // per host thread: one thread may drive each GPU (ba_set_device; BaMultiBatch does)
 static int ensure_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -1077,6 +1077,110 @@ int block_batch_align_profile_exp(const AAProfile* const* profiles, SizeRange si
                            [&](size_t k) { return profiles[idx[k]]; });
     }, results, reached_min);
 }
+}  // extern "C"
+
+// ------------------------------------------------------------------ one batch over several GPUs
+// Pairs are independent, so a batch shards without any exchange step: contiguous slices of the caller's pair
+// list, balanced by cost (|q| + |r|, what the number of driver steps follows), one BaBatch per device, each created by its
+// own host thread (packing and upload run in parallel), launched on its own stream; results come back in the caller's order.
+extern "C" int ba_shard_slices(const uint32_t* q_len, const uint32_t* r_len, uintptr_t n, int parts, uint64_t* bounds) {
+    if (!q_len || !r_len || !bounds || parts < 1) return fail("null argument");
+    std::vector<uint64_t> pre(n + 1, 0);
+    for (size_t p = 0; p < n; p++) pre[p + 1] = pre[p] + (uint64_t)q_len[p] + r_len[p] + 16;   // (+16: even empty pairs cost a launch slot)
+    bounds[0] = 0;
+    for (int k = 1; k < parts; k++) {
+        const uint64_t target = pre[n] / (uint64_t)parts * (uint64_t)k + pre[n] % (uint64_t)parts * (uint64_t)k / (uint64_t)parts;
+        size_t lo = std::lower_bound(pre.begin(), pre.end(), target) - pre.begin();
+        if (lo > n) lo = n;
+        if (lo < bounds[k - 1]) lo = bounds[k - 1];
+        bounds[k] = lo;
+    }
+    bounds[parts] = n;
+    return 0;
+}
+
+struct BaMultiBatch {
+    std::vector<std::unique_ptr<BaBatch>> part;
+    std::vector<uint64_t> bounds;     // part k holds the caller's pairs [bounds[k], bounds[k + 1])
+    uint32_t mode = 0;
+};
+
+extern "C" {
+BaMultiBatch* ba_multibatch_create(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, const uint8_t* pool,
+                                   const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n,
+                                   const int* devices, int n_devices) {
+    if (!matrix || !pool || !q_off || !q_len || !r_off || !r_len || !devices || n_devices < 1) { fail("null argument"); return nullptr; }
+    if (n == 0) { fail("batch must hold at least one pair"); return nullptr; }
+    const int have = ba_device_count();
+    for (int k = 0; k < n_devices; k++)
+        if (devices[k] < 0 || devices[k] >= have) { fail("device %d out of range (%d devices)", devices[k], have); return nullptr; }
+    std::unique_ptr<BaMultiBatch> m(new BaMultiBatch);
+    m->mode = mode;
+    m->bounds.resize(n_devices + 1);
+    if (ba_shard_slices(q_len, r_len, n, n_devices, m->bounds.data())) return nullptr;
+    m->part.resize(n_devices);
+    std::vector<std::string> errs(n_devices);
+    auto build = [&](int k) {
+        const size_t lo = m->bounds[k], cnt = m->bounds[k + 1] - lo;
+        if (cnt == 0) return;                                  // more devices than pairs: this one stays idle
+        g_device = devices[k];                                 // (thread-local)
+        BaBatch* b = ba_batch_create(kind, matrix, gaps, size, x_drop, mode, pool, q_off + lo, q_len + lo, r_off + lo, r_len + lo, cnt);
+        if (!b) errs[k] = g_err; else m->part[k].reset(b);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_devices; k++) th.emplace_back(build, k);
+    const int keep = g_device;
+    build(0);
+    g_device = keep;
+    for (auto& t : th) t.join();
+    for (int k = 0; k < n_devices; k++)
+        if (!errs[k].empty()) { fail("device %d: %s", devices[k], errs[k].c_str()); return nullptr; }
+    return m.release();
+}
+int ba_multibatch_run(BaMultiBatch* m, float* kernel_ms) {
+    if (!m) return fail("null batch");
+    for (auto& b : m->part) if (b && batch_launch(b.get())) return 1;        // all devices first ...
+    float worst = 0;
+    for (auto& b : m->part) {                                                // ... then collect
+        float ms = 0;
+        if (b && batch_wait(b.get(), &ms)) return 1;
+        worst = std::max(worst, ms);
+    }
+    if (kernel_ms) *kernel_ms = worst;
+    return 0;
+}
+int ba_multibatch_results(BaMultiBatch* m, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {
+    if (!m) return fail("null batch");
+    for (size_t k = 0; k < m->part.size(); k++) {
+        if (!m->part[k]) continue;
+        const size_t lo = m->bounds[k];
+        if (ba_batch_results(m->part[k].get(), score ? score + lo : nullptr, qi ? qi + lo : nullptr, ri ? ri + lo : nullptr, cells ? cells + lo : nullptr,
+                             cigar_len ? cigar_len + lo : nullptr, status ? status + lo : nullptr)) return 1;
+    }
+    return 0;
+}
+int ba_multibatch_cigars(BaMultiBatch* m, uint32_t* runs, uint64_t capacity) {
+    if (!m) return fail("null batch");
+    uint64_t at = 0;
+    for (auto& b : m->part) {
+        if (!b) continue;
+        std::vector<uint32_t> len(b->n);
+        HIP_TRY(hipSetDevice(b->device));
+        if (d2h(b->cig_len, len.data(), b->n)) return 1;
+        uint64_t total = 0;
+        for (uint32_t x : len) total += x;
+        if (at + total > capacity) return fail("cigar buffer too small: need more than %llu entries", (unsigned long long)capacity);
+        if (total && ba_batch_cigars(b.get(), runs + at, capacity - at)) return 1;
+        at += total;
+    }
+    return 0;
+}
+int ba_multibatch_parts(BaMultiBatch* m, uint64_t* bounds, int capacity) {   // slice boundaries (n_devices + 1 entries); returns n_devices
+    if (!m) return -1;
+    for (int k = 0; k < capacity && k < (int)m->bounds.size(); k++) bounds[k] = m->bounds[k];
+    return (int)m->part.size();
+}
+void ba_multibatch_destroy(BaMultiBatch* m) { delete m; }
 }  // extern "C"
 
 // ------------------------------------------------------------------ Block handles (Part 1 + generic)

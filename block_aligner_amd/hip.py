@@ -112,6 +112,14 @@ def lib() -> C.CDLL:
         L.ba_device_memory.argtypes = [vp, vp]
         L.ba_batch_info.argtypes = [vp, vp]
         L.ba_batch_destroy.argtypes = [vp]
+        L.ba_multibatch_create.restype = vp
+        L.ba_multibatch_create.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, u32, vp, vp, vp, vp, vp, sz, vp, C.c_int]
+        L.ba_multibatch_run.argtypes = [vp, C.POINTER(C.c_float)]
+        L.ba_multibatch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.ba_multibatch_cigars.argtypes = [vp, vp, C.c_uint64]
+        L.ba_multibatch_parts.argtypes = [vp, vp, C.c_int]
+        L.ba_multibatch_destroy.argtypes = [vp]
+        L.ba_shard_slices.argtypes = [vp, vp, sz, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -411,6 +419,70 @@ class BatchAligner:
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.ba_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def shard_slices(q_len, r_len, parts: int) -> np.ndarray:
+    """ba_shard_slices: boundaries of `parts` contiguous slices of near-equal summed |q| + |r| (needs no device)."""
+    q_len = np.ascontiguousarray(q_len, dtype=np.uint32); r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+    bounds = np.zeros(parts + 1, np.uint64)
+    if lib().ba_shard_slices(q_len.ctypes.data, r_len.ctypes.data, len(q_len), parts, bounds.ctypes.data):
+        raise RuntimeError(last_error())
+    return bounds
+
+
+class MultiBatchAligner:
+    """One batch over several GPUs (ba_multibatch_*): contiguous cost-balanced slices, one per entry of `devices`."""
+
+    def __init__(self, matrix, gaps, size, x_drop: int, mode: int, pool, q_off, q_len, r_off, r_len, devices):
+        L = lib()
+        self.n = len(q_len)
+        self.mode = mode
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64); r_off = np.ascontiguousarray(r_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32); r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+        raw = matrix.raw()
+        g = GapsC(gaps.open, gaps.extend) if isinstance(gaps, S.Gaps) else GapsC(gaps[0], gaps[1])
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self._h = L.ba_multibatch_create(matrix.KIND, raw.ctypes.data, g, _size(size), x_drop, mode, pool.ctypes.data, q_off.ctypes.data,
+                                         q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, self.n, dev.ctypes.data, len(dev))
+        if not self._h:
+            raise RuntimeError(last_error())
+
+    def run(self) -> float:
+        ms = C.c_float()
+        if lib().ba_multibatch_run(self._h, C.byref(ms)):
+            raise RuntimeError(last_error())
+        return ms.value
+
+    def results(self):
+        n = self.n
+        out = dict(score=np.zeros(n, np.int32), query_idx=np.zeros(n, np.uint32), reference_idx=np.zeros(n, np.uint32),
+                   cells=np.zeros(n, np.uint64), cigar_len=np.zeros(n, np.uint32), status=np.zeros(n, np.uint32))
+        if lib().ba_multibatch_results(self._h, *(out[k].ctypes.data for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"))):
+            raise RuntimeError(last_error())
+        return out
+
+    def cigars(self, cigar_len=None):
+        if cigar_len is None:
+            cigar_len = self.results()["cigar_len"]
+        off = np.zeros(self.n + 1, np.uint64)
+        np.cumsum(cigar_len, out=off[1:])
+        runs = np.zeros(int(off[-1]), np.uint32)
+        if lib().ba_multibatch_cigars(self._h, runs.ctypes.data, runs.size):
+            raise RuntimeError(last_error())
+        return runs, off
+
+    def parts(self):
+        b = np.zeros(65, np.uint64)
+        k = lib().ba_multibatch_parts(self._h, b.ctypes.data, 65)
+        return b[: k + 1].copy()
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.ba_multibatch_destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -15,6 +15,22 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def balanced_slices(q_len, r_len, parts: int):
+    """Boundaries of `parts` contiguous slices of near-equal summed cost |q| + |r| + 16 -- the rule of the library's
+    ba_shard_slices (ba_host.cpp), restated in numpy so a launcher can cut a global pair list the same way per rank."""
+    import numpy as np
+    cost = np.asarray(q_len, dtype=np.uint64) + np.asarray(r_len, dtype=np.uint64) + np.uint64(16)
+    pre = np.concatenate([[0], np.cumsum(cost)]).astype(np.uint64)
+    n, total = len(cost), int(pre[-1])
+    bounds = [0]
+    for k in range(1, parts):
+        target = total // parts * k + total % parts * k // parts
+        lo = int(np.searchsorted(pre, np.uint64(target), side="left"))
+        bounds.append(max(min(lo, n), bounds[-1]))
+    bounds.append(n)
+    return bounds
+
+
 def reduce_job(elapsed_s: float, cells: float, device=None):
     """-> (max elapsed over ranks, total cells over ranks). Works on any initialised backend (nccl on GPU, gloo on CPU)."""
     import torch

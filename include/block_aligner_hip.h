@@ -119,7 +119,8 @@ BA_DECLARE_BLOCK_FNS(aa_trace_xdrop, block_cigar_aa_trace_xdrop, block_cigar_eq_
 
 /* thread-local message for the last failing Part 2 call */
 const char* ba_last_error(void);
-/* number of usable HIP devices (0 if the runtime is unusable); ba_set_device selects the one later calls use */
+/* number of usable HIP devices (0 if the runtime is unusable); ba_set_device selects the one later calls OF THE CALLING
+ * THREAD use (the selection is per host thread, so one thread can drive each GPU) */
 int ba_device_count(void);
 int ba_set_device(int device);
 /* free / total bytes of the selected device's memory (hipMemGetInfo) */
@@ -226,6 +227,25 @@ int ba_batch_info(BaBatch* batch, uint64_t out[4]);
  * Number of pairs the last run re-ran (results are identical either way; -1 for a null batch). */
 int ba_batch_retried(BaBatch* batch);
 void ba_batch_destroy(BaBatch* batch);
+
+/* ---- one batch over several GPUs of a node (pairs are independent, so the batch shards without any exchange
+ * step). The pair list is cut into contiguous cost-balanced slices (cost = |q| + |r|), one per entry of `devices` (an
+ * entry may repeat a device); every slice is a batch of its own, built by its own host thread and launched on its own
+ * stream. Results and CIGAR runs come back in the caller's pair order, exactly as from a single ba_batch_*. */
+typedef struct BaMultiBatch BaMultiBatch;
+BaMultiBatch* ba_multibatch_create(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,
+                                   const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off,
+                                   const uint32_t* r_len, uintptr_t n_pairs, const int* devices, int n_devices);
+/* Launch on every device, then wait for all. kernel_ms (optional) = the longest device's kernel time. */
+int ba_multibatch_run(BaMultiBatch* batch, float* kernel_ms);
+int ba_multibatch_results(BaMultiBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells,
+                          uint32_t* cigar_len, uint32_t* status);
+int ba_multibatch_cigars(BaMultiBatch* batch, uint32_t* runs, uint64_t capacity);
+/* slice boundaries: bounds[k] .. bounds[k + 1] are the pairs of devices[k]; returns the number of slices */
+int ba_multibatch_parts(BaMultiBatch* batch, uint64_t* bounds, int capacity);
+void ba_multibatch_destroy(BaMultiBatch* batch);
+/* The slicing rule on its own (no device needed): bounds[0 .. parts] for contiguous slices of near-equal summed |q| + |r|. */
+int ba_shard_slices(const uint32_t* q_len, const uint32_t* r_len, uintptr_t n_pairs, int parts, uint64_t* bounds);
 
 enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16,
        BA_ST_SLOT_TIMEOUT = 32, BA_ST_MODE = 64 /* FREE_QUERY_END_GAPS reached a down step: the reference panics there */ };

@@ -556,3 +556,34 @@ def test_adaptive_trace_slots_rerun_overflows(hip, oracle, monkeypatch, margin):
         assert int(b.surviving_cells().sum()) > 0
     print(f"\nmargin {margin} %: {retried} of {len(pairs)} pairs re-run")
     b.close()
+
+
+def test_multibatch_slices_merge_in_caller_order(hip, oracle):
+    """ba_multibatch_*: the library cuts the pair list into cost-balanced contiguous slices, one batch per entry of
+    `devices`, built by concurrent host threads and launched on their own streams; results and CIGAR runs come back in the
+    caller's order, identical to a single batch. (A 1-GPU box runs the slices on the same device.)"""
+    pairs = synth.make_pairs(900, (0, 2500), (0, 200), 30, synth.DNA, seed=808)
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    one = hip.BatchAligner(NUC, (-5, -1), (32, 256), 70, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    one.run()
+    want = one.results()
+    want_runs, want_off = one.cigars(want["cigar_len"])
+    one.close()
+    ndev = hip.device_count()
+    for devices in ([0, 0], [0, 0, 0, 0, 0], list(range(ndev)) * 2):
+        m = hip.MultiBatchAligner(NUC, (-5, -1), (32, 256), 70, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, devices)
+        bounds = m.parts()
+        assert len(bounds) == len(devices) + 1 and bounds[0] == 0 and bounds[-1] == len(pairs)
+        assert [int(x) for x in bounds] == [int(x) for x in hip.shard_slices(pairs.q_len, pairs.r_len, len(devices))]
+        ms = m.run()
+        assert ms > 0
+        got = m.results()
+        for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"):
+            assert np.array_equal(got[k], want[k]), (devices, k)
+        runs, off = m.cigars(got["cigar_len"])
+        assert np.array_equal(runs, want_runs) and np.array_equal(off, want_off)
+        m.close()
+    ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 256), 70, ("trace", "x_drop"), cigar_eq=True, threads=8)
+    assert np.array_equal(want["score"], ref["scores"]) and np.array_equal(want["cigar_len"], ref["cig_len"])
+    with pytest.raises(RuntimeError, match="out of range"):
+        hip.MultiBatchAligner(NUC, (-5, -1), (32, 256), 70, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, [0, 99])

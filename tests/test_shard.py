@@ -48,3 +48,69 @@ def test_reduce_job_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert out == [(0, 2.0, 30.0), (1, 2.0, 30.0)]   # max elapsed, summed cells, identical on every rank
+
+
+def test_cost_balanced_slices_match_the_library():
+    """ba_shard_slices (what ba_multibatch_create cuts by) == shard.balanced_slices; slices are contiguous, cover everything
+    and differ in cost by at most one pair."""
+    import numpy as np
+    from block_aligner_amd import hip as H
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 17, 5000):
+        ql = rng.integers(0, 3000, n).astype(np.uint32); rl = rng.integers(0, 3000, n).astype(np.uint32)
+        if n == 5000:
+            ql[:50] = 200000          # a few very long pairs at the front
+        for parts in (1, 2, 3, 8):
+            lib_b = [int(x) for x in H.shard_slices(ql, rl, parts)]
+            assert lib_b == shard.balanced_slices(ql, rl, parts)
+            assert lib_b[0] == 0 and lib_b[-1] == n and all(a <= b for a, b in zip(lib_b, lib_b[1:]))
+            cost = ql.astype(np.int64) + rl + 16
+            sums = [int(cost[a:b].sum()) for a, b in zip(lib_b, lib_b[1:])]
+            if n >= parts * 4:
+                assert max(sums) - min(sums) <= 2 * int(cost.max())
+
+
+def _slice_worker(rank, world, port, q):
+    """Each rank aligns its cost-balanced slice of ONE global pair list (the oracle stands in for the device on CPU) and
+    rank 0 merges the slices in caller order."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from block_aligner_amd import scores as S
+    from oracle.oracle_py import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pairs = synth.make_pairs(64, (50, 900), (0, 60), 20, seed=99)          # the same global list on every rank
+    b = shard.balanced_slices(pairs.q_len, pairs.r_len, world)
+    lo, hi = b[rank], b[rank + 1]
+    sub = pairs.subset(np.arange(lo, hi))
+    o = Oracle("avx2")
+    m = S.NucMatrix.new_simple(2, -3)
+    ref = o.batch_align(m, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, (-5, -1), (32, 128), 50, ("x_drop",))
+    mine = torch.zeros(len(pairs), 3, dtype=torch.int64)
+    mine[lo:hi, 0] = torch.from_numpy(ref["scores"].astype(np.int64)); mine[lo:hi, 1] = torch.from_numpy(ref["query_idx"].astype(np.int64))
+    mine[lo:hi, 2] = torch.from_numpy(ref["reference_idx"].astype(np.int64))
+    dist.reduce(mine, dst=0, op=dist.ReduceOp.SUM)                          # slices are disjoint: the sum is the merge
+    if rank == 0:
+        full = o.batch_align(m, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 128), 50, ("x_drop",))
+        ok = (np.array_equal(mine[:, 0].numpy(), full["scores"]) and np.array_equal(mine[:, 1].numpy(), full["query_idx"])
+              and np.array_equal(mine[:, 2].numpy(), full["reference_idx"]))
+        q.put(("merged", ok, b))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_batch_merges_in_caller_order_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slice_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    tag, ok, bounds = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+    assert tag == "merged" and ok and bounds[0] == 0 and bounds[-1] == 64 and 0 < bounds[1] < 64
