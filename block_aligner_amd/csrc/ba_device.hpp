@@ -382,13 +382,31 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
 // height / 2 lanes are active. width is a multiple of 8.
 // PDIR (KIND_PROFILE only): 1 = vectors along the query, one profile position per column (place_block_profile_right,
 // scan_block.rs:612-783 with $right = true); 2 = vectors along the profile, one query residue per column.
+// Row tiling of rectangles taller than the register budget (blocks of 4096 .. 32768 cells): the rectangle is filled tile by
+// tile, each a place_rect call over TILE rows and all columns; a tile hands its last row (D and R per column) to the tile
+// below through two scratch arrays, which is all the recurrence needs across the cut (scan_block.rs:1123-1150: D00 from the
+// previous column, the R carry from the row above). The reference's 16-lane vectors never straddle a tile (TILE % 16 == 0).
+struct TileCtx {
+    int ch_base, nch_total;     // where this tile's chunks sit in the rectangle's trace layout
+    bool first, last;           // first: the rows above are outside the rectangle; last: its last row feeds the real orthogonal border
+    int corner0;                // !first: D of the cell above the tile in the column left of the rectangle (already re-based)
+    const short* topD; const short* topR;   // !first: D and R of the row above, per column (the tile above wrote them; overwritten in place)
+    bool break_armed;           // the whole rectangle's early-break condition (scan_block.rs:1216-1224)
+};
+// uniform value from memory this kernel also writes: a vector load (never the scalar cache), then broadcast
+__device__ __forceinline__ int load_uniform_i16(const short* p) {
+    uintptr_t a = (uintptr_t)p;
+    asm volatile("" : "+v"(a));
+    return uni((int)*(const short*)a);
+}
+
 template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false, int PDIR = 0, bool FULL128 = false>
 __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
                                            short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out,
                                            unsigned long long& cells, FastIO* fs = nullptr, unsigned long long* tacc_prof = nullptr,
-                                           uint32_t sp = 0, FqeOut* fq = nullptr, const ProfileView* pv = nullptr) {
+                                           uint32_t sp = 0, FqeOut* fq = nullptr, const ProfileView* pv = nullptr, const TileCtx* tc = nullptr) {
     BA_TSTAMP(tp0);
     static_assert(!FAST || NCH == 1, "the fast path handles single-chunk steps");
     static_assert((KIND == KIND_PROFILE) == (PDIR != 0) && !(FAST && PDIR), "profile rectangles take the generic path with a direction");
@@ -464,7 +482,11 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         dmax[ch] = 0; jlast[ch] = 0; tacc[ch] = 0;
         key[ch] = make_key<KIND>(a, b);
     }
-    const bool break_armed = !XDROP && !(sp & SP_FQE) && (start_i + height > lenV);
+    const bool break_armed = tc ? tc->break_armed : (!XDROP && !(sp & SP_FQE) && (start_i + height > lenV));
+    const int NCHT = tc ? tc->nch_total : NCH, CHB = tc ? tc->ch_base : 0;   // trace layout of the whole rectangle
+    const bool below = tc && !tc->first;                                      // rows above this tile belong to the rectangle
+    int top_d_hold = below ? tc->corner0 : 0, top_d_next = 0, top_r_next = 0;
+    if (below) { top_d_next = load_uniform_i16(tc->topD); top_r_next = load_uniform_i16(tc->topR); }
     const int rz2 = splat(rel_zero);
     const uint32_t zwords = (width >> 2) * (uint32_t)(NCH * nl);   // SP_LOCAL: the zero mask follows the rectangle's trace words
     int corner_cur = corner;
@@ -548,6 +570,10 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
+        if (below) {   // the tile above supplies both (its values for the next column are fetched before this column overwrites its own)
+            up_d = (int)((uint32_t)top_d_hold << 16); carry_r = top_r_next; top_d_hold = top_d_next;
+            if (j + 1 < width) { top_d_next = load_uniform_i16(tc->topD + j + 1); top_r_next = load_uniform_i16(tc->topR + j + 1); }
+        }
         const int jp1 = splat((int)j + 1);
         int r_last = 0;
 #pragma unroll
@@ -620,7 +646,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             // that are stored later: the next column group, the next rectangle, or the slack behind the slot)
             if (FAST || active) {
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCH + ch) * nl + lane] = (uint32_t)tacc[ch];
+                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCHT + CHB + ch) * nl + lane] = (uint32_t)tacc[ch];
             }
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) tacc[ch] = 0;
@@ -633,7 +659,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCH + ch) * nl + lane] = (uint32_t)tacc[ch];
+                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCHT + CHB + ch) * nl + lane] = (uint32_t)tacc[ch];
             }
             return false;
         }

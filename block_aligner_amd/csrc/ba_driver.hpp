@@ -9,8 +9,15 @@ namespace ba {
 // ------------------------------------------------------------------ LDS border helpers (whole wave cooperates)
 // Lanes exchange border data through LDS. The hardware executes one wave's LDS operations in program order; this
 // keeps the compiler from reordering them across a hand-off point (no instruction is emitted beyond waits).
+#ifndef BA_BIG
+#define BA_BIG 0   // 1: the kernels of this TU (class BA_PMAX = 32) handle blocks of 4096 .. 32768 cells (borders in global memory, tiled fill)
+#endif
+constexpr bool kBig = BA_BIG != 0;
 __device__ __forceinline__ void lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // (big-block kernels keep the borders in global memory: a workgroup-scope fence drains this wave's stores and drops its
+    // CU's stale L1 lines before another lane reads them back)
+    if (kBig) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void lds_fill0(short* a, uint32_t n) {
@@ -466,6 +473,7 @@ struct Aligner {
     const uint8_t* q; const uint8_t* r;
     uint32_t qlen, rlen;
     uint32_t* trace; BlockRec* blocks; short* ckpt;   // this wave's slot in the global scratch arenas
+    short* big_top = nullptr;                         // big-block kernels: the row hand-off arrays of the tiled fill (2 x big_array_shorts)
     uint32_t trace_top = 0, nblocks = 0;
     int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot, 9-11 the first grow rectangle's max / row / col (see park())
     uint32_t status = 0;
@@ -514,7 +522,7 @@ struct Aligner {
         uint32_t si = in.si, sj = in.sj; int dir = in.dir, prev_dir = in.prev_dir, off = in.off, prev_off = in.prev_off, off_max = in.off_max;
         int off_add = in.off_add, best_max = in.best_max; uint32_t y_drop_iter = in.y_drop_iter; int x_drop_iter = in.x_drop_iter, D_corner = in.D_corner;
         uint32_t step_budget = in.step_budget; int run_exit = RUN_EXIT_POST; FastOut fo{};
-        constexpr int PR_DIST = (int)(lds_array_bytes_h(PMAX * 128) / 2);   // D_row -> R_row and D_col -> C_col, in entries
+        constexpr int PR_DIST = (int)(lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u) / 2);   // D_row -> R_row and D_col -> C_col, in entries
         const int lane = lane_id();
         const int nl = (int)(B >> 1);
         int Dcol, Ccol, Drow, Rrow;
@@ -793,7 +801,7 @@ struct Aligner {
             }
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
             BA_TSTAMP(tsa);
-            const bool fast = KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV);
+            const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
@@ -811,7 +819,41 @@ struct Aligner {
             const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
 #define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
 #define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
-            if (fast) {
+            if (kBig && rh > BIG_TILE) {
+                // ---- row tiles of BIG_TILE cells (TileCtx): the tile above hands its last row over through big_top
+                const uint32_t ntiles = rh / BIG_TILE;
+                int corner_t[16];                       // D above each tile in the column left of the rectangle: the old border, re-based
+                lds_sync();
+#pragma unroll
+                for (uint32_t t = 1; t < 16; t++)
+                    corner_t[t] = t < ntiles ? uni((int)as_s(adds(splat((int)Dc[t * BIG_TILE - 1]), splat(off_add))).x) : 0;
+                const bool brk = !XDROP && (ri + rh > lenV);
+                for (uint32_t t = 0; t < ntiles; t++) {
+                    TileCtx tc;
+                    tc.ch_base = (int)(t * (BIG_TILE / 128)); tc.nch_total = (int)(rh / 128); tc.first = t == 0; tc.last = t + 1 == ntiles;
+                    tc.corner0 = 0;
+#pragma unroll
+                    for (uint32_t u = 1; u < 16; u++) if (u == t) tc.corner0 = corner_t[u];
+                    tc.topD = big_top; tc.topR = big_top + big_array_shorts(h_max_size); tc.break_armed = brk;
+                    short* oD = tc.last ? Dr : big_top; short* oR = tc.last ? Rr : big_top + big_array_shorts(h_max_size);
+                    Best part;
+#define BA_TILE1(PD) part = place_rect<(int)(BIG_TILE / 128), KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri + t * BIG_TILE, rj, rw, BIG_TILE, \
+                                   Dc + t * BIG_TILE, Cc + t * BIG_TILE, oD, oR, t == 0 ? corner : 0, rz, off_add, tout, cells, nullptr, prof, 0u, nullptr, &pv, &tc)
+                    if constexpr (KIND == KIND_PROFILE) { if (right) BA_TILE1(1); else BA_TILE1(2); } else BA_TILE1(0);
+#undef BA_TILE1
+                    part.row += (int)(t * BIG_TILE);
+                    // the rectangle's maximum and its location: largest value, then smallest row % 16, largest column, largest row
+                    // (the order in which place_rect resolves ties inside a tile; tiles are multiples of 16 rows)
+                    bool take = t == 0 || part.mx > cur.mx;
+                    if (XDROP && t > 0 && part.mx == cur.mx) {
+                        const int a = part.row & 15, b = cur.row & 15;
+                        take = a < b || (a == b && (part.col > cur.col || (part.col == cur.col && part.row > cur.row)));
+                    }
+                    if (take) cur = part;
+                    lds_sync();
+                }
+            }
+            else if (fast) {
                 if constexpr (KIND != KIND_PROFILE) {
                     // ---- a run of plain shift steps with the four borders in registers (fast_rect). The run ends -- with the last
                     // step's results handed to the generic post-processing below -- as soon as a step calls for anything but
@@ -1021,8 +1063,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
     // The LDS layout depends only on the kernel's block class (PMAX * 128 cells), not on the batch's max size: the
     // four border arrays then sit at compile-time offsets from one per-wave base, i.e. in the immediate offset field of
     // the DS instructions instead of in five SGPRs (which the step loop does not have: they were spilled and reloaded).
-    constexpr uint32_t ab = lds_array_bytes_h(PMAX * 128);
-    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(PMAX * 128);
+    constexpr uint32_t LCLS = kBig ? 128u : (uint32_t)PMAX * 128u;   // LDS layout class (big-block kernels keep only misc in LDS)
+    constexpr uint32_t ab = lds_array_bytes_h(LCLS);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(LCLS);
     WaveLds L;
     L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
     L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
@@ -1055,7 +1098,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
-                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(PMAX * 128), 64u, true);
+                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(LCLS), 64u, true);
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -1091,6 +1134,12 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
             al.ckpt = bp.ckpt + (uint64_t)fill_wave * 4 * bp.max_size;
+            if (kBig) {   // the four borders live in this wave's slice of the big arena, not in LDS
+                short* bw = bp.big + (uint64_t)fill_wave * big_wave_shorts(bp.max_size);
+                const uint64_t as = big_array_shorts(bp.max_size);
+                L.D_col = bw; L.C_col = bw + as; L.D_row = bw + 2 * as; L.R_row = bw + 3 * as;
+                al.big_top = bw + 4 * as;
+            }
             al.run(pair, slot, batch_traceback);
         }
 #ifdef BA_TIMING

@@ -31,6 +31,10 @@ using ba::BlockRec;
     extern "C" hipError_t ba_occupancy_s_k##K##_p##P(int, int, unsigned, int*);
 #define BA_DECL_KIND(K) BA_DECL(K, 1) BA_DECL(K, 2) BA_DECL(K, 4) BA_DECL(K, 8) BA_DECL(K, 16)
 BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
+#define BA_DECL_BIG(K)                                                                                                  \
+    extern "C" hipError_t ba_launch_big_k##K##_p32(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
+    extern "C" hipError_t ba_occupancy_big_k##K##_p32(int, int, unsigned, int*);
+BA_DECL_BIG(0) BA_DECL_BIG(1) BA_DECL_BIG(2) BA_DECL_BIG(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_merge_retry(hipStream_t, const uint32_t*, uint32_t, const BatchParams*, const BatchParams*, const uint32_t*, uint32_t*);
@@ -46,6 +50,9 @@ typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 // [special modes?][kind][block class]
 static const LaunchFn g_launch[2][4][5] = {{BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)}, {BA_SROW(0), BA_SROW(1), BA_SROW(2), BA_SROW(3)}};
 static const OccFn g_occ[2][4][5] = {{BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)}, {BA_SOROW(0), BA_SOROW(1), BA_SOROW(2), BA_SOROW(3)}};
+static const LaunchFn g_launch_big[4] = {ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32};
+static const OccFn g_occ_big[4] = {ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32};
+constexpr int BA_PCLASS_BIG = 5;
 static inline int special_of(uint32_t mode) { return (mode & (BA_LOCAL_START | BA_FREE_QUERY_START_GAPS | BA_FREE_QUERY_END_GAPS)) ? 1 : 0; }
 constexpr int BA_KIND_PROFILE_ = ba::KIND_PROFILE;   // batches whose "reference" is an AAProfile (sequence bytes: AA alphabet)
 
@@ -180,7 +187,7 @@ struct BaBatch {
     bool adaptive = false;      // trace_stride < trace_full: pairs that overflow their slot are re-run by batch_wait
     uint32_t retried = 0;       // pairs the last run had to re-run with full-size slots
     uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
-    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace_words, trace, blocks, ckpt, counter,
+    DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace_words, trace, blocks, ckpt, big, counter,
            tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
     std::vector<uint32_t> h_order;   // device order -> caller's pair index (empty: identical); see Packed::order
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1, tb_reserve = 0;
@@ -202,7 +209,7 @@ struct BaBatch {
         bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>(); bp.trace_words_out = trace_words.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
-        bp.ckpt = ckpt.as<short>();
+        bp.ckpt = ckpt.as<short>(); bp.big = big.as<short>();
         bp.tb_stride = tb_stride; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots; bp.tb_reserve = tb_reserve;
         bp.tb_qmask = tb_qsize - 1;
         bp.tb_queue = tb_queue.as<uint32_t>(); bp.tb_ctrl = tb_ctrl.as<uint32_t>();
@@ -233,15 +240,17 @@ static int check_align_params(bool profile, Gaps g, size_t min_size, size_t max_
     return 0;
 }
 
-constexpr size_t BA_MAX_BLOCK = 2048;
-static int pclass_of(size_t max_size) {   // index into {1,2,4,8,16} packed registers per lane
+constexpr size_t BA_MAX_BLOCK = 32768;   // the reference takes any power of two below 65535 (scan_block.rs:855)
+static int pclass_of(size_t max_size) {   // index into {1,2,4,8,16} packed registers per lane; 5 = tiled (blocks above 2048 cells)
     if (max_size <= 128) return 0;
     if (max_size == 256) return 1;
     if (max_size == 512) return 2;
     if (max_size == 1024) return 3;
     if (max_size == 2048) return 4;
+    if (max_size == 4096 || max_size == 8192 || max_size == 16384 || max_size == 32768) return BA_PCLASS_BIG;
     return -1;
 }
+static inline uint32_t lds_class_cells(int pc) { return pc == BA_PCLASS_BIG ? 128u : 128u << pc; }   // LDS layout class of a kernel class
 
 // Build a batch from already-converted byte ranges. `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1).
 // AAProfile -> device image (layout in ba_params.h). `P` positions, defaults (-128) beyond the profile's own length.
@@ -409,13 +418,15 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
-    b->lds = ba::lds_wg_bytes_h(kind, 128u << pc) + (trace ? ba::TB_LDS_BYTES : 0u);
+    if (pc == BA_PCLASS_BIG && special_of(mode)) return fail("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
+    b->lds = ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    if (g_occ[special_of(mode)][kind][pc](trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[kind] : g_occ[special_of(mode)][kind][pc];
+    if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
     if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
@@ -503,6 +514,7 @@ static int batch_alloc_scratch(BaBatch* b) {
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * b->max_size * sizeof(short));
+    BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short) : 0);
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
 #undef BA_ALLOC
@@ -650,7 +662,8 @@ static int batch_launch(BaBatch* b) {
     }
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    HIP_TRY(g_launch[special_of(b->mode)][b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : g_launch[special_of(b->mode)][b->kind][b->pclass];
+    HIP_TRY(launch((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     b->in_flight = true;
     return 0;
@@ -1235,7 +1248,8 @@ static int handle_prepare(BlockImpl* h) {
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail("hipEventCreate failed");
     if (b->hblk.alloc(b->cap_pool) || b->rblk.alloc(sizeof(HandleResult)) || b->matrix.alloc(1024) || b->cig_ops.alloc((trace ? b->cap_cig : 1) * 4) ||
         b->trace.alloc(b->trace_stride * 4) || b->blocks.alloc(b->blocks_stride * sizeof(BlockRec)) ||
-        b->ckpt.alloc((size_t)ba::WAVES_PER_WG * 4 * max_size * sizeof(short)) || b->prof.alloc(512) || b->tb_ctrl.alloc(256) ||
+        b->ckpt.alloc((size_t)ba::WAVES_PER_WG * 4 * max_size * sizeof(short)) ||
+        b->big.alloc(max_size > 2048 ? (size_t)ba::WAVES_PER_WG * ba::big_wave_shorts((uint32_t)max_size) * sizeof(short) : 0) || b->prof.alloc(512) || b->tb_ctrl.alloc(256) ||
         b->tb_queue.alloc(4) || b->slot_free.alloc(4) || b->slot_info.alloc(sizeof(ba::SlotInfo))) return 1;
     uint8_t* hb = b->hblk.as<uint8_t>(); uint8_t* rb = b->rblk.as<uint8_t>();
     b->pool.view(hb, b->cap_pool);   // the images' offsets are relative to the start of hblk
@@ -1268,7 +1282,8 @@ static void handle_align(BlockImpl* h, int kind, const PaddedBytes* q, const Pad
     if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > q->len)) die("Min block size must be larger than the query length for FREE_QUERY_END_GAPS!");   // scan_block.rs:860-862
     b->kind = kind; b->mode = mode; b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
     b->gap_open = g.open; b->gap_extend = g.extend; b->x_drop = x;
-    b->lds = ba::lds_wg_bytes_h(kind, 128u << pc) + (trace ? ba::TB_LDS_BYTES : 0u);
+    if (pc == BA_PCLASS_BIG && special_of(mode)) die("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
+    b->lds = ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
     // ---- the upload: per-pair words + the two padded images (scan_block.rs:1798-1812), built in the handle's staging buffer
     const size_t pad = max_size + 16;
     const uint32_t ql = (uint32_t)q->len, rl = (uint32_t)(profile ? profile->str_len : r->len);

@@ -16,7 +16,10 @@
 
 #define BA_CAT_(a, b, c, d) a##b##c##d
 #define BA_CAT(a, b, c, d) BA_CAT_(a, b, c, d)
-#if BA_SPECIAL
+#if BA_BIG   // blocks of 4096 .. 32768 cells (one class per kind; the special alignment modes stop at 2048)
+#define BA_LAUNCH BA_CAT(ba_launch_big_k, BA_KIND, _p, BA_PMAX)
+#define BA_OCC BA_CAT(ba_occupancy_big_k, BA_KIND, _p, BA_PMAX)
+#elif BA_SPECIAL
 #define BA_LAUNCH BA_CAT(ba_launch_s_k, BA_KIND, _p, BA_PMAX)
 #define BA_OCC BA_CAT(ba_occupancy_s_k, BA_KIND, _p, BA_PMAX)
 #else
@@ -51,7 +54,7 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
     return xdrop ? occ1<false, true>(blocks_per_cu, lds) : occ1<false, false>(blocks_per_cu, lds);
 }
 
-#if BA_KIND == 0 && BA_PMAX == 1 && !BA_SPECIAL
+#if BA_KIND == 0 && BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
 // kernels that exist once
 // Traceback from an arbitrary end cell over slot 0's trace (the per-handle API: block_cigar_* after block_align_*).
 __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {

@@ -56,6 +56,8 @@ struct BatchParams {
     uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot
     short* ckpt;                 // per fill wave: 4 x max_size i16 (best-so-far borders, scan_block.rs:406-427)
+    short* big;                  // block sizes above 2048 only: per fill wave big_wave_shorts(max_size) i16 -- the four live borders
+                                 // (too large for LDS) and the two row hand-off arrays of the tiled fill (ba_device.hpp TileCtx)
     uint32_t* work_counter;
     unsigned long long* prof;    // development (-DBA_TIMING builds): per-phase cycle sums, 32 slots
     // in-launch hand-off of finished trace stacks from fill waves to traceback lanes (TRACE batches)
@@ -72,6 +74,11 @@ struct BatchParams {
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;
 };
 
+
+// blocks of 4096 .. 32768 cells: borders in an L2-resident arena, rectangles filled in row tiles of BIG_TILE cells
+constexpr uint32_t BIG_TILE = 2048;
+BA_HD constexpr uint64_t big_array_shorts(uint32_t max_size) { return (uint64_t)max_size + 64; }
+BA_HD constexpr uint64_t big_wave_shorts(uint32_t max_size) { return 6 * big_array_shorts(max_size); }
 
 constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
 

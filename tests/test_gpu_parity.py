@@ -507,8 +507,10 @@ def test_batch_api_errors_and_coexisting_batches(hip, oracle):
         hip.BatchAligner(NUC, (5, -1), (32, 64), 0, 0, *args)
     with pytest.raises(RuntimeError, match="powers of two"):
         hip.BatchAligner(NUC, (-5, -1), (48, 64), 0, 0, *args)
-    with pytest.raises(RuntimeError, match="not supported"):
-        hip.BatchAligner(NUC, (-5, -1), (32, 4096), 0, 0, *args)
+    with pytest.raises(RuntimeError, match="supported up to a max block size of 2048"):
+        hip.BatchAligner(NUC, (-5, -1), (32, 4096), 0, hip.LOCAL_START, *args)
+    with pytest.raises(RuntimeError, match="smaller than 2\\^16"):
+        hip.BatchAligner(NUC, (-5, -1), (32, 65536), 0, 0, *args)
     with pytest.raises(RuntimeError, match="LOCAL_START"):
         hip.BatchAligner(NUC, (-5, -1), (32, 64), 0, hip.LOCAL_START | hip.FREE_QUERY_START_GAPS, *args)
     with pytest.raises(RuntimeError):
@@ -587,3 +589,25 @@ def test_multibatch_slices_merge_in_caller_order(hip, oracle):
     assert np.array_equal(want["score"], ref["scores"]) and np.array_equal(want["cigar_len"], ref["cig_len"])
     with pytest.raises(RuntimeError, match="out of range"):
         hip.MultiBatchAligner(NUC, (-5, -1), (32, 256), 70, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, [0, 99])
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",), ("x_drop",), ()])
+@pytest.mark.parametrize("size", [(128, 4096), (1024, 8192), (2048, 16384)])
+def test_big_blocks(hip, oracle, mode, size):
+    """Block sizes above 2048 (the reference takes any power of two below 2^16 - 1, scan_block.rs:855; percent_len returns up to
+    16384, lib.rs:109-111; nanopore_bench_global runs 1 % - 10 % of < 50 kbp reads, examples/nanopore_bench_global.rs:144-183):
+    borders in the L2-resident arena, rectangles filled in row tiles of 2048 cells. 60 kbp pairs with kb-scale insertions and
+    deletions make the block grow through every size up to the maximum."""
+    pairs = synth.make_pairs(5, (40000, 60000), (2000, 5000), 300, synth.DNA, seed=size[1] + len(mode), indels=4, indel_len=(800, 6000), workers=4)
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 400, mode)
+    assert res["cells"].max() > 60000 * size[0]
+
+
+def test_percent_len_sizes_are_accepted(hip, oracle):
+    """Every size block_percent_len can return is a size the batch constructor takes (lib.rs:109-111: up to 16384)."""
+    assert hip.percent_len(10 ** 7, 0.1) == 16384 and hip.percent_len(60000, 0.1) == 8192
+    pairs = synth.make_pairs(3, 3000, 200, 50, synth.DNA, seed=4)
+    for mx in (4096, 8192, 16384, 32768):
+        compare(hip, oracle, pairs, NUC, (-5, -1), (32, mx), 60, ("trace", "x_drop"))
+    prot = synth.make_pairs(3, (2000, 5000), (200, 900), 0, synth.AMINO, seed=6, indels=2, indel_len=(300, 1500))
+    compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 4096), 0, ("trace",), cigar_eq=False)
