@@ -412,7 +412,7 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
 
 // Launch geometry and scratch sizes of a batch whose inputs are known: workgroups, LDS, trace slot size, traceback waves,
 // slots per wave, hand-off ring. fixed_bytes = device memory the batch needs besides its per-wave scratch.
-static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxlen2, bool full_trace) {
+static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxlen2, bool full_trace, uint64_t avg_len2 = ~0ull) {
     const int kind = b->kind; const uint32_t mode = b->mode; const int pc = (int)b->pclass; const size_t max_size = b->max_size;
     const bool trace = mode & BA_TRACE;
     hipDeviceProp_t prop;
@@ -470,12 +470,17 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
     b->tb_stride = 0; b->slots_per_wave = 1;
     b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
-    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !getenv("BA_INLINE_TRACEBACK")) {
+    // Short pairs: a walk is a few hundred dependent steps, cheaper done at once by the fill wave's lane 0 than handed to a
+    // traceback lane (protein pairs of ~300 residues, block 32..256: 202 vs 99 GCUPS; 1 kbp DNA pairs already prefer the hand-off).
+    const bool short_pairs = kind != BA_KIND_PROFILE_ && avg_len2 <= 1024 && !getenv("BA_FORCE_TB");
+    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !getenv("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
         // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
         // no difference now that a walk runs out of LDS.)
-        uint32_t stride = b->grid >= 32 ? 4 : 2;
+        // (the traceback work per filled cell grows as the block shrinks: with blocks below 128 cells one wave per 3
+        // workgroups -- 1 kbp DNA, block 32..256: 360 GCUPS against 285 at one per 4)
+        uint32_t stride = b->grid >= 32 ? (b->min_size >= 128 ? 4 : 3) : 2;
         if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
@@ -587,7 +592,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     const bool trace = mode & BA_TRACE;
     const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : (profile ? 0 : 2));
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
-    if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false)) return nullptr;
+    uint64_t sum_len2 = 0;
+    for (size_t p = 0; p < n; p++) sum_len2 += (uint64_t)ql[p] + rl[p];
+    if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
     b->cig_total = trace ? cig_total : 0;
 
     lap("launch geometry");
