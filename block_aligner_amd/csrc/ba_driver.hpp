@@ -679,17 +679,19 @@ struct Aligner {
             lds_sync();
             return;
         }
-        // drain this wave's checkpoint stores and drop stale L1 lines before reading them back
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        // The wave reads back its own checkpoint stores: loads that bypass this CU's L1 (agent-scope relaxed = `sc1`, served by
+        // L2, where the wave's earlier stores to the same addresses have arrived in program order) instead of an agent-scope
+        // fence -- a fence writes back and invalidates for the whole XCD, and short pairs grow often.
         const uint32_t ms = h_max_size;
         for (uint32_t k = 2 * lane_id(); k < n; k += 128) {
-            *(int*)(L.D_col + k) = *(const int*)(ckpt + k);
-            *(int*)(L.C_col + k) = *(const int*)(ckpt + ms + k);
-            *(int*)(L.D_row + k) = *(const int*)(ckpt + 2 * ms + k);
-            *(int*)(L.R_row + k) = *(const int*)(ckpt + 3 * ms + k);
+            *(int*)(L.D_col + k) = ckpt_load(ckpt + k);
+            *(int*)(L.C_col + k) = ckpt_load(ckpt + ms + k);
+            *(int*)(L.D_row + k) = ckpt_load(ckpt + 2 * ms + k);
+            *(int*)(L.R_row + k) = ckpt_load(ckpt + 3 * ms + k);
         }
         lds_sync();
     }
+    __device__ __forceinline__ static int ckpt_load(const short* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }
 
     // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done). The wait only
     // gives up when the traceback side as a whole has stopped making progress: no task claimed for ~2 s, scaled by the
@@ -728,8 +730,33 @@ struct Aligner {
         }
     }
 
+    // Write this pair's loop-top state as a PairCont record (block of 32 cells: 16 lanes hold each border).
+    __device__ __forceinline__ void suspend(uint32_t pair, uint32_t si, uint32_t sj, int dir, int prev_dir, int off, int off_max, int best_max,
+                                            uint32_t y_drop_iter, int x_drop_iter, int D_corner, uint32_t step_budget) {
+        PairCont* c = coldp()->cont_out + pair;
+        const int lane = lane_id();
+        lds_sync();
+        if (is_lane(0)) {
+            coldp()->cont_out_flag[pair] = 1u;
+            c->pair = pair; c->si = si; c->sj = sj; c->dir = dir; c->prev_dir = prev_dir; c->off = off; c->off_max = off_max; c->best_max = best_max;
+            c->y_drop_iter = y_drop_iter; c->x_drop_iter = x_drop_iter; c->D_corner = D_corner;
+            c->best_i = (uint32_t)unpark<5>(parked); c->best_j = (uint32_t)unpark<6>(parked);
+            c->ck_i = (uint32_t)unpark<0>(parked); c->ck_j = (uint32_t)unpark<1>(parked); c->ck_off = unpark<2>(parked);
+            c->cells = cells; c->step_budget = step_budget;
+        }
+        if (lane < 16) {
+            c->borders[0][lane] = (uint32_t)*(const int*)(L.D_col + 2 * lane); c->borders[1][lane] = (uint32_t)*(const int*)(L.C_col + 2 * lane);
+            c->borders[2][lane] = (uint32_t)*(const int*)(L.D_row + 2 * lane); c->borders[3][lane] = (uint32_t)*(const int*)(L.R_row + 2 * lane);
+            if (ck_in_regs) { for (int k = 0; k < 4; k++) c->ckpt[k][lane] = (uint32_t)ck_reg[k]; }
+            else {   // (this wave's own checkpoint stores, read back past the L1: see restore_ckpt_borders)
+                const uint32_t ms = h_max_size;
+                for (int k = 0; k < 4; k++) c->ckpt[k][lane] = (uint32_t)ckpt_load(ckpt + k * ms + 2 * lane);
+            }
+        }
+    }
+
     // (always inlined: as a real call the Aligner object and everything it references would live in scratch memory)
-    __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback) {
+    __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr) {
         q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
         qlen = coldp()->q_len[pair_in]; rlen = coldp()->r_len[pair_in];
         const uint32_t min_size = coldp()->min_size, max_size = h_max_size;
@@ -765,6 +792,22 @@ struct Aligner {
 #ifdef BA_TIMING
         uint32_t steps = 0;
 #endif
+        if (!TRACE && resume) {   // a pair that comes back from the small-block kernel: its state at the top of the loop
+            const int lane = lane_id();
+            si = resume->si; sj = resume->sj; dir = resume->dir; prev_dir = resume->prev_dir; off = resume->off; off_max = resume->off_max;
+            best_max = resume->best_max; y_drop_iter = resume->y_drop_iter; x_drop_iter = resume->x_drop_iter; D_corner = resume->D_corner;
+            cells = resume->cells; step_budget = resume->step_budget;
+            park<5>(parked, (int)resume->best_i); park<6>(parked, (int)resume->best_j);
+            park<0>(parked, (int)resume->ck_i); park<1>(parked, (int)resume->ck_j); park<2>(parked, resume->ck_off);
+            if (lane < 16) {
+                *(int*)(L.D_col + 2 * lane) = (int)resume->borders[0][lane]; *(int*)(L.C_col + 2 * lane) = (int)resume->borders[1][lane];
+                *(int*)(L.D_row + 2 * lane) = (int)resume->borders[2][lane]; *(int*)(L.R_row + 2 * lane) = (int)resume->borders[3][lane];
+                ck_reg[0] = (int)resume->ckpt[0][lane]; ck_reg[1] = (int)resume->ckpt[1][lane];
+                ck_reg[2] = (int)resume->ckpt[2][lane]; ck_reg[3] = (int)resume->ckpt[3][lane];
+            }
+            ck_in_regs = true;
+            lds_sync();
+        }
         BA_TSTAMP(tr0);
         for (;;) {
             BA_TSTAMP(ts0);
@@ -803,6 +846,13 @@ struct Aligner {
             BA_TSTAMP(tsa);
             const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
+            if (!TRACE && fast && block_size == 32 && coldp()->cont_mode == 1) {
+                // small-block batch, first pass: the pair leaves for the 4-pairs-per-wave kernel at its first register-path step.
+                // What is written is the state the top of this loop would start the step from (the set-up above is undone).
+                step_budget++; off = prev_off;
+                suspend(pair_in, si, sj, dir, prev_dir, off, off_max, best_max, y_drop_iter, x_drop_iter, D_corner, step_budget);
+                return;
+            }
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
             if (TRACE && !fast) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
@@ -1109,11 +1159,21 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
         const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
         const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
         uint32_t turn = 0;
+        uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter: bp.work_chunk pairs per atomic
         for (;;) {
-            uint32_t pair = 0;
-            if (is_lane(0)) pair = atomicAdd(bp.work_counter, 1u);
-            pair = (uint32_t)uni((int)pair);
-            if (pair >= bp.n) break;
+            if (w_next == w_end) {
+                uint32_t v = 0;
+                if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
+                w_next = (uint32_t)uni((int)v);
+                if (w_next >= bp.n) break;
+                w_end = min(w_next + bp.work_chunk, bp.n);
+            }
+            uint32_t pair = w_next++;
+            const PairCont* rec = nullptr;
+            if (!TRACE && bp.cont_mode == 2) {   // only the pairs the small-block kernel left a record for are still in flight
+                if (!bp.cont_in_flag[pair]) continue;
+                rec = bp.cont_in + pair;
+            }
             const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
             if (++turn == bp.slots_per_wave) turn = 0;
             Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
@@ -1140,7 +1200,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                 L.D_col = bw; L.C_col = bw + as; L.D_row = bw + 2 * as; L.R_row = bw + 3 * as;
                 al.big_top = bw + 4 * as;
             }
-            al.run(pair, slot, batch_traceback);
+            al.run(pair, slot, batch_traceback, rec);
         }
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());

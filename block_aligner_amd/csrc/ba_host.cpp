@@ -50,6 +50,11 @@ typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 // [special modes?][kind][block class]
 static const LaunchFn g_launch[2][4][5] = {{BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)}, {BA_SROW(0), BA_SROW(1), BA_SROW(2), BA_SROW(3)}};
 static const OccFn g_occ[2][4][5] = {{BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)}, {BA_SOROW(0), BA_SOROW(1), BA_SOROW(2), BA_SOROW(3)}};
+typedef hipError_t (*QuadFn)(int, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k0(int, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k1(int, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k2(int, hipStream_t, const BatchParams*);
+static const QuadFn g_launch_quad[3] = {ba_launch_quad_k0, ba_launch_quad_k1, ba_launch_quad_k2};
 static const LaunchFn g_launch_big[4] = {ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32};
 static const OccFn g_occ_big[4] = {ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32};
 constexpr int BA_PCLASS_BIG = 5;
@@ -193,6 +198,9 @@ struct BaBatch {
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1, tb_reserve = 0;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false, in_flight = false;
+    uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
+    bool quad = false;          // small-block score-only batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
+    DevBuf contA, contB, cont_n;   // PairCont lists between the three launches of such a batch, and their counters
     bool handle_mode = false;   // the device state of one Block handle: one pair per launch, CIGARs only on request (k_traceback)
     DevBuf hblk, rblk;          // handle mode: everything uploaded per align / everything read back, one buffer each
     BatchParams params() const {
@@ -215,6 +223,7 @@ struct BaBatch {
         bp.tb_queue = tb_queue.as<uint32_t>(); bp.tb_ctrl = tb_ctrl.as<uint32_t>();
         bp.slot_free = slot_free.as<uint32_t>(); bp.slot_info = slot_info.as<ba::SlotInfo>();
         bp.work_counter = counter.as<uint32_t>();
+        bp.work_chunk = work_chunk;
         bp.prof = prof.as<unsigned long long>();
         return bp;
     }
@@ -473,6 +482,11 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // Short pairs: a walk is a few hundred dependent steps, cheaper done at once by the fill wave's lane 0 than handed to a
     // traceback lane (protein pairs of ~300 residues, block 32..256: 202 vs 99 GCUPS; 1 kbp DNA pairs already prefer the hand-off).
     const bool short_pairs = kind != BA_KIND_PROFILE_ && avg_len2 <= 1024 && !getenv("BA_FORCE_TB");
+    {   // several short pairs per work-counter atomic; long pairs one by one (a chunk of long pairs would lengthen the launch's ragged end)
+        const uint64_t waves = grid * ba::WAVES_PER_WG;
+        const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
+        b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
+    }
     if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !getenv("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
@@ -607,6 +621,14 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(cig_ops, b->cig_total * 4);
 #undef BA_ALLOC
     if (batch_alloc_scratch(b.get())) return nullptr;
+    // Small blocks: a 32-cell block keeps 16 of a wave's 64 lanes busy, so score-only batches that start at 32 cells run
+    // their plain shift steps four pairs to a wave (k_quad) between two passes of the per-pair kernel (see batch_launch).
+    // (Measured: 1 kbp DNA at ~90 % identity 606 -> 1295 GCUPS; protein pairs at 30..100 % identity grow within a few steps and
+    // spend most of their time beyond 32 cells, where the two extra passes cost more than k_quad saves: 585 -> 489. Hence
+    // amino-acid batches stay on the per-pair kernel unless BA_FORCE_QUAD is set.)
+    b->quad = !trace && !profile && !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
+              (getenv("BA_FORCE_QUAD") || (n >= 2048 && kind != BA_KIND_AA));
+    if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->contB.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(2 * n * 4))) return nullptr;
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -670,6 +692,26 @@ static int batch_launch(BaBatch* b) {
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : g_launch[special_of(b->mode)][b->kind][b->pclass];
+    if (b->quad && b->n <= b->cap_n) {
+        // pass 1 (per-pair kernel): every pair up to its first register-path step at 32 cells -> list A;
+        // pass 2 (k_quad): plain shift steps, four pairs per wave, until a pair needs anything else -> list B;
+        // pass 3 (per-pair kernel): the pairs of list B to their end.
+        uint32_t* flagA = b->cont_n.as<uint32_t>(); uint32_t* flagB = flagA + b->cap_n;
+        HIP_TRY(hipMemsetAsync(flagA, 0, 2 * b->cap_n * 4, b->stream));
+        BatchParams p1 = bp; p1.cont_mode = 1; p1.cont_out = b->contA.as<ba::PairCont>(); p1.cont_out_flag = flagA;
+        HIP_TRY(launch(0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
+        const ba::PairCont* last = b->contA.as<ba::PairCont>(); const uint32_t* last_flag = flagA;
+        if (!getenv("BA_QUAD_SKIP")) {   // (development switch: passes 1 and 3 only)
+            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+            BatchParams p2 = bp; p2.cont_in = last; p2.cont_in_flag = last_flag; p2.cont_out = b->contB.as<ba::PairCont>(); p2.cont_out_flag = flagB;
+            p2.work_chunk = 16;
+            HIP_TRY(g_launch_quad[b->kind]((b->mode & BA_X_DROP) != 0, b->stream, &p2));
+            last = b->contB.as<ba::PairCont>(); last_flag = flagB;
+        }
+        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+        BatchParams p3 = bp; p3.cont_mode = 2; p3.cont_in = last; p3.cont_in_flag = last_flag;
+        HIP_TRY(launch(0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p3));
+    } else
     HIP_TRY(launch((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     b->in_flight = true;

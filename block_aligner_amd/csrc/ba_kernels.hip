@@ -54,6 +54,27 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
     return xdrop ? occ1<false, true>(blocks_per_cu, lds) : occ1<false, false>(blocks_per_cu, lds);
 }
 
+#if BA_KIND != 3 && BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
+// four pairs per wave while the block is 32 cells (score-only batches; ba_quad.hpp): one kernel per sequence kind
+#include "ba_quad.hpp"
+template <bool XDROP>
+static hipError_t launch_quad(hipStream_t s, const ba::BatchParams& bp) {
+    const unsigned lds = ba::lds_table_bytes_h(BA_KIND) + ba::WAVES_PER_WG * 4 * ba::QUAD_SLOT_BYTES;
+    int per_cu = 0, dev = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba::k_quad<BA_KIND, XDROP>, ba::WAVES_PER_WG * 64, lds);
+    if (e != hipSuccess) return e;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
+    ba::k_quad<BA_KIND, XDROP><<<dim3(prop.multiProcessorCount * per_cu), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+extern "C" hipError_t BA_CAT(ba_launch_quad_k, BA_KIND, , )(int xdrop, hipStream_t s, const ba::BatchParams* bp) {
+    return xdrop ? launch_quad<true>(s, *bp) : launch_quad<false>(s, *bp);
+}
+#endif
+
 #if BA_KIND == 0 && BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
 // kernels that exist once
 // Traceback from an arbitrary end cell over slot 0's trace (the per-handle API: block_cigar_* after block_align_*).

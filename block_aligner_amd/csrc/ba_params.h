@@ -33,6 +33,17 @@ struct SlotInfo { uint32_t pair, nblocks, end_i, end_j; };
 BA_HD inline uint32_t profile_positions(uint32_t len, uint32_t max_size) { return (len + max_size + 17u) & ~1u; }
 BA_HD inline uint64_t profile_image_bytes(uint32_t len, uint32_t max_size) { return (uint64_t)profile_positions(len, max_size) * (32 + 64 + 6); }
 
+// A pair in flight between kernels (small-block batches, ba_quad.hpp): the driver's state at the top of its loop
+// (scan_block.rs:123-130's locals) with the four 32-cell borders and the checkpoint. 64 + 2 x 256 bytes.
+struct PairCont {
+    uint32_t pair, si, sj; int32_t dir, prev_dir, off, off_max, best_max;
+    uint32_t y_drop_iter; int32_t x_drop_iter, D_corner; uint32_t best_i, best_j, ck_i, ck_j; int32_t ck_off;
+    unsigned long long cells; uint32_t step_budget, pad_[5];
+    uint32_t borders[4][16];   // D_col, C_col, D_row, R_row: lane l holds cells 2l, 2l+1 (packed i16)
+    uint32_t ckpt[4][16];
+};
+static_assert(sizeof(PairCont) == 96 + 512, "PairCont layout");
+
 struct BatchParams {
     // inputs: pool holds PaddedBytes images: [NULL] + converted bytes + NULL x pad (scan_block.rs:1790-1812)
     const uint8_t* pool;
@@ -70,6 +81,12 @@ struct BatchParams {
     uint32_t* tb_ctrl;           // [0] tail (next entry to produce), [32] head (next entry to claim); separate cache lines
     uint32_t* slot_free;         // per slot: 1 = free, 0 = owned by a fill wave or a pending traceback
     SlotInfo* slot_info;         // per slot: what the traceback lane needs
+    // small-block batches (score only, min block 32): pairs move between kernels as PairCont records
+    uint32_t cont_mode;          // 0 plain; 1 suspend every pair at its first register-path step (-> cont_out); 2 resume from cont_in
+    // records are indexed by the pair's position in the batch; flag[p] != 0: pair p has a record (it is still in flight)
+    const PairCont* cont_in; const uint32_t* cont_in_flag;
+    PairCont* cont_out; uint32_t* cont_out_flag;
+    uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;
 };

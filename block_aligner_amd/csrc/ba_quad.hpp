@@ -1,0 +1,264 @@
+// block_aligner_amd — four pairs per wavefront while the block is 32 cells.
+//
+// A 32-cell block fills 16 of a wave's 64 lanes (two cells per lane), so the per-pair kernels (ba_driver.hpp) spend three
+// quarters of every vector instruction on nothing when a batch starts at the reference's usual minimum block size
+// (examples/uc_bench.rs:85-100, examples/pssm_bench.rs:94-100: 32..=256). k_quad runs FOUR pairs per wave, one per 16-lane
+// DPP row ("slot"): row_shr DPP stays inside a row, so the column code of fast_rect carries over lane for lane; what is
+// wave-uniform there (offsets, direction, column bytes, the whole driver state) is row-uniform here and lives in VGPRs,
+// replicated across the slot's 16 lanes, and the driver decisions of scan_block.rs:332-558 are evaluated for all four slots at
+// once with vector compares and selects. A slot only ever executes PLAIN shift steps at 32 cells: whatever else a pair needs
+// (its first block, a grow, termination, the early column break at the matrix edge) is done by the per-pair kernel, before
+// and after: pairs arrive and leave as PairCont records (ba_params.h) holding the driver's state at the top of its loop.
+// A step whose outcome calls for anything but another shift is rolled back and the pair leaves with its pre-step state.
+// Score-only batches (no trace), sequence-sequence kinds.
+#pragma once
+#include "ba_driver.hpp"
+
+namespace ba {
+
+constexpr int QUAD_B = 32;             // block size of a slot
+constexpr int QUAD_SLOT_BYTES = 512;   // LDS per slot: D scratch at 0, R scratch at +128, the two sinks at +256 / +384
+constexpr int QUAD_PR = 64;            // D -> R scratch, in entries
+
+// lane SRC (0..15) of every 16-lane slot to all lanes of the slot: ds_swizzle, bit-mask mode (and 0x10, or SRC)
+template <int SRC>
+__device__ __forceinline__ int slot_bcast(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x10 | (SRC << 5)); }
+__device__ __forceinline__ int row_shr1_z(int src) { return __builtin_amdgcn_update_dpp(0, src, 0x111, 0xf, 0xf, true); }   // lane l <- l-1 inside the row; row lane 0 <- 0
+__device__ __forceinline__ int add_row_shr1(int a, int b) {   // a[l-1] + b[l] inside a row (row lane 0: 0 + b)
+    int t;
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ int sat16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
+
+struct QuadOut { int mx, row, col, act_max8, pas_max8, corner_new; };
+
+// One 8-column shift step for the four slots of a wave (fast_rect with row-uniform operands in VGPRs).
+template <int KIND, bool XDROP>
+__device__ __forceinline__ void quad_rect(const char* table, const FillConsts& fc, int l, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
+                                          int vec_a, int vec_b, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, int loc_thr, QuadOut& o) {
+    const int offa = splat(off_add);
+    int d = adds(Ad, offa), c = adds(Ac, offa);
+    const int pd = adds(Pd, offa), pr = adds(Pr, offa);
+    lds_fence();
+    *(int*)(Pl + 2 * l) = pd; *(int*)(Pl + QUAD_PR + 2 * l) = pr;
+    o.corner_new = slot_bcast<3>(pd) >> 16;
+    const ScoreKey<KIND> key = make_key<KIND>(vec_a, vec_b);
+    int dmax = 0;
+    int dcol[STEP];
+    short* last_base = l == 15 ? Pl + QUAD_B : sink;
+#pragma unroll
+    for (int j = 0; j < STEP; j++) {
+        const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
+        const int sc = fetch_score<KIND>(table, key, cb);
+        int prev = row_shr1_z(d);
+        if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
+        const int d00 = __builtin_amdgcn_alignbit(d, prev, 16);
+        int d11 = adds(d00, sc);
+        const int copen = adds(d, fc.go2);
+        const int cn = vmax(adds(c, fc.ge2), copen);
+        d11 = vmax(d11, cn);
+        const int x = adds(d11, fc.ome2);
+        const s16x2 t2 = as_s(adds(x, fc.ge2));
+        int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
+        const int pm = wave_prefix_max16((int)as_s(r).y - fc.laneKG);
+        const s16x2 cs = as_s(add_row_shr1(pm, fc.lanem1KG));
+        r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst_top);
+        const int dn = vmax(d11, r);
+        dmax = vmax(dmax, dn);
+        dcol[j] = dn;
+        d = dn; c = cn;
+        last_base[j] = (short)(d >> 16); last_base[QUAD_PR + j] = (short)(r >> 16);
+    }
+    lds_fence();
+    Pd = *(const int*)(Pl + 2 * l + STEP); Pr = *(const int*)(Pl + QUAD_PR + 2 * l + STEP);
+    Ad = d; Ac = c;
+    {   // max of the first 8 entries of both borders (lanes 0..3 of the slot), to every lane of the slot
+        const s16x2 sa = as_s(d), sb = as_s(Pd);
+        const int xa = vmax(d, as_i(s16x2{sa.y, sa.x})), xb = vmax(Pd, as_i(s16x2{sb.y, sb.x}));
+        int m = __builtin_amdgcn_perm(xb, xa, 0x05040100);
+        m = vmax(m, __builtin_amdgcn_update_dpp(m, m, 0xB1, 0xf, 0xf, false));
+        m = vmax(m, __builtin_amdgcn_update_dpp(m, m, 0x4E, 0xf, 0xf, false));
+        const s16x2 rr = as_s(slot_bcast<0>(m));
+        o.act_max8 = rr.x; o.pas_max8 = rr.y;
+    }
+    const int m32 = max(dmax & 0xffff, (int)((uint32_t)dmax >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
+    const int M = slot_bcast<15>(wave_prefix_max16(m32));
+    o.mx = M; o.row = 0; o.col = 0;
+    if (XDROP && __any(M > loc_thr)) {   // (some slot raises its best score: the location matters)
+        // location of the maximum inside each slot: among the cells equal to it, smallest row % 16, then largest column, then
+        // largest row (avx2.rs:271-274 + scan_block.rs:1198-1200). jl1 = 1 + the last column in which this lane's cell holds M.
+        const int Ms = splat(M);
+        int jl1 = 0;
+#pragma unroll
+        for (int j = 0; j < STEP; j++) jl1 = vmaxu(jl1, pk_mul(eq01(dcol[j], Ms, fc.ones), splat(j + 1)));
+        int best = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int jl = h ? (jl1 >> 16) & 0xffff : jl1 & 0xffff;
+            const int row = 2 * l + h;
+            const int k = ((15 - (row & 15)) << 11) | (jl << 7) | row;
+            best = max(best, jl ? k : 0);
+        }
+        best = slot_bcast<15>(wave_prefix_max16(best));
+        const int jl = (best >> 7) & 15;
+        o.col = jl ? jl - 1 : 0;
+        o.row = jl ? best & 127 : 0;   // no cell equals the maximum (it is the initial MIN): lane 0 / column 0 / vector 0
+    }
+}
+
+template <int KIND, bool XDROP>
+__global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), l = lane & 15, g = lane >> 4;
+    const int wave = (int)threadIdx.x >> 6;
+    {   // workgroup-shared scoring table, as in k_align
+        char* tab = smem;
+        if (KIND == KIND_NUC) {
+            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
+                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
+                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
+            }
+        } else {
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
+        }
+    }
+    __syncthreads();
+    char* sl = smem + lds_table_bytes_h(KIND) + (uint32_t)(wave * 4 + g) * QUAD_SLOT_BYTES;
+    short* Pl = (short*)sl;
+    short* sink = (short*)(sl + 256) + l;
+    FillConsts fc;
+    {
+        const int gx = bp.gap_extend;
+        fc.gap_extend = gx;
+        fc.go2 = splat(bp.gap_open); fc.ge2 = splat(gx); fc.ome2 = splat(clamp16(bp.gap_open - gx));
+        fc.g12 = pk(gx, 2 * gx);
+        fc.ones = 0x00010001;
+        fc.laneKG = l * 2 * gx; fc.lanem1KG = l ? (l - 1) * 2 * gx : -32768;
+        int v[2];
+        for (int h = 0; h < 2; h++) {
+            const int k = (2 * l + h) & 15;
+            const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
+            v[h] = mult ? max(-32768, mult * gx) : -32768;
+        }
+        fc.vconst = pk(v[0], v[1]);
+        fc.vconst_top = pk(max(v[0], max(-32768, (2 * l + 1) * gx)), max(v[1], max(-32768, (2 * l + 2) * gx)));
+    }
+    const uint32_t total = bp.n;
+    const uint32_t max_size = bp.max_size;
+    const int x_drop = bp.x_drop;
+
+    // ---- slot state (row-uniform, replicated over the slot's lanes)
+    uint32_t pair = ~0u, si = 0, sj = 0, qlen = 0, rlen = 0, y_drop = 0, best_i = 0, best_j = 0, ck_i = 0, ck_j = 0, budget = 0, nsteps = 0;
+    int dir = DIR_RIGHT, prev_dir = DIR_GROW, off = 0, off_max = 0, best_max = 0, x_iter = 0, D_corner = 0, ck_off = 0;
+    unsigned long long cells0 = 0;
+    const uint8_t* qp = bp.pool; const uint8_t* rp = bp.pool;
+    int Dcol = 0, Ccol = 0, Drow = 0, Rrow = 0, ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0;
+    uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter (wave-uniform)
+    bool more = true;
+
+    for (;;) {
+        // ---- idle slots take the next records (positions without a record -- pairs already finished -- are skipped)
+        bool idle = pair == ~0u;
+        while (more && __any(idle)) {
+            if (w_next == w_end) {
+                uint32_t v = 0;
+                if (lane == 0) v = atomicAdd(bp.work_counter, bp.work_chunk);
+                w_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                if (w_next >= total) { more = false; break; }
+                w_end = min(w_next + bp.work_chunk, total);
+            }
+            // the idle slots, in slot order, take consecutive positions
+            const unsigned long long im = __ballot(idle && l == 0);
+            const uint32_t rank = (uint32_t)__popcll(im & ((1ull << (g * 16)) - 1ull));
+            const uint32_t idx = w_next + rank;
+            const uint32_t take = min((uint32_t)__popcll(im), w_end - w_next);
+            w_next += take;
+            const bool got = idle && rank < take && bp.cont_in_flag[idx] != 0;
+            if (got) {
+                const PairCont* c = bp.cont_in + idx;
+                pair = c->pair; si = c->si; sj = c->sj; dir = c->dir; prev_dir = c->prev_dir; off = c->off; off_max = c->off_max; best_max = c->best_max;
+                y_drop = c->y_drop_iter; x_iter = c->x_drop_iter; D_corner = c->D_corner; best_i = c->best_i; best_j = c->best_j;
+                ck_i = c->ck_i; ck_j = c->ck_j; ck_off = c->ck_off; cells0 = c->cells; budget = c->step_budget; nsteps = 0;
+                Dcol = (int)c->borders[0][l]; Ccol = (int)c->borders[1][l]; Drow = (int)c->borders[2][l]; Rrow = (int)c->borders[3][l];
+                ck0 = (int)c->ckpt[0][l]; ck1 = (int)c->ckpt[1][l]; ck2 = (int)c->ckpt[2][l]; ck3 = (int)c->ckpt[3][l];
+                qp = bp.pool + bp.q_off[pair]; rp = bp.pool + bp.r_off[pair];
+                qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
+            }
+            idle = pair == ~0u;
+        }
+        if (__all(idle)) break;
+
+        // ---- the step every live slot is about to take
+        const bool right = dir == DIR_RIGHT;
+        const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (QUAD_B - STEP);
+        const uint32_t lenV = right ? qlen : rlen;
+        // a step that could break early at the matrix edge (never with X-drop) is not ours: leave before it
+        const bool elig = XDROP || ri + QUAD_B <= lenV;
+        bool leave = !idle && (!elig || budget <= 1);
+        const bool run = !idle && !leave;
+        const int off_n = off_max;
+        const int off_add = sat16(off - off_n);
+        const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
+        const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
+        int vc = 0; uint32_t cb_lo = 0, cb_hi = 0;
+        if (run) {
+            vc = *(const unsigned short*)(Vp + ri + 2 * l);
+            const uint2 cb = *(const uint2*)(Cp + rj);       // the step's 8 column bytes (images are 4-byte aligned, positions multiples of 8)
+            cb_lo = cb.x; cb_hi = cb.y;
+        }
+        int Ad = right ? Dcol : Drow, Ac = right ? Ccol : Rrow, Pd = right ? Drow : Dcol, Pr = right ? Rrow : Ccol;
+        QuadOut o;
+        const int loc_thr = best_max - off_n + ZERO;
+        quad_rect<KIND, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add, run ? loc_thr : 0x7fffffff, o);
+
+        // ---- what does the step call for? (scan_block.rs:332-558; nothing is committed yet)
+        const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
+        const int new_off_max = off_n + o.mx - ZERO;
+        const bool improve = new_off_max > best_max;
+        const uint32_t new_y = improve ? 0u : y_drop + 1;
+        const bool q_out = si + QUAD_B > qlen, r_out = sj + QUAD_B > rlen;
+        bool stop = q_out && r_out;                                                                   // end of the matrix
+        if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
+        stop = stop || (!q_out && !r_out && 2 * QUAD_B <= max_size && new_y > QUAD_B / STEP - 1);    // grow
+        const bool commit = run && !stop;
+        leave = leave || (run && stop);
+
+        // ---- slots that leave: their state as it was at the top of this step
+        if (__any(leave)) {
+            if (leave) {
+                PairCont* c = bp.cont_out + pair;
+                if (l == 0) {
+                    bp.cont_out_flag[pair] = 1u;
+                    c->pair = pair; c->si = si; c->sj = sj; c->dir = dir; c->prev_dir = prev_dir; c->off = off; c->off_max = off_max; c->best_max = best_max;
+                    c->y_drop_iter = y_drop; c->x_drop_iter = x_iter; c->D_corner = D_corner; c->best_i = best_i; c->best_j = best_j;
+                    c->ck_i = ck_i; c->ck_j = ck_j; c->ck_off = ck_off; c->cells = cells0 + (unsigned long long)nsteps * (STEP * QUAD_B); c->step_budget = budget;
+                }
+                c->borders[0][l] = (uint32_t)Dcol; c->borders[1][l] = (uint32_t)Ccol; c->borders[2][l] = (uint32_t)Drow; c->borders[3][l] = (uint32_t)Rrow;
+                c->ckpt[0][l] = (uint32_t)ck0; c->ckpt[1][l] = (uint32_t)ck1; c->ckpt[2][l] = (uint32_t)ck2; c->ckpt[3][l] = (uint32_t)ck3;
+                pair = ~0u;
+            }
+        }
+        // ---- slots that go on: commit the step
+        if (commit) {
+            Dcol = right ? Ad : Pd; Ccol = right ? Ac : Pr; Drow = right ? Pd : Ad; Rrow = right ? Pr : Ac;
+            off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = dir; D_corner = o.corner_new;
+            nsteps++; budget--;
+            if (improve) {
+                if (XDROP) {   // scan_block.rs:370-404
+                    best_i = right ? si + (uint32_t)o.row : si + (QUAD_B - STEP) + (uint32_t)o.col;
+                    best_j = right ? sj + (QUAD_B - STEP) + (uint32_t)o.col : sj + (uint32_t)o.row;
+                }
+                if (QUAD_B < max_size) { ck_i = si; ck_j = sj; ck_off = off; ck0 = Dcol; ck1 = Ccol; ck2 = Drow; ck3 = Rrow; }
+                best_max = off_max;
+            }
+            if (XDROP) x_iter = (off_max < best_max - x_drop) ? x_iter + 1 : 0;
+            const bool go_down = r_out || (!q_out && down_max > right_max);
+            si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
+            dir = go_down ? DIR_DOWN : DIR_RIGHT;
+        }
+    }
+}
+
+}  // namespace ba

@@ -611,3 +611,27 @@ def test_percent_len_sizes_are_accepted(hip, oracle):
         compare(hip, oracle, pairs, NUC, (-5, -1), (32, mx), 60, ("trace", "x_drop"))
     prot = synth.make_pairs(3, (2000, 5000), (200, 900), 0, synth.AMINO, seed=6, indels=2, indel_len=(300, 1500))
     compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 4096), 0, ("trace",), cigar_eq=False)
+
+
+@pytest.mark.parametrize("skip_quad", ["1", ""])
+@pytest.mark.parametrize("mode", [("x_drop",), ()])
+def test_small_block_pipeline(hip, oracle, monkeypatch, mode, skip_quad):
+    """Score-only batches that start at 32 cells run in three passes: the per-pair kernel up to each pair's first plain shift
+    step, k_quad (four pairs per wave, one per 16-lane DPP row) through the plain shift steps, the per-pair kernel again for
+    whatever else a pair needs (grow, termination, matrix edge); pairs travel between the passes as PairCont records. Forced on
+    small batches here; BA_QUAD_SKIP = 1 runs passes 1 and 3 alone (the record plumbing without k_quad). DNA, protein and byte
+    pairs, with growth (indels), tiny and empty sequences."""
+    monkeypatch.setenv("BA_FORCE_QUAD", "1")
+    if skip_quad:
+        monkeypatch.setenv("BA_QUAD_SKIP", "1")
+    dna = synth.make_pairs(700, (0, 1500), (0, 150), 40, synth.DNA, seed=61, indels=1, indel_len=(10, 120))
+    for size in [(32, 32), (32, 64), (32, 256), (32, 2048)]:
+        compare(hip, oracle, dna, NUC, (-5, -1), size, 60, mode)
+    prot = synth.make_pairs(500, (22, 900), (0, 250), 0, synth.AMINO, seed=62)
+    compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 256), 40, mode)
+    if not mode:
+        byt = synth.make_pairs(200, (0, 400), (0, 50), 5, np.frombuffer(b"abcdefghij\x01\xff", np.uint8), seed=63)
+        compare(hip, oracle, byt, S.BYTES1, (-2, -1), (32, 128), 0, ())
+    edge = synth.PairSet.from_lists([(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A" * 40, b"A" * 40), (b"ACGT" * 30, b"ACGT" * 30 + b"TTTT" * 20),
+                                     (b"A" * 33, b"T" * 300), (b"ACGTNNNNACGT" * 5, b"ACGTACGT" * 6)] * 8)
+    compare(hip, oracle, edge, S.NW1, (-2, -1), (32, 128), 20, mode)
