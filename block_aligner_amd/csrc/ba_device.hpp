@@ -152,6 +152,12 @@ __device__ __forceinline__ int sign_bits(int x) {
     asm("v_and_b32_e32 %0, 0x80008000, %1" : "=v"(t) : "v"(x));
     return t;
 }
+// (a & mask) | (b & ~mask) as ONE instruction (left to itself the compiler re-expands the pattern into and / or forms)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t t;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "s"(mask), "v"(a), "v"(b));
+    return t;
+}
 __device__ __forceinline__ int pk_mul(int a, int m) {
     int t;
     asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(a), "s"(m));
@@ -180,28 +186,6 @@ struct WaveLds {
     const char* table;    // per workgroup: NUC packed-pair score table (8 KB) / AA 27x32 bytes / BYTES {match, mismatch}
 };
 struct Best { int mx; int row; int col; };
-
-// Extra inputs / outputs of the shift-step fast path (block <= 128 cells: one chunk, everything in registers).
-struct FastIO {
-    int vec_a, vec_b;         // in: this lane's two vector-axis bytes (already waited for by the caller)
-    int col_chars;            // in: lanes 0..7 hold the 8 column bytes of the step
-    short* Pd; short* Pr;     // in: the orthogonal ("passive") border pair in LDS: shifted by 8 and re-based here
-    short* sink;              // in: >= 256 bytes of this wave's LDS nothing reads (or null): lets every lane store the column's last cell unpredicated
-    int act_max8, pas_max8;   // out: max of the first 8 entries of the active / passive D border (scan_block.rs:1020-1022)
-    int corner_new;           // out: D_corner for a following orthogonal step (scan_block.rs:1042)
-    int rAd, rAc, rPd, rPr;   // out: register images of the four borders after the step (checkpoint source)
-};
-// max over lanes 0..3 of max(lo, hi) of a packed register (quad-permute DPP reduce), wave-uniform result
-__device__ __forceinline__ int first8_max(int v) {
-    int m = max((int)as_s(v).x, (int)as_s(v).y);
-    // quad_perm:[1,0,3,2] then [2,3,0,1], fused into the max (same hazard padding as wave_prefix_max)
-    asm volatile(
-        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(m));
-    return __builtin_amdgcn_readlane(m, 0);
-}   // rect max (i16 value) and, for X-drop, its resolved location
 
 // max of the first 8 entries of two packed border registers at once (scan_block.rs:1020-1022 for both borders): the two
 // per-lane maxima share one register (a: low half, b: high half) for the reduction over lanes 0..3
@@ -322,11 +306,13 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
         if (TRACE) {
             // the four flags of a cell (D != C, D != R, C != C_open, R != D_open): each is "left side greater", i.e. the sign of
             // a saturating difference; the sign bits of both halves go into the step's trace word with 32-bit logic ops
-            // (2-cycle VOP2 forms on gfx950, profiles/r02_valu_rate.md): nibble = nC | nR << 1 | nCo << 2 | nRo << 3
-            const int fC = sign_bits(subs(cn, dn)), fR = sign_bits(subs(r, dn));
-            const int fCo = sign_bits(subs(copen, cn)), fRo = sign_bits(subs(x, r));
-            const uint32_t nib = (uint32_t)fRo | ((uint32_t)fCo >> 1) | ((uint32_t)fR >> 2) | ((uint32_t)fC >> 3);   // bits 15..12 / 31..28
-            tacc = (int)(((uint32_t)tacc >> 4) | nib);                                                               // column j ends up in bits 4j .. 4j+3
+            // (nibble = nC | nR << 1 | nCo << 2 | nRo << 3; same-box A/B: +1.0 % over masking every difference and or-ing them)
+            // (bit-field inserts take the sign bits and leave the rest of the differences behind as garbage below the nibble,
+            // which one mask removes when the nibble joins the word: 8 instructions per column besides the four differences)
+            const uint32_t sC = (uint32_t)subs(cn, dn), sR = (uint32_t)subs(r, dn), sCo = (uint32_t)subs(copen, cn), sRo = (uint32_t)subs(x, r);
+            const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);   // bits 15, 14 of each half
+            const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);                                        // bits 15..12: nRo, nCo, nR, nC
+            tacc = (int)(((uint32_t)tacc >> 4) | (nib & 0xF000F000u));                                   // column j ends up in bits 4j .. 4j+3
             if ((j & 3) == 3) {   // (unpredicated: lanes beyond a small block write words that a later store covers, or the slot's slack)
                 trace_out[(uint32_t)((j >> 2) * nl + lane)] = (uint32_t)tacc;
                 tacc = 0;
@@ -400,24 +386,20 @@ __device__ __forceinline__ int load_uniform_i16(const short* p) {
     return uni((int)*(const short*)a);
 }
 
-template <int NCH, int KIND, bool TRACE, bool XDROP, bool FAST = false, int PDIR = 0, bool FULL128 = false>
+template <int NCH, int KIND, bool TRACE, bool XDROP, int PDIR = 0>
 __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
                                            short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out,
-                                           unsigned long long& cells, FastIO* fs = nullptr, unsigned long long* tacc_prof = nullptr,
+                                           unsigned long long& cells, unsigned long long* tacc_prof = nullptr,
                                            uint32_t sp = 0, FqeOut* fq = nullptr, const ProfileView* pv = nullptr, const TileCtx* tc = nullptr) {
     BA_TSTAMP(tp0);
-    static_assert(!FAST || NCH == 1, "the fast path handles single-chunk steps");
-    static_assert((KIND == KIND_PROFILE) == (PDIR != 0) && !(FAST && PDIR), "profile rectangles take the generic path with a direction");
+    static_assert((KIND == KIND_PROFILE) == (PDIR != 0), "profile rectangles come with a direction");
     const int lane = lane_id();
-    // FULL128 (fast path only): the step is exactly 128 cells high, so all 64 lanes hold cells and the lane count, the
-    // activity tests and the trace indices are compile-time
-    static_assert(!FULL128 || (FAST && NCH == 1), "FULL128 is a variant of the fast path");
-    const int nl = (NCH > 1 || FULL128) ? 64 : (int)(height >> 1);   // active lanes
-    const bool active = FULL128 ? true : lane < nl;
+    const int nl = NCH > 1 ? 64 : (int)(height >> 1);   // active lanes
+    const bool active = lane < nl;
     Best res{0, 0, 0};                                   // MIN = 0 (avx2.rs:16)
-    if (!FAST && (width == 0 || height == 0)) return res;   // (a shift step is 8 x block)
+    if (width == 0 || height == 0) return res;
 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -425,13 +407,11 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     ScoreKey<KIND> key[NCH];
     int fqM = 0, fqJ = 0;            // SP_FQE: running max / last column of the tracked vector lane
     const int offa = splat(off_add);
-    int pasD = 0, pasR = 0;          // FAST: passive border entries [2l+8, 2l+9], re-based
-    const bool pas_in = FAST && lane + 4 < nl;   // this lane's shifted passive pair comes from the old border (else: the 8 new cells)
     int ca[NCH], cb_[NCH];           // the chunk's two vector-axis bytes: all loads issued before any is used
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
         ca[ch] = 0; cb_[ch] = 0;
-        if (!FAST && PDIR != 2 && active) { ca[ch] = seqV[start_i + ch * 128 + 2 * lane]; cb_[ch] = seqV[start_i + ch * 128 + 2 * lane + 1]; }
+        if (PDIR != 2 && active) { ca[ch] = seqV[start_i + ch * 128 + 2 * lane]; cb_[ch] = seqV[start_i + ch * 128 + 2 * lane + 1]; }
     }
     // profile, vectors along the profile: per-position gap costs of this lane's two cells, swapped as the reference
     // swaps them for its "down" orientation (scan_block.rs:671-682)
@@ -466,17 +446,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     for (int ch = 0; ch < NCH; ch++) {
         const int r0 = ch * 128 + 2 * lane;
         int dv = 0, cv = 0, a = ca[ch], b = cb_[ch];
-        // (fast path: unpredicated reads -- every lane's address is inside the border arrays and their padding, and what
-        // the inactive lanes of a block below 128 cells compute never reaches an active lane, a store or a reduction)
-        if (FAST || active) { dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0); }
-        if (FAST) {
-            // every LDS read of the step is issued here, in one batch
-            pasD = *(const int*)(fs->Pd + r0 + STEP); pasR = *(const int*)(fs->Pr + r0 + STEP);
-            const int c7 = (int)fs->Pd[STEP - 1];
-            fs->corner_new = uni((int)as_s(adds(splat(c7), offa)).x);
-            pasD = adds(pasD, offa); pasR = adds(pasR, offa);
-            a = fs->vec_a; b = fs->vec_b;
-        }
+        if (active) { dv = *(const int*)(Dc + r0); cv = *(const int*)(Cc + r0); }
         d[ch] = adds(dv, offa);                 // just_offset folded into the load (scan_block.rs:1003-1012)
         c[ch] = adds(cv, offa);
         dmax[ch] = 0; jlast[ch] = 0; tacc[ch] = 0;
@@ -490,7 +460,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     const int rz2 = splat(rel_zero);
     const uint32_t zwords = (width >> 2) * (uint32_t)(NCH * nl);   // SP_LOCAL: the zero mask follows the rectangle's trace words
     int corner_cur = corner;
-    int cvec = FAST ? fs->col_chars : (PDIR == 1 ? 0 : (int)seqC[start_j + (lane & 7)]);   // 8 column bytes at a time, one per lane (lanes 0..7)
+    int cvec = PDIR == 1 ? 0 : (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
     // Profiles, blocks up to 256 cells: the scores (and per-position gap costs) of a whole group of 8 columns are fetched
     // from the pair's image at once -- one round of HBM latency per 8 columns instead of one per column. Vectors along
     // the query: the transposed table aa_pos holds the 8 positions of a residue contiguously (two 16-byte loads per lane
@@ -531,7 +501,6 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     }
     BA_TSTAMP(tp1);
     const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
-    short* last_base = (FAST && fs->sink) ? (last_lane ? Dr : fs->sink + lane) : nullptr;
     // kc: an integral_constant; >= 0 in the grouped profile mode = the column's index inside its group of 8
     auto column = [&](const uint32_t j, auto kc) -> bool {   // returns false when the fill stops early (scan_block.rs:1216-1224)
         constexpr int K = decltype(kc)::value;
@@ -555,9 +524,9 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         for (int ch = 0; ch < NCH; ch++) sc[ch] = sc_next[ch];
         }
         // scores of the next column are fetched while this one is computed
-        if (K < 0 && !FAST && PDIR != 1 && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
+        if (K < 0 && PDIR != 1 && ((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
         if constexpr (K < 0 && PDIR == 1) { col_goC = nxt_goC; col_clC = nxt_clC; col_goR = nxt_goR; }
-        if (K < 0 && !(FAST && j == 7)) {   // (last column of a shift step: nothing left to fetch)
+        if (K < 0) {
             const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) sc_next[ch] = PDIR ? profile_score(start_j + j + 1, cbn, ch) : fetch_score<KIND>(L.table, key[ch], cbn);
@@ -565,8 +534,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         }
         // cell (0,0) -- or, with free query start gaps, every cell of row 0 -- starts from the relative zero
         // (scan_block.rs:1130-1136)
-        // (never in a fast step: a shift step's rectangle starts block - 8 > 0 cells along the step's direction)
-        const bool first_cell = !FAST && ((j == 0 && start_i == 0 && start_j == 0 && !(sp & SP_LOCAL)) || ((sp & SP_FQS_ROW0) && start_i == 0));
+        const bool first_cell = ((j == 0 && start_i == 0 && start_j == 0 && !(sp & SP_LOCAL)) || ((sp & SP_FQS_ROW0) && start_i == 0));
         int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
         corner_cur = 0;
         int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
@@ -580,8 +548,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         for (int ch = 0; ch < NCH; ch++) {
             // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
             int prev = wave_shr1_z(d[ch]);
-            // (fast step: only column 0 has a cell above the chunk, and writing its 0 when there is none is what the shift left there)
-            if (FAST ? j == 0 : up_d != 0) prev = set_lane0(prev, up_d);
+            if (up_d != 0) prev = set_lane0(prev, up_d);
             if (NCH > 1) up_d = __builtin_amdgcn_readlane(d[ch], 63);
             const int d00 = __builtin_amdgcn_alignbit(d[ch], prev, 16);
             int d11 = adds(d00, sc[ch]);
@@ -589,7 +556,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 const int v0 = __builtin_amdgcn_readlane(d11, 0);
                 d11 = set_lane0(d11, (v0 & (int)0xffff0000) | (rel_zero & 0xffff));
             }
-            if (!FAST && (sp & SP_LOCAL)) d11 = vmax(d11, rz2);   // a local alignment may start anywhere (scan_block.rs:1134-1136)
+            if (sp & SP_LOCAL) d11 = vmax(d11, rz2);   // a local alignment may start anywhere (scan_block.rs:1134-1136)
             const int copen = adds(d[ch], PDIR == 0 ? fc.go2 : (PDIR == 1 ? col_goC : goCv[ch]));
             const int cn = vmax(adds(c[ch], fc.ge2), copen);
             const int cend = PDIR == 1 ? adds(cn, col_clC) : cn;                       // C11_end (scan_block.rs:697-701)
@@ -618,10 +585,10 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 nib = pk_mad_k<4>(nCo, nib);
                 nib = pk_mad_k<8>(nRo, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
-                if (!FAST && (sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
+                if ((sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
                     trace_out[zwords + (j * NCH + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);
             }
-            if (!FAST && (sp & SP_FQE)) {
+            if (sp & SP_FQE) {
                 // D_max / argmax_j of vector lane k = len % 16 in the reference's visiting order (columns outer, vectors
                 // inner; scan_block.rs:1189-1201): a running max over that lane's cells of this column, seeded with the
                 // max of all earlier columns; a tracked vector records the column when it ties or raises it
@@ -642,9 +609,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             if (ch == NCH - 1) r_last = r;
         }
         if (TRACE && (j & 3) == 3) {
-            // (fast path: unpredicated -- what the lanes beyond a block of fewer than 128 cells write lands in trace words
-            // that are stored later: the next column group, the next rectangle, or the slack behind the slot)
-            if (FAST || active) {
+            if (active) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCHT + CHB + ch) * nl + lane] = (uint32_t)tacc[ch];
             }
@@ -652,9 +617,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
             for (int ch = 0; ch < NCH; ch++) tacc[ch] = 0;
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-        if (FAST && fs->sink) {   // every lane stores; only the last lane's address is the real one (temp2 = temp1 + 16 entries)
-            last_base[j] = (short)(d[NCH - 1] >> 16); last_base[16 + j] = (short)(r_last >> 16);
-        } else if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
+        if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
         cells += height;
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {
@@ -666,12 +629,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         return true;
     };
     using NoGroup = std::integral_constant<int, -1>;
-    if constexpr (FAST) {
-        // a shift step is exactly 8 columns: fully unrolled, so column indices, trace shifts and border offsets are
-        // immediates and only column 0 carries the corner / first-cell handling
-#pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)STEP; j++) { if (!column(j, NoGroup{})) break; }
-    } else if constexpr (PGROUP) {
+    if constexpr (PGROUP) {
         bool go = true;
         for (uint32_t j0 = 0; go && j0 < width; j0 += STEP) {   // (rectangle widths are multiples of 8)
             refill_group(j0);
@@ -683,7 +641,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         for (uint32_t j = 0; j < width; j++) { if (!column(j, NoGroup{})) break; }
     }
     BA_TSTAMP(tp2);
-    if (!FAST && fq) { fq->M = fqM; fq->j = fqJ; }
+    if (fq) { fq->M = fqM; fq->j = fqJ; }
     // ---- write the vector-axis border back
     if (active) {
 #pragma unroll
@@ -691,42 +649,8 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (FAST) {
-        // shift_and_offset (scan_block.rs:1040-1061) on registers: the last 4 lanes take the 8 cells this step appended
-        if (active && !pas_in) { pasD = *(const int*)(Dr + 2 * (lane + 4 - nl)); pasR = *(const int*)(Rr + 2 * (lane + 4 - nl)); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (active) { *(int*)(fs->Pd + 2 * lane) = pasD; *(int*)(fs->Pr + 2 * lane) = pasR; }
-        fs->act_max8 = first8_max(d[0]);
-        fs->pas_max8 = first8_max(pasD);
-        fs->rAd = d[0]; fs->rAc = c[0]; fs->rPd = pasD; fs->rPr = pasR;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
     // ---- rectangle max and (X-drop) its location: among cells equal to the max, smallest (row % 16), then
     // largest column, then largest row (avx2.rs:271-274 + scan_block.rs:1198-1200 last-writer-wins per lane)
-    if (FAST && XDROP) {
-        // one reduction for both: value (16 bits, >= 0 because D_max starts at MIN = 0) | 15 - row%16 | last column + 1 | row
-        int best = 0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int v = h ? (int)as_s(dmax[0]).y : (int)as_s(dmax[0]).x;
-            const int jl1 = h ? (jlast[0] >> 16) & 0xffff : jlast[0] & 0xffff;
-            const int row = 2 * lane + h;
-            best = max(best, (v << 15) | ((15 - (row & 15)) << 11) | (jl1 << 7) | row);
-        }
-        if (!active) best = 0;
-        best = wave_max(best);
-        res.mx = best >> 15;
-        const int jl1 = (best >> 7) & 15;
-        res.col = jl1 ? jl1 - 1 : 0;
-        res.row = best & 127;
-        // no cell equalled the max (it is the initial MIN): the reference reports lane 0 / column 0 / vector 0
-        if (res.mx == 0 && jl1 == 0) res.row = 0;
-        BA_TSTAMP(tp3f);
-        BA_TADD(tacc_prof, 0, tp0, tp1); BA_TADD(tacc_prof, 1, tp1, tp2); BA_TADD(tacc_prof, 2, tp2, tp3f);
-        return res;
-    }
     int lm = -32768;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) lm = max(lm, max((int)as_s(dmax[ch]).x, (int)as_s(dmax[ch]).y));
@@ -752,9 +676,9 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         res.row = 4095 - (kmin & 4095);
     }
     BA_TSTAMP(tp3);
-    BA_TADD(tacc_prof, FAST ? 0 : (NCH == 1 ? 4 : 8), tp0, tp1);
-    BA_TADD(tacc_prof, FAST ? 1 : (NCH == 1 ? 5 : 9), tp1, tp2);
-    BA_TADD(tacc_prof, FAST ? 2 : (NCH == 1 ? 6 : 10), tp2, tp3);
+    BA_TADD(tacc_prof, NCH == 1 ? 4 : 8, tp0, tp1);
+    BA_TADD(tacc_prof, NCH == 1 ? 5 : 9, tp1, tp2);
+    BA_TADD(tacc_prof, NCH == 1 ? 6 : 10, tp2, tp3);
     return res;
 }
 

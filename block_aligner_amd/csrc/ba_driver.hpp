@@ -867,7 +867,7 @@ struct Aligner {
             Best cur{0, 0, 0};
             FastOut fo{}; int run_exit = RUN_EXIT_POST;
             const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
-#define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, nullptr, prof, sp, &fq, &pv)
+#define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, prof, sp, &fq, &pv)
 #define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
             if (kBig && rh > BIG_TILE) {
                 // ---- row tiles of BIG_TILE cells (TileCtx): the tile above hands its last row over through big_top
@@ -887,8 +887,8 @@ struct Aligner {
                     tc.topD = big_top; tc.topR = big_top + big_array_shorts(h_max_size); tc.break_armed = brk;
                     short* oD = tc.last ? Dr : big_top; short* oR = tc.last ? Rr : big_top + big_array_shorts(h_max_size);
                     Best part;
-#define BA_TILE1(PD) part = place_rect<(int)(BIG_TILE / 128), KIND, TRACE, XDROP, false, PD>(L, fc, seqV, seqC, lenV, lenC, ri + t * BIG_TILE, rj, rw, BIG_TILE, \
-                                   Dc + t * BIG_TILE, Cc + t * BIG_TILE, oD, oR, t == 0 ? corner : 0, rz, off_add, tout, cells, nullptr, prof, 0u, nullptr, &pv, &tc)
+#define BA_TILE1(PD) part = place_rect<(int)(BIG_TILE / 128), KIND, TRACE, XDROP, PD>(L, fc, seqV, seqC, lenV, lenC, ri + t * BIG_TILE, rj, rw, BIG_TILE, \
+                                   Dc + t * BIG_TILE, Cc + t * BIG_TILE, oD, oR, t == 0 ? corner : 0, rz, off_add, tout, cells, prof, 0u, nullptr, &pv, &tc)
                     if constexpr (KIND == KIND_PROFILE) { if (right) BA_TILE1(1); else BA_TILE1(2); } else BA_TILE1(0);
 #undef BA_TILE1
                     part.row += (int)(t * BIG_TILE);
