@@ -386,7 +386,9 @@ __device__ __forceinline__ int load_uniform_i16(const short* p) {
     return uni((int)*(const short*)a);
 }
 
-template <int NCH, int KIND, bool TRACE, bool XDROP, int PDIR = 0>
+// LOC: keep the per-row "last column at the running maximum" bookkeeping and resolve the location of the rectangle maximum
+// (X-drop needs it when the step raises the best score; a speculative grow -- ba_driver.hpp -- goes without).
+template <int NCH, int KIND, bool TRACE, bool XDROP, int PDIR = 0, bool LOC = XDROP>
 __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV,
                                            const uint8_t* __restrict__ seqC, uint32_t lenV, uint32_t lenC, uint32_t start_i,
                                            uint32_t start_j, uint32_t width, uint32_t height, short* Dc, short* Cc, short* Dr,
@@ -602,7 +604,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 fqM = max(fqM, __builtin_amdgcn_readlane(pm, 63));
             }
             dmax[ch] = vmax(dmax[ch], dn);
-            if (XDROP) {   // jlast = 1 + last column whose cell ties or raises its row's running max
+            if (LOC) {   // jlast = 1 + last column whose cell ties or raises its row's running max
                 jlast[ch] = vmaxu(jlast[ch], pk_mul(eq01(dmax[ch], dn, fc.ones), jp1));
             }
             d[ch] = dn; c[ch] = cn;
@@ -657,7 +659,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     if (!active) lm = -32768;
     const int M = wave_max(lm);
     res.mx = M;
-    if (XDROP) {
+    if (LOC) {
         int kmin = 0x7fffffff;
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {

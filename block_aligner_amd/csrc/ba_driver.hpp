@@ -123,7 +123,8 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             if (i >= br.i && j >= br.j) break;
         }
         const bool right_blk = br.trace_base >> 31;
-        const uint32_t tbase = br.trace_base & 0x7fffffffu;
+        if (br.trace_base & 0x40000000u) { *status |= ST_TRACEBACK_LOST; return 0; }   // a speculative grow that was never materialised: must not be on a path
+        const uint32_t tbase = br.trace_base & 0x3fffffffu;
         const uint32_t Hv = right_blk ? br.h : br.w;          // cells along the vector axis
         const uint32_t nch = Hv > 128 ? Hv / 128 : 1, nl = Hv > 128 ? 64 : Hv / 2;   // chunks of 128 cells, lanes per chunk
         while (i >= br.i && j >= br.j && (i > 0 || j > 0)) {
@@ -213,11 +214,12 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         t.in_rect = t.i >= t.bi && t.j >= t.bj;
         t.zoff = h * w / 8;
         t.right = rec.w >> 31;
-        t.tbase = rec.w & 0x7fffffffu;
+        t.tbase = rec.w & 0x3fffffffu;
         const uint32_t Hv = t.right ? h : w;
         t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
         t.tw_ok = false;
         if (!t.in_rect) return;
+        if (rec.w & 0x40000000u) { tb_fail(t); return; }   // a speculative grow that was never materialised: must not be on a path
     }
     {
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
@@ -504,6 +506,7 @@ struct Aligner {
     // a fast run parks its border registers here instead of storing to memory.
     int ck_reg[4] = {0, 0, 0, 0};
     bool ck_in_regs = false;
+    bool chain = false;   // TRACE: rectangles of speculative (untraced) grows are on the trace stack, see run()
 
     // A shift step is taken by the register path unless its columns could break early at the end of the matrix
     // (scan_block.rs:1216-1224; never with X-drop): those go through place_rect, which implements the break.
@@ -580,6 +583,7 @@ struct Aligner {
                     leave = leave || max(max((int)a.x, (int)a.y), max((int)b.x, (int)b.y)) >= mx;
                 }
             }
+            if (TRACE && chain && improve) leave = true;   // untraced grow rectangles below: the generic post-processing rolls back
             if (leave) { run_exit = RUN_EXIT_POST; break; }
 
             // ---- a plain step: scan_block.rs:332-450 without the grow / shrink / termination branches
@@ -640,14 +644,14 @@ struct Aligner {
         h_flags = b.flags; h_max_size = b.max_size; h_x_drop = b.x_drop;
     }
 
-    __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right) {
+    __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right, bool untraced = false) {
         if (nblocks >= (uint32_t)coldp()->blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
         // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
         const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 5u : 1u);
         if ((uint64_t)trace_top + words + 64 > coldp()->trace_stride) { status |= ST_TRACE_OVERFLOW; return; }   // (64 words of slack stay free: see the host's trace_stride)
         {   // every lane stores the same 16 bytes to the same address (one transaction): no exec-mask region per step
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
-            br.trace_base = trace_top | (right ? 0x80000000u : 0u);
+            br.trace_base = trace_top | (right ? 0x80000000u : 0u) | (untraced ? 0x40000000u : 0u);   // (untraced: space reserved, flags not computed)
             blocks[nblocks] = br;
         }
         nblocks++;
@@ -667,6 +671,23 @@ struct Aligner {
             *(int*)(ckpt + 2 * ms + k) = *(const int*)(L.D_row + k);
             *(int*)(ckpt + 3 * ms + k) = *(const int*)(L.R_row + k);
         }
+    }
+    // The checkpoint borders to (save = true) or from the second half of this wave's checkpoint arena: the base of a chain of
+    // speculative grows.
+    __device__ __forceinline__ void copy_ckpt(bool save, uint32_t n) {
+        const uint32_t ms = h_max_size;
+        short* second = ckpt + 4 * ms;
+        if (save && ck_in_regs) {
+            const uint32_t k = 2 * lane_id();
+            if (k < n) for (int a = 0; a < 4; a++) *(int*)(second + a * ms + k) = ck_reg[a];
+            return;
+        }
+        for (uint32_t k = 2 * lane_id(); k < n; k += 128)
+            for (int a = 0; a < 4; a++) {
+                if (save) *(int*)(second + a * ms + k) = ckpt_load(ckpt + a * ms + k);
+                else *(int*)(ckpt + a * ms + k) = ckpt_load(second + a * ms + k);
+            }
+        if (!save) ck_in_regs = false;
     }
     __device__ __forceinline__ void restore_ckpt_borders(uint32_t n) {
         if (ck_in_regs) {   // checkpoint of a single-chunk block: registers -> LDS
@@ -808,6 +829,20 @@ struct Aligner {
             ck_in_regs = true;
             lds_sync();
         }
+        // speculative grows (see the grow transition below): the checkpoint the chain started from
+        uint32_t ub_size = 0, ub_tt = 0, ub_nb = 0, ub_budget = 0; int ub_xiter = 0; unsigned long long ub_cells = 0;
+        bool no_spec = false;
+        chain = false;
+        auto rollback = [&]() {   // back to the chain's base checkpoint; the grow it was about to take is taken again, traced
+            block_size = ub_size; x_drop_iter = ub_xiter; cells = ub_cells; step_budget = ub_budget;
+            copy_ckpt(false, block_size);
+            chain = false; no_spec = true;
+            prev_size = block_size; block_size *= 2; dir = DIR_GROW; gphase = 0;
+            si = (uint32_t)unpark<0>(parked); sj = (uint32_t)unpark<1>(parked); off = unpark<2>(parked);
+            restore_ckpt_borders(prev_size);
+            trace_top = ub_tt; nblocks = ub_nb; park<3>(parked, (int)ub_tt); park<4>(parked, (int)ub_nb);
+            y_drop_iter = 0; pf_ok = false;
+        };
         BA_TSTAMP(tr0);
         for (;;) {
             BA_TSTAMP(ts0);
@@ -855,9 +890,10 @@ struct Aligner {
             }
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
+            const bool spec = TRACE && chain && dir == DIR_GROW;   // this grow step runs without trace flags and location bookkeeping
             if (TRACE && !fast) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,257,284)
-                if (right) add_block(ri, rj, rw, rh, true);
-                else add_block(rj, ri, rh, rw, false);
+                if (right) add_block(ri, rj, rw, rh, true, spec);
+                else add_block(rj, ri, rh, rw, false, spec);
                 if (status) break;
             }
             uint32_t* tout = TRACE ? trace + tb : nullptr;
@@ -868,7 +904,9 @@ struct Aligner {
             FastOut fo{}; int run_exit = RUN_EXIT_POST;
             const uint32_t sp = special ? ((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && right) ? SP_FQS_ROW0 : 0u) | (FQE ? SP_FQE : 0u) : 0u;
 #define BA_PLACE1(N, PD) cur = place_rect<N, KIND, TRACE, XDROP, PD>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells, prof, sp, &fq, &pv)
-#define BA_PLACE(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
+#define BA_PLACE_T(N) do { if constexpr (KIND == KIND_PROFILE) { if (right) BA_PLACE1(N, 1); else BA_PLACE1(N, 2); } else BA_PLACE1(N, 0); } while (0)
+#define BA_PLACE_S(N) cur = place_rect<N, KIND, false, XDROP, 0, false>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, rh, Dc, Cc, Dr, Rr, corner, rz, off_add, nullptr, cells, prof, sp, &fq, &pv)
+#define BA_PLACE(N) do { if constexpr (TRACE && KIND != KIND_PROFILE && !SPECIAL && !kBig) { if (spec) BA_PLACE_S(N); else BA_PLACE_T(N); } else BA_PLACE_T(N); } while (0)
             if (kBig && rh > BIG_TILE) {
                 // ---- row tiles of BIG_TILE cells (TileCtx): the tile above hands its last row over through big_top
                 const uint32_t ntiles = rh / BIG_TILE;
@@ -927,6 +965,8 @@ struct Aligner {
             else if (PMAX >= 8 && rh == 1024) BA_PLACE(8);
             else if (PMAX >= 16 && rh == 2048) BA_PLACE(16);
 #undef BA_PLACE
+#undef BA_PLACE_S
+#undef BA_PLACE_T
 #undef BA_PLACE1
             BA_TSTAMP(ts2);
             BA_TADD(prof, 12, ts0, ts1); BA_TADD(prof, 13, ts1, ts2);
@@ -965,6 +1005,8 @@ struct Aligner {
             const int D_max_max = FQE ? fq.M : cur.mx, grow_max = was_grow ? unpark<9>(parked) : 0;   // (0 = MIN: no grow rectangle)
             const int mx = max(D_max_max, grow_max);
             off_max = off + mx - ZERO;
+            if (TRACE && chain && off_max > best_max) { rollback(); continue; }   // the path to a new best may cross the untraced rectangles
+            if (TRACE && no_spec && off_max > best_max) no_spec = false;         // the re-run has reached the step that called for it
             y_drop_iter++;
             bool grow_no_max = this_dir == DIR_GROW;
 
@@ -1002,12 +1044,27 @@ struct Aligner {
             BA_TSTAMP(ts3);
             BA_TADD(prof, 14, ts2, ts3);
             BA_TADD(prof, 35, ts2, tpa); BA_TADD(prof, 36, tpa, tpb); BA_TADD(prof, 37, tpb, ts3);
-            if (si + block_size > qlen && sj + block_size > rlen) break;
+            if (si + block_size > qlen && sj + block_size > rlen) {
+                if (TRACE && chain && !XDROP) { rollback(); continue; }   // a global alignment's path starts at the end cell: everything below must be traced
+                break;
+            }
             if (sj + block_size > rlen) { si += STEP; dir = DIR_DOWN; continue; }
             if (si + block_size > qlen) { sj += STEP; dir = DIR_RIGHT; continue; }
 
             const uint32_t next_size = block_size * 2;
             if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
+                if (TRACE && KIND != KIND_PROFILE && !SPECIAL && !kBig && !chain && !no_spec && !(h_flags & 0x400u)) {
+                    // Speculative grows. A grow that does not raise the best score is followed at once by the next grow, and the
+                    // sequence that closes an X-drop alignment (128 -> 1024 in config 3: 29 % of its cells) never does: its rectangles
+                    // can be on no path. From here on grow steps reserve their trace space but compute neither trace flags nor
+                    // the location bookkeeping; should any later step raise the best score (or a global alignment end) while such
+                    // rectangles are on the stack, the driver returns to this point -- the checkpoint below -- and repeats
+                    // the steps since, traced (results and the cell count are those of the single, traced execution).
+                    ub_size = block_size; ub_tt = (uint32_t)unpark<3>(parked); ub_nb = (uint32_t)unpark<4>(parked);
+                    ub_xiter = x_drop_iter; ub_cells = cells; ub_budget = step_budget;
+                    copy_ckpt(true, block_size);
+                    chain = true;
+                }
                 prev_size = block_size; block_size = next_size; dir = DIR_GROW;
                 si = (uint32_t)unpark<0>(parked); sj = (uint32_t)unpark<1>(parked); off = unpark<2>(parked);
                 restore_ckpt_borders(prev_size);
@@ -1193,7 +1250,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             }
             al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
-            al.ckpt = bp.ckpt + (uint64_t)fill_wave * 4 * bp.max_size;
+            al.ckpt = bp.ckpt + (uint64_t)fill_wave * 8 * bp.max_size;   // (second half: the base of a chain of speculative grows)
             if (kBig) {   // the four borders live in this wave's slice of the big arena, not in LDS
                 short* bw = bp.big + (uint64_t)fill_wave * big_wave_shorts(bp.max_size);
                 const uint64_t as = big_array_shorts(bp.max_size);

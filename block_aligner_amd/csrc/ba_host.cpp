@@ -209,7 +209,7 @@ struct BaBatch {
         bp.q_off = q_off.as<uint64_t>(); bp.q_len = q_len.as<uint32_t>();
         bp.r_off = r_off.as<uint64_t>(); bp.r_len = r_len.as<uint32_t>();
         bp.n = n; bp.gap_open = gap_open; bp.gap_extend = gap_extend;
-        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (getenv("BA_NO_FAST") ? 0x100u : 0u) | (getenv("BA_SKIP_WALK") ? 0x200u : 0u);
+        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (getenv("BA_NO_FAST") ? 0x100u : 0u) | (getenv("BA_SKIP_WALK") ? 0x200u : 0u) | ((handle_mode || getenv("BA_NO_SPEC")) ? 0x400u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
         bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
@@ -461,7 +461,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         if (want < b->trace_full) { b->trace_stride = want; b->adaptive = true; }
     }
     b->blocks_stride = trace ? maxlen2 : 0;
-    if (b->trace_stride >= (1ull << 31)) { fail("trace stack of %llu words per pair exceeds the 2^31 limit", (unsigned long long)b->trace_stride); return 1; }
+    if (b->trace_stride >= (1ull << 30)) { fail("trace stack of %llu words per pair exceeds the 2^30 limit", (unsigned long long)b->trace_stride); return 1; }
     if (trace) {
         // very long pairs: a trace slot can be hundreds of MB, so fewer waves may be resident than the chip could hold --
         // shrink the launch until one slot per wave fits in device memory (a long pair keeps its wave busy for long anyway)
@@ -532,7 +532,7 @@ static int batch_alloc_scratch(BaBatch* b) {
 #define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return 1
     BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
-    BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 4 * b->max_size * sizeof(short));
+    BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
     BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short) : 0);
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
@@ -1292,12 +1292,12 @@ static int handle_prepare(BlockImpl* h) {
     b->cap_maxlen2 = sum + 2; b->cap_n = 1; b->cap_cig = sum + 1;
     b->trace_stride = trace ? handle_trace_stride(max_size, b->cap_maxlen2, h->mode) : 0;
     b->blocks_stride = trace ? b->cap_maxlen2 : 0;
-    if (b->trace_stride >= (1ull << 31)) return fail("trace stack of %llu words exceeds the 2^31 limit", (unsigned long long)b->trace_stride);
+    if (b->trace_stride >= (1ull << 30)) return fail("trace stack of %llu words exceeds the 2^30 limit", (unsigned long long)b->trace_stride);
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) return fail("hipEventCreate failed");
     if (b->hblk.alloc(b->cap_pool) || b->rblk.alloc(sizeof(HandleResult)) || b->matrix.alloc(1024) || b->cig_ops.alloc((trace ? b->cap_cig : 1) * 4) ||
         b->trace.alloc(b->trace_stride * 4) || b->blocks.alloc(b->blocks_stride * sizeof(BlockRec)) ||
-        b->ckpt.alloc((size_t)ba::WAVES_PER_WG * 4 * max_size * sizeof(short)) ||
+        b->ckpt.alloc((size_t)ba::WAVES_PER_WG * 8 * max_size * sizeof(short)) ||
         b->big.alloc(max_size > 2048 ? (size_t)ba::WAVES_PER_WG * ba::big_wave_shorts((uint32_t)max_size) * sizeof(short) : 0) || b->prof.alloc(512) || b->tb_ctrl.alloc(256) ||
         b->tb_queue.alloc(4) || b->slot_free.alloc(4) || b->slot_info.alloc(sizeof(ba::SlotInfo))) return 1;
     uint8_t* hb = b->hblk.as<uint8_t>(); uint8_t* rb = b->rblk.as<uint8_t>();

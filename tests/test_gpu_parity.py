@@ -635,3 +635,18 @@ def test_small_block_pipeline(hip, oracle, monkeypatch, mode, skip_quad):
     edge = synth.PairSet.from_lists([(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A" * 40, b"A" * 40), (b"ACGT" * 30, b"ACGT" * 30 + b"TTTT" * 20),
                                      (b"A" * 33, b"T" * 300), (b"ACGTNNNNACGT" * 5, b"ACGTACGT" * 6)] * 8)
     compare(hip, oracle, edge, S.NW1, (-2, -1), (32, 128), 20, mode)
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
+def test_speculative_grows_are_invisible(hip, oracle, monkeypatch, mode):
+    """TRACE batches run grow steps without trace flags while nothing says their rectangles can be on a path, and go back to the
+    chain's checkpoint -- re-running the steps since, traced -- when a later step raises the best score or a global alignment
+    ends on top of them (ba_driver.hpp, "speculative grows"). Pairs with long indels grow in mid-alignment, improve afterwards
+    and so take the roll-back; results, cell counts and CIGARs equal the oracle's and those of a run with BA_NO_SPEC=1."""
+    pairs = synth.make_pairs(300, (1500, 4000), (100, 400), 150, synth.DNA, seed=17, indels=4, indel_len=(30, 400))
+    size = (32, 1024)
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 120, mode)
+    monkeypatch.setenv("BA_NO_SPEC", "1")
+    res2 = compare(hip, oracle, pairs, NUC, (-5, -1), size, 120, mode)
+    for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len"):
+        assert np.array_equal(res[k], res2[k]), k
