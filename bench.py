@@ -271,11 +271,15 @@ def main():
                    "sanity_block32_us_per_pair": round(ref32["seconds"] / n32 * 1e6, 1),
                    "sanity_reference_notebook_us_per_pair": 239.7}
             if not a.no_secondary:
-                secondary = [secondary_line(np, H, W, o, W.config2(50000, workers=workers), cores),
-                             secondary_line(np, H, W, o, W.config2(50000, trace=True, workers=workers), cores),
-                             secondary_line(np, H, W, o, W.config4(50000), cores),
-                             secondary_line(np, H, W, o, W.config4(50000, trace=True), cores),
-                             secondary_line(np, H, W, o, W.config5(5000), cores)]
+                # (counts large enough that every resident wave sees a few dozen pairs: these launches last 5 - 30 ms)
+                c2, c4 = W.config2(200000, workers=1), W.config4(100000)
+                secondary = [secondary_line(np, H, W, o, c2, cores)]
+                c2.mode = ("trace", "x_drop"); c2.name += ", traceback"
+                secondary.append(secondary_line(np, H, W, o, c2, cores))
+                secondary.append(secondary_line(np, H, W, o, c4, cores))
+                c4.mode = ("trace",); c4.name += ", traceback"
+                secondary.append(secondary_line(np, H, W, o, c4, cores))
+                secondary.append(secondary_line(np, H, W, o, W.config5(20000), cores))
         out = {
             "metric": "GCUPS (DP cells/s) on 10 kbp DNA X-drop batch; bit-exact score+CIGAR vs AVX2",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
