@@ -272,7 +272,7 @@ def main():
                    "sanity_reference_notebook_us_per_pair": 239.7}
             if not a.no_secondary:
                 # (counts large enough that every resident wave sees a few dozen pairs: these launches last 5 - 30 ms)
-                c2, c4 = W.config2(200000, workers=1), W.config4(100000)
+                c2, c4 = W.config2(200000, workers=1), W.config4(400000)
                 secondary = [secondary_line(np, H, W, o, c2, cores)]
                 c2.mode = ("trace", "x_drop"); c2.name += ", traceback"
                 secondary.append(secondary_line(np, H, W, o, c2, cores))

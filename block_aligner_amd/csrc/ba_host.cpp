@@ -623,11 +623,11 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (batch_alloc_scratch(b.get())) return nullptr;
     // Small blocks: a 32-cell block keeps 16 of a wave's 64 lanes busy, so score-only batches that start at 32 cells run
     // their plain shift steps four pairs to a wave (k_quad) between two passes of the per-pair kernel (see batch_launch).
-    // (Measured: 1 kbp DNA at ~90 % identity 606 -> 1295 GCUPS; protein pairs at 30..100 % identity grow within a few steps and
-    // spend most of their time beyond 32 cells, where the two extra passes cost more than k_quad saves: 585 -> 489. Hence
-    // amino-acid batches stay on the per-pair kernel unless BA_FORCE_QUAD is set.)
+    // (Measured: 1 kbp DNA at ~90 % identity, 200k pairs: 606 -> 1353 GCUPS. Protein pairs at 30..100 % identity leave k_quad at
+    // their first grow and the two extra passes each bring a launch tail: 100k pairs 540 -> 485, 200k 589 -> 725, 800k 597 -> 983.
+    // Hence amino-acid batches take the pipeline from 131072 pairs on; BA_FORCE_QUAD / BA_NO_QUAD override.)
     b->quad = !trace && !profile && !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
-              (getenv("BA_FORCE_QUAD") || (n >= 2048 && kind != BA_KIND_AA));
+              (getenv("BA_FORCE_QUAD") || n >= (kind == BA_KIND_AA ? 131072u : 2048u));
     if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->contB.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(2 * n * 4))) return nullptr;
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
@@ -704,7 +704,7 @@ static int batch_launch(BaBatch* b) {
         if (!getenv("BA_QUAD_SKIP")) {   // (development switch: passes 1 and 3 only)
             HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
             BatchParams p2 = bp; p2.cont_in = last; p2.cont_in_flag = last_flag; p2.cont_out = b->contB.as<ba::PairCont>(); p2.cont_out_flag = flagB;
-            p2.work_chunk = 16;
+            p2.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
             HIP_TRY(g_launch_quad[b->kind]((b->mode & BA_X_DROP) != 0, b->stream, &p2));
             last = b->contB.as<ba::PairCont>(); last_flag = flagB;
         }

@@ -155,6 +155,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     unsigned long long cells0 = 0;
     const uint8_t* qp = bp.pool; const uint8_t* rp = bp.pool;
     int Dcol = 0, Ccol = 0, Drow = 0, Rrow = 0, ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0;
+    // sequence bytes of the next step, fetched one step ahead for both possible directions (a pair's steps are a dependent
+    // chain: without this every step of the batch's longest pair waits a memory round trip)
+    int pf_qv = 0, pf_rv = 0; uint2 pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter (wave-uniform)
     bool more = true;
 
@@ -185,6 +188,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
                 ck0 = (int)c->ckpt[0][l]; ck1 = (int)c->ckpt[1][l]; ck2 = (int)c->ckpt[2][l]; ck3 = (int)c->ckpt[3][l];
                 qp = bp.pool + bp.q_off[pair]; rp = bp.pool + bp.r_off[pair];
                 qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
+                pf_ok = false;
             }
             idle = pair == ~0u;
         }
@@ -202,11 +206,19 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         const int off_add = sat16(off - off_n);
         const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
         const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
-        int vc = 0; uint32_t cb_lo = 0, cb_hi = 0;
-        if (run) {
-            vc = *(const unsigned short*)(Vp + ri + 2 * l);
-            const uint2 cb = *(const uint2*)(Cp + rj);       // the step's 8 column bytes (images are 4-byte aligned, positions multiples of 8)
-            cb_lo = cb.x; cb_hi = cb.y;
+        int vc = right ? pf_qv : pf_rv; uint32_t cb_lo = right ? pf_rc.x : pf_qc.x, cb_hi = right ? pf_rc.y : pf_qc.y;
+        if (__any(run && !pf_ok)) {   // a slot that has just taken a pair
+            if (run && !pf_ok) {
+                vc = *(const unsigned short*)(Vp + ri + 2 * l);
+                const uint2 cb = *(const uint2*)(Cp + rj);   // the step's 8 column bytes (images are 4-byte aligned, positions multiples of 8)
+                cb_lo = cb.x; cb_hi = cb.y;
+            }
+        }
+        asm volatile("" : "+v"(vc));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
+        if (run) {                      // for the step after this one, whichever way it goes
+            pf_qv = *(const unsigned short*)(qp + si + 2 * l); pf_rv = *(const unsigned short*)(rp + sj + 2 * l);
+            pf_qc = *(const uint2*)(qp + si + QUAD_B); pf_rc = *(const uint2*)(rp + sj + QUAD_B);
+            pf_ok = true;
         }
         int Ad = right ? Dcol : Drow, Ac = right ? Ccol : Rrow, Pd = right ? Drow : Dcol, Pr = right ? Rrow : Ccol;
         QuadOut o;
