@@ -453,6 +453,57 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
 #endif
 }
 
+// Pair-slot batches (every pair's trace stack stays in its own region until the batch ends): the tracebacks of the whole
+// batch after its fill kernels, one pair per LANE, all 64 lanes of every wave walking (tb_step). Lanes that finish take the
+// next pairs of the batch order (longest first, so the lanes of a wave walk paths of similar length) with one atomic per wave.
+__device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
+    const uint32_t eq = bp.flags & flag_mask;
+    unsigned char* lut = tb_lds;
+    unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * TB_LANE_BYTES;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const uint32_t idx = (uint32_t)lane_id() + 64u * e;
+        const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);
+        lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
+    }
+    lds_sync();
+    TbLane t{};
+    bool walking = false, more = true;
+    for (;;) {
+        if (more && !__all(walking)) {
+            const unsigned long long im = __ballot(!walking);
+            uint32_t base = 0;
+            if (is_lane(0)) base = atomicAdd(bp.work_counter, (uint32_t)__popcll(im));
+            base = (uint32_t)uni((int)base);
+            if (base + (uint32_t)__popcll(im) >= bp.n) more = false;
+            const uint32_t p = base + (uint32_t)__popcll(im & ((1ull << lane_id()) - 1ull));
+            if (!walking && p < bp.n) {
+                const SlotInfo si = bp.slot_info[p];
+                t = TbLane{};
+                t.qw0 = t.rw0 = 0xffffffffu; t.tw_ok = false;
+                t.slot = p; t.pair = p; t.i = si.end_i; t.j = si.end_j; t.bidx = si.nblocks;
+                t.blocks = bp.blocks + bp.blocks_off[p];
+                t.trace = bp.trace_arena + bp.trace_off[p];
+                t.q = bp.pool + bp.q_off[p]; t.r = bp.pool + bp.r_off[p];
+                t.lo = bp.cig_off[p]; t.wp = bp.cig_off[p + 1];
+                t.status = bp.status[p];
+                if (t.status || (bp.flags & 0x200u)) t.i = t.j = 0;   // the fill failed (or development switch: skip the walk)
+                walking = true;
+            }
+        }
+        if (!__any(walking)) break;
+        if (walking) {
+            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut);
+            if (!(t.i > 0 || t.j > 0)) {
+                tb_emit(t, bp.cig_ops);
+                bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
+                if (t.status) bp.status[t.pair] = t.status;
+                walking = false;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ driver
 // SPECIAL: the batch uses LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS. A separate instantiation, so the
 // common kernels carry none of that state (it costs registers: +30 % spills when folded into one kernel).
@@ -477,7 +528,7 @@ struct Aligner {
     uint32_t* trace; BlockRec* blocks; short* ckpt;   // this wave's slot in the global scratch arenas
     short* big_top = nullptr;                         // big-block kernels: the row hand-off arrays of the tiled fill (2 x big_array_shorts)
     uint32_t trace_top = 0, nblocks = 0;
-    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot, 9-11 the first grow rectangle's max / row / col (see park())
+    int parked = 0;   // lanes: 0 i_ckpt, 1 j_ckpt, 2 off_ckpt, 3 ck_trace_top, 4 ck_nblocks, 5 best_i, 6 best_j, 7 pair, 8 slot, 9-11 the first grow rectangle's max / row / col (see park()), 12 / 13 the capacity of the pair's trace region (words) / record list
     uint32_t status = 0;
     unsigned long long cells = 0;
     // sequence bytes for the next shift step, fetched one step ahead for both possible directions: this lane's two
@@ -645,10 +696,10 @@ struct Aligner {
     }
 
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right, bool untraced = false) {
-        if (nblocks >= (uint32_t)coldp()->blocks_stride) { status |= ST_BLOCKS_OVERFLOW; return; }
+        if (nblocks >= (uint32_t)unpark<13>(parked)) { status |= ST_BLOCKS_OVERFLOW; return; }
         // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
         const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 5u : 1u);
-        if ((uint64_t)trace_top + words + 64 > coldp()->trace_stride) { status |= ST_TRACE_OVERFLOW; return; }   // (64 words of slack stay free: see the host's trace_stride)
+        if (trace_top + words + 64 > (uint32_t)unpark<12>(parked)) { status |= ST_TRACE_OVERFLOW; return; }   // (64 words of slack stay free: see the host's trace_stride)
         {   // every lane stores the same 16 bytes to the same address (one transaction): no exec-mask region per step
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
             br.trace_base = trace_top | (right ? 0x80000000u : 0u) | (untraced ? 0x40000000u : 0u);   // (untraced: space reserved, flags not computed)
@@ -764,6 +815,7 @@ struct Aligner {
             c->best_i = (uint32_t)unpark<5>(parked); c->best_j = (uint32_t)unpark<6>(parked);
             c->ck_i = (uint32_t)unpark<0>(parked); c->ck_j = (uint32_t)unpark<1>(parked); c->ck_off = unpark<2>(parked);
             c->cells = cells; c->step_budget = step_budget;
+            if (TRACE) { c->trace_top = trace_top; c->nblocks = nblocks; c->ck_trace_top = (uint32_t)unpark<3>(parked); c->ck_nblocks = (uint32_t)unpark<4>(parked); c->status = status; }
         }
         if (lane < 16) {
             c->borders[0][lane] = (uint32_t)*(const int*)(L.D_col + 2 * lane); c->borders[1][lane] = (uint32_t)*(const int*)(L.C_col + 2 * lane);
@@ -801,6 +853,14 @@ struct Aligner {
         int best_max = 0;
         parked = 0;
         park<7>(parked, (int)pair_in); park<8>(parked, (int)slot_in);   // not needed again before the pair is done
+        if (TRACE) {   // room for this pair's trace words and rectangle records: the ring slot's, or the pair's own region
+            uint64_t tcap = coldp()->trace_stride, bcap = coldp()->blocks_stride;
+            if (coldp()->trace_off) {
+                tcap = coldp()->trace_off[pair_in + 1] - coldp()->trace_off[pair_in];
+                bcap = coldp()->blocks_off[pair_in + 1] - coldp()->blocks_off[pair_in];
+            }
+            park<12>(parked, (int)(tcap < 0x7fffffffull ? tcap : 0x7fffffffull)); park<13>(parked, (int)(bcap < 0x7fffffffull ? bcap : 0x7fffffffull));
+        }
         int prev_dir = DIR_GROW, dir = DIR_GROW;
         uint32_t prev_size = 0, block_size = min_size;
         int off = 0, prev_off = 0, off_max = 0;
@@ -813,13 +873,17 @@ struct Aligner {
 #ifdef BA_TIMING
         uint32_t steps = 0;
 #endif
-        if (!TRACE && resume) {   // a pair that comes back from the small-block kernel: its state at the top of the loop
+        if (resume) {   // a pair that comes back from the small-block kernel: its state at the top of the loop
             const int lane = lane_id();
             si = resume->si; sj = resume->sj; dir = resume->dir; prev_dir = resume->prev_dir; off = resume->off; off_max = resume->off_max;
             best_max = resume->best_max; y_drop_iter = resume->y_drop_iter; x_drop_iter = resume->x_drop_iter; D_corner = resume->D_corner;
             cells = resume->cells; step_budget = resume->step_budget;
             park<5>(parked, (int)resume->best_i); park<6>(parked, (int)resume->best_j);
             park<0>(parked, (int)resume->ck_i); park<1>(parked, (int)resume->ck_j); park<2>(parked, resume->ck_off);
+            if (TRACE) {
+                trace_top = resume->trace_top; nblocks = resume->nblocks; status = resume->status;
+                park<3>(parked, (int)resume->ck_trace_top); park<4>(parked, (int)resume->ck_nblocks);
+            }
             if (lane < 16) {
                 *(int*)(L.D_col + 2 * lane) = (int)resume->borders[0][lane]; *(int*)(L.C_col + 2 * lane) = (int)resume->borders[1][lane];
                 *(int*)(L.D_row + 2 * lane) = (int)resume->borders[2][lane]; *(int*)(L.R_row + 2 * lane) = (int)resume->borders[3][lane];
@@ -881,7 +945,7 @@ struct Aligner {
             BA_TSTAMP(tsa);
             const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
-            if (!TRACE && fast && block_size == 32 && coldp()->cont_mode == 1) {
+            if (fast && block_size == 32 && coldp()->cont_mode == 1) {
                 // small-block batch, first pass: the pair leaves for the 4-pairs-per-wave kernel at its first register-path step.
                 // What is written is the state the top of this loop would start the step from (the set-up above is undone).
                 step_budget++; off = prev_off;
@@ -1138,6 +1202,7 @@ struct Aligner {
             if (coldp()->nblocks_out) coldp()->nblocks_out[pair] = nblocks;
             if (coldp()->trace_words_out) coldp()->trace_words_out[pair] = trace_top;
             if (coldp()->slot_out) coldp()->slot_out[pair] = slot;
+            if (TRACE && coldp()->trace_off) coldp()->slot_info[pair] = SlotInfo{pair, nblocks, ri, rj};   // pair-slot batches: walked by k_walk
         }
     }
 };
@@ -1227,12 +1292,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             }
             uint32_t pair = w_next++;
             const PairCont* rec = nullptr;
-            if (!TRACE && bp.cont_mode == 2) {   // only the pairs the small-block kernel left a record for are still in flight
+            if (bp.cont_mode == 2) {   // only the pairs the small-block kernel left a record for are still in flight
                 if (!bp.cont_in_flag[pair]) continue;
                 rec = bp.cont_in + pair;
             }
-            const uint32_t slot = fill_wave * bp.slots_per_wave + turn;
+            uint32_t slot = fill_wave * bp.slots_per_wave + turn;
             if (++turn == bp.slots_per_wave) turn = 0;
+            if (TRACE && bp.trace_off) slot = pair;   // pair-slot batches: the pair's own region (never shared, never waited for)
             Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
             BA_TSTAMP(tw0);
             const bool got_slot = !batch_traceback || al.acquire_slot(slot);
@@ -1250,6 +1316,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             }
             al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
+            if (TRACE && bp.trace_off) { al.trace = bp.trace_arena + bp.trace_off[pair]; al.blocks = bp.blocks + bp.blocks_off[pair]; }
             al.ckpt = bp.ckpt + (uint64_t)fill_wave * 8 * bp.max_size;   // (second half: the base of a chain of speculative grows)
             if (kBig) {   // the four borders live in this wave's slice of the big arena, not in LDS
                 short* bw = bp.big + (uint64_t)fill_wave * big_wave_shorts(bp.max_size);

@@ -37,6 +37,7 @@ BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
 BA_DECL_BIG(0) BA_DECL_BIG(1) BA_DECL_BIG(2) BA_DECL_BIG(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_walk(hipStream_t, const BatchParams*, uint32_t grid);
 extern "C" hipError_t ba_launch_merge_retry(hipStream_t, const uint32_t*, uint32_t, const BatchParams*, const BatchParams*, const uint32_t*, uint32_t*);
 extern "C" hipError_t ba_launch_pack_sequences(hipStream_t, int, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint32_t*,
                                                const uint64_t*, const uint32_t*, uint8_t*, uint32_t, uint32_t, unsigned long long*);
@@ -50,10 +51,10 @@ typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 // [special modes?][kind][block class]
 static const LaunchFn g_launch[2][4][5] = {{BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)}, {BA_SROW(0), BA_SROW(1), BA_SROW(2), BA_SROW(3)}};
 static const OccFn g_occ[2][4][5] = {{BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)}, {BA_SOROW(0), BA_SOROW(1), BA_SOROW(2), BA_SOROW(3)}};
-typedef hipError_t (*QuadFn)(int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k0(int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k1(int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k2(int, hipStream_t, const BatchParams*);
+typedef hipError_t (*QuadFn)(int, int, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k0(int, int, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k1(int, int, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k2(int, int, hipStream_t, const BatchParams*);
 static const QuadFn g_launch_quad[3] = {ba_launch_quad_k0, ba_launch_quad_k1, ba_launch_quad_k2};
 static const LaunchFn g_launch_big[4] = {ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32};
 static const OccFn g_occ_big[4] = {ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32};
@@ -199,8 +200,13 @@ struct BaBatch {
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false, in_flight = false;
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
-    bool quad = false;          // small-block score-only batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
+    bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, contB, cont_n;   // PairCont lists between the three launches of such a batch, and their counters
+    // pair-slot batch (a small-block batch with TRACE): every pair owns a region of the trace / record arenas for the whole
+    // batch (offsets below, n + 1 entries each), the fill kernels only stack, and k_walk does all tracebacks at the end
+    bool pipe = false;
+    DevBuf trace_off, blocks_off;
+    uint64_t pipe_words = 0, pipe_recs = 0;   // arena capacities (ba_batch_reload re-cuts them)
     bool handle_mode = false;   // the device state of one Block handle: one pair per launch, CIGARs only on request (k_traceback)
     DevBuf hblk, rblk;          // handle mode: everything uploaded per align / everything read back, one buffer each
     BatchParams params() const {
@@ -217,6 +223,7 @@ struct BaBatch {
         bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>(); bp.trace_words_out = trace_words.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
+        bp.trace_off = pipe ? trace_off.as<uint64_t>() : nullptr; bp.blocks_off = pipe ? blocks_off.as<uint64_t>() : nullptr;
         bp.ckpt = ckpt.as<short>(); bp.big = big.as<short>();
         bp.tb_stride = tb_stride; bp.slots_per_wave = slots_per_wave; bp.n_slots = slots; bp.tb_reserve = tb_reserve;
         bp.tb_qmask = tb_qsize - 1;
@@ -419,6 +426,40 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
                                [&](size_t s) { return getp(order[s]); }, P, lap);
 }
 
+// Pair-slot batches: pair p's region of the trace arena holds its expected stack -- every step at the minimum block size, one
+// grow sequence to the maximum, a few steps there -- times a margin (pct), never more than the reference's bound for the pair
+// (Trace::new, scan_block.rs:1363-1366); its record list one entry per 4 residues. Pairs that outgrow their region report
+// BA_ST_TRACE_OVERFLOW and are re-run by batch_wait. Returns the arena sizes in words / records.
+static void pipe_regions(const BaBatch* b, const uint32_t* ql, const uint32_t* rl, size_t n, uint64_t pct, std::vector<uint64_t>& toff,
+                         std::vector<uint64_t>& boff) {
+    toff.resize(n + 1); boff.resize(n + 1);
+    const uint64_t mx = b->max_size, mn = b->min_size;
+    uint64_t t = 0, r = 0;
+    for (size_t p = 0; p < n; p++) {
+        const uint64_t len2 = (uint64_t)ql[p] + rl[p] + 2;
+        const uint64_t full = (mx / 16) * (len2 + 2 * mx) * 2 + 64;
+        const uint64_t want = (len2 * mn / 8 + mx * mx / 8 + 16 * mx) * pct / 100 + 4096;
+        toff[p] = t; t += (std::min(want, full) + 15) & ~15ull;
+        boff[p] = r; r += len2 / 4 + 64;
+    }
+    toff[n] = t; boff[n] = r;
+}
+// Cut the arenas for the pairs (ql, rl). cap_words / cap_recs = 0: choose the margin by the free device memory (the caller
+// allocates pipe_words / pipe_recs afterwards); otherwise the regions must fit the existing arenas. Returns 1 if they cannot.
+static int pipe_cut(BaBatch* b, const uint32_t* ql, const uint32_t* rl, size_t n, uint64_t fixed_bytes, std::vector<uint64_t>& toff, std::vector<uint64_t>& boff) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    uint64_t forced = 0;   // (development / test switch, as for the ring slots)
+    if (const char* env = getenv("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) forced = (uint64_t)v; }
+    for (uint64_t pct : {175ull, 140ull, 110ull}) {
+        if (forced) pct = forced;
+        pipe_regions(b, ql, rl, n, pct, toff, boff);
+        if (b->pipe_words) { if (toff[n] <= b->pipe_words && boff[n] <= b->pipe_recs) return 0; }
+        else if (toff[n] * 4 + boff[n] * sizeof(BlockRec) + fixed_bytes + (1ull << 30) <= (uint64_t)free_b * 85 / 100) return 0;
+    }
+    return 1;
+}
+
 // Launch geometry and scratch sizes of a batch whose inputs are known: workgroups, LDS, trace slot size, traceback waves,
 // slots per wave, hand-off ring. fixed_bytes = device memory the batch needs besides its per-wave scratch.
 static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxlen2, bool full_trace, uint64_t avg_len2 = ~0ull) {
@@ -487,7 +528,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
         b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
     }
-    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !getenv("BA_INLINE_TRACEBACK")) {
+    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !b->pipe && !getenv("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
         // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
@@ -518,6 +559,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
     }
     b->slots = b->n_fill_waves * b->slots_per_wave;
+    if (b->pipe) b->slots = (uint32_t)n;   // (slot = pair: slot_info holds one entry per pair for k_walk)
     {
         const uint64_t lanes = b->tb_stride ? (uint64_t)((b->grid + b->tb_stride - 1) / b->tb_stride) * 64 + b->n_fill_waves : 0;   // + one helper lane per fill wave
         uint64_t need_q = std::max<uint64_t>(lanes, b->slots);
@@ -530,8 +572,8 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
 }
 static int batch_alloc_scratch(BaBatch* b) {
 #define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return 1
-    BA_ALLOC(trace, b->trace_stride * 4 * b->slots);
-    BA_ALLOC(blocks, b->blocks_stride * sizeof(BlockRec) * b->slots);
+    BA_ALLOC(trace, b->pipe ? b->pipe_words * 4 : b->trace_stride * 4 * b->slots);
+    BA_ALLOC(blocks, b->pipe ? b->pipe_recs * sizeof(BlockRec) : b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
     BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short) : 0);
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams));
@@ -608,7 +650,21 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
     uint64_t sum_len2 = 0;
     for (size_t p = 0; p < n; p++) sum_len2 += (uint64_t)ql[p] + rl[p];
+    // Small blocks: a 32-cell block keeps 16 of a wave's 64 lanes busy, so batches that start at 32 cells run their plain shift
+    // steps four pairs to a wave (k_quad) between two passes of the per-pair kernel (see batch_launch).
+    // (Measured, score only: 1 kbp DNA at ~90 % identity, 200k pairs: 606 -> 1353 GCUPS. Protein pairs at 30..100 % identity leave
+    // k_quad at their first grow and the two extra passes each bring a launch tail: 100k pairs 540 -> 485, 200k 589 -> 725,
+    // 800k 597 -> 983. Hence amino-acid batches take the pipeline from 131072 pairs on; BA_FORCE_QUAD / BA_NO_QUAD override.)
+    b->quad = !profile && !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
+              (getenv("BA_FORCE_QUAD") || n >= (kind == BA_KIND_AA ? 131072u : 2048u));
+    std::vector<uint64_t> toff, boff;
+    if (b->quad && trace) {   // with TRACE the pipeline needs every pair's trace stack resident until the end
+        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * (64 + 2 * sizeof(ba::PairCont) + 40);
+        if (getenv("BA_NO_TRACE_QUAD") || pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) b->quad = false;
+        else { b->pipe = true; b->pipe_words = toff[n] + toff[n] / 8; b->pipe_recs = boff[n] + boff[n] / 8; }   // (headroom for ba_batch_reload)
+    }
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
+    if (b->pipe) b->adaptive = true;
     b->cig_total = trace ? cig_total : 0;
 
     lap("launch geometry");
@@ -621,18 +677,13 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(cig_ops, b->cig_total * 4);
 #undef BA_ALLOC
     if (batch_alloc_scratch(b.get())) return nullptr;
-    // Small blocks: a 32-cell block keeps 16 of a wave's 64 lanes busy, so score-only batches that start at 32 cells run
-    // their plain shift steps four pairs to a wave (k_quad) between two passes of the per-pair kernel (see batch_launch).
-    // (Measured: 1 kbp DNA at ~90 % identity, 200k pairs: 606 -> 1353 GCUPS. Protein pairs at 30..100 % identity leave k_quad at
-    // their first grow and the two extra passes each bring a launch tail: 100k pairs 540 -> 485, 200k 589 -> 725, 800k 597 -> 983.
-    // Hence amino-acid batches take the pipeline from 131072 pairs on; BA_FORCE_QUAD / BA_NO_QUAD override.)
-    b->quad = !trace && !profile && !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
-              (getenv("BA_FORCE_QUAD") || n >= (kind == BA_KIND_AA ? 131072u : 2048u));
     if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->contB.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(2 * n * 4))) return nullptr;
+    if (b->pipe && (b->trace_off.alloc((n + 1) * 8) || b->blocks_off.alloc((n + 1) * 8))) return nullptr;
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
     BA_H2D(r_off, ro.data(), n * 8); BA_H2D(r_len, rl.data(), n * 4); BA_H2D(cig_off, cig_off.data(), (n + 1) * 8);
+    if (b->pipe) { BA_H2D(trace_off, toff.data(), (n + 1) * 8); BA_H2D(blocks_off, boff.data(), (n + 1) * 8); }
     if (upload_images(b.get(), P, n)) return nullptr;
     {
         int8_t tmp[1024] = {0};
@@ -660,6 +711,8 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     if (P.total > b->cap_pool) return fail("reload: %llu sequence bytes exceed the batch's capacity of %llu", (unsigned long long)P.total, (unsigned long long)b->cap_pool);
     if (P.maxlen2 > b->cap_maxlen2) return fail("reload: a pair is longer (%llu) than the longest pair the batch was created with (%llu)", (unsigned long long)P.maxlen2 - 2, (unsigned long long)b->cap_maxlen2 - 2);
     if ((b->mode & BA_TRACE) && P.cig_total > b->cap_cig) return fail("reload: CIGAR capacity exceeded");
+    std::vector<uint64_t> toff, boff;
+    if (b->pipe && pipe_cut(b, P.ql.data(), P.rl.data(), n, 0, toff, boff)) return fail("reload: the new pairs' trace regions exceed the batch's trace arena");
     // from here on the device arrays change: a failure leaves no pairs loaded (a later launch says so) instead of a mix
     b->n = 0; b->ran = false;
     HIP_TRY(hipMemcpy(b->q_off.p, P.qo.data(), n * 8, hipMemcpyHostToDevice));
@@ -668,6 +721,10 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     HIP_TRY(hipMemcpy(b->r_len.p, P.rl.data(), n * 4, hipMemcpyHostToDevice));
     if (upload_images(b, P, n)) return 1;
     HIP_TRY(hipMemcpy(b->cig_off.p, P.cig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    if (b->pipe) {
+        HIP_TRY(hipMemcpy(b->trace_off.p, toff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->blocks_off.p, boff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemset(b->cig_len.p, 0, n * 4));
     HIP_TRY(hipMemset(b->status.p, 0, n * 4));
     b->n = (uint32_t)n; b->h_q_off = P.qo; b->h_r_off = P.ro; b->h_order = P.order; b->pool_bytes = P.total;
@@ -698,19 +755,31 @@ static int batch_launch(BaBatch* b) {
         // pass 3 (per-pair kernel): the pairs of list B to their end.
         uint32_t* flagA = b->cont_n.as<uint32_t>(); uint32_t* flagB = flagA + b->cap_n;
         HIP_TRY(hipMemsetAsync(flagA, 0, 2 * b->cap_n * 4, b->stream));
+        // TRACE (a pair-slot batch): the three fill launches only stack trace words and records in the pairs' regions;
+        // pass 4 (k_walk) walks every pair's path, one pair per lane.
+        const int tr = (b->mode & BA_TRACE) ? 1 : 0;
         BatchParams p1 = bp; p1.cont_mode = 1; p1.cont_out = b->contA.as<ba::PairCont>(); p1.cont_out_flag = flagA;
-        HIP_TRY(launch(0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
+        if (tr) p1.cig_ops = nullptr;
+        HIP_TRY(launch(tr, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
         const ba::PairCont* last = b->contA.as<ba::PairCont>(); const uint32_t* last_flag = flagA;
         if (!getenv("BA_QUAD_SKIP")) {   // (development switch: passes 1 and 3 only)
             HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
             BatchParams p2 = bp; p2.cont_in = last; p2.cont_in_flag = last_flag; p2.cont_out = b->contB.as<ba::PairCont>(); p2.cont_out_flag = flagB;
             p2.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
-            HIP_TRY(g_launch_quad[b->kind]((b->mode & BA_X_DROP) != 0, b->stream, &p2));
+            HIP_TRY(g_launch_quad[b->kind](tr, (b->mode & BA_X_DROP) != 0, b->stream, &p2));
             last = b->contB.as<ba::PairCont>(); last_flag = flagB;
         }
         HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
         BatchParams p3 = bp; p3.cont_mode = 2; p3.cont_in = last; p3.cont_in_flag = last_flag;
-        HIP_TRY(launch(0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p3));
+        if (tr) p3.cig_ops = nullptr;
+        HIP_TRY(launch(tr, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p3));
+        if (tr && bp.cig_ops) {
+            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, b->device));
+            const uint32_t need = (b->n + 255u) / 256u, full = (uint32_t)prop.multiProcessorCount * 8u;
+            HIP_TRY(ba_launch_walk(b->stream, &bp, std::min(need, full)));
+        }
     } else
     HIP_TRY(launch((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
     HIP_TRY(hipEventRecord(b->ev1, b->stream));

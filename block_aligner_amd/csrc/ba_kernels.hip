@@ -55,23 +55,24 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
 }
 
 #if BA_KIND != 3 && BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
-// four pairs per wave while the block is 32 cells (score-only batches; ba_quad.hpp): one kernel per sequence kind
+// four pairs per wave while the block is 32 cells (ba_quad.hpp): one kernel per sequence kind
 #include "ba_quad.hpp"
-template <bool XDROP>
+template <bool TRACE, bool XDROP>
 static hipError_t launch_quad(hipStream_t s, const ba::BatchParams& bp) {
     const unsigned lds = ba::lds_table_bytes_h(BA_KIND) + ba::WAVES_PER_WG * 4 * ba::QUAD_SLOT_BYTES;
     int per_cu = 0, dev = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba::k_quad<BA_KIND, XDROP>, ba::WAVES_PER_WG * 64, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba::k_quad<BA_KIND, TRACE, XDROP>, ba::WAVES_PER_WG * 64, lds);
     if (e != hipSuccess) return e;
     hipDeviceProp_t prop;
     if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
-    ba::k_quad<BA_KIND, XDROP><<<dim3(prop.multiProcessorCount * per_cu), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    ba::k_quad<BA_KIND, TRACE, XDROP><<<dim3(prop.multiProcessorCount * per_cu), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
     return hipGetLastError();
 }
-extern "C" hipError_t BA_CAT(ba_launch_quad_k, BA_KIND, , )(int xdrop, hipStream_t s, const ba::BatchParams* bp) {
-    return xdrop ? launch_quad<true>(s, *bp) : launch_quad<false>(s, *bp);
+extern "C" hipError_t BA_CAT(ba_launch_quad_k, BA_KIND, , )(int trace, int xdrop, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch_quad<true, true>(s, *bp) : launch_quad<true, false>(s, *bp);
+    return xdrop ? launch_quad<false, true>(s, *bp) : launch_quad<false, false>(s, *bp);
 }
 #endif
 
@@ -87,6 +88,13 @@ __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {
                                  bp.flags, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
     bp.cig_len[0] = n;
     bp.status[0] = st;
+}
+
+// Pair-slot batches: all tracebacks of the batch, one pair per lane (ba_driver.hpp traceback_all).
+constexpr int WALK_WAVES = 4;
+__global__ void __launch_bounds__(WALK_WAVES * 64) k_walk(const ba::BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char walk_lds[];
+    ba::traceback_all(bp, (uint32_t)ba::F_CIGAR_EQ, walk_lds + ((uint32_t)threadIdx.x >> 6) * ba::TB_LDS_BYTES);
 }
 
 __global__ void __launch_bounds__(256) k_compact_cigars(const uint32_t* __restrict__ ops, const uint64_t* __restrict__ cig_off,
@@ -163,6 +171,10 @@ __global__ void __launch_bounds__(256) k_merge_retry(const uint32_t* __restrict_
 extern "C" hipError_t ba_launch_merge_retry(hipStream_t s, const uint32_t* idx, uint32_t k, const ba::BatchParams* sub, const ba::BatchParams* dst,
                                             const uint32_t* sub_tw, uint32_t* dst_tw) {
     k_merge_retry<<<dim3(k), dim3(256), 0, s>>>(idx, *sub, *dst, sub_tw, dst_tw);
+    return hipGetLastError();
+}
+extern "C" hipError_t ba_launch_walk(hipStream_t s, const ba::BatchParams* bp, uint32_t grid) {
+    k_walk<<<dim3(grid), dim3(WALK_WAVES * 64), WALK_WAVES * ba::TB_LDS_BYTES, s>>>(*bp);
     return hipGetLastError();
 }
 extern "C" hipError_t ba_launch_traceback(hipStream_t s, const ba::BatchParams* bp) {

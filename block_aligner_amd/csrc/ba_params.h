@@ -38,7 +38,8 @@ BA_HD inline uint64_t profile_image_bytes(uint32_t len, uint32_t max_size) { ret
 struct PairCont {
     uint32_t pair, si, sj; int32_t dir, prev_dir, off, off_max, best_max;
     uint32_t y_drop_iter; int32_t x_drop_iter, D_corner; uint32_t best_i, best_j, ck_i, ck_j; int32_t ck_off;
-    unsigned long long cells; uint32_t step_budget, pad_[5];
+    unsigned long long cells; uint32_t step_budget;
+    uint32_t trace_top, nblocks, ck_trace_top, ck_nblocks, status;   // TRACE: the pair's trace stack (it lives in the pair's own region)
     uint32_t borders[4][16];   // D_col, C_col, D_row, R_row: lane l holds cells 2l, 2l+1 (packed i16)
     uint32_t ckpt[4][16];
 };
@@ -66,6 +67,9 @@ struct BatchParams {
     // scratch, one region per resident wave
     uint32_t* trace_arena; uint64_t trace_stride;     // dwords per slot
     BlockRec* blocks; uint64_t blocks_stride;         // records per slot
+    // pair-slot batches (the small-block TRACE pipeline): every pair owns a region for the whole batch, pair p's trace words at
+    // trace_arena + trace_off[p] (capacity trace_off[p + 1] - trace_off[p]) and its records at blocks + blocks_off[p]; slot = pair
+    const uint64_t* trace_off; const uint64_t* blocks_off;
     short* ckpt;                 // per fill wave: 4 x max_size i16 (best-so-far borders, scan_block.rs:406-427)
     short* big;                  // block sizes above 2048 only: per fill wave big_wave_shorts(max_size) i16 -- the four live borders
                                  // (too large for LDS) and the two row hand-off arrays of the tiled fill (ba_device.hpp TileCtx)

@@ -10,7 +10,8 @@
 // (its first block, a grow, termination, the early column break at the matrix edge) is done by the per-pair kernel, before
 // and after: pairs arrive and leave as PairCont records (ba_params.h) holding the driver's state at the top of its loop.
 // A step whose outcome calls for anything but another shift is rolled back and the pair leaves with its pre-step state.
-// Score-only batches (no trace), sequence-sequence kinds.
+// Sequence-sequence kinds. TRACE batches are pair-slot batches (ba_params.h): a pair's trace words and rectangle records go to
+// the pair's own region, which the per-pair kernel continues and k_walk reads after the last fill kernel.
 #pragma once
 #include "ba_driver.hpp"
 
@@ -34,9 +35,10 @@ __device__ __forceinline__ int sat16(int x) { return x < -32768 ? -32768 : (x > 
 struct QuadOut { int mx, row, col, act_max8, pas_max8, corner_new; };
 
 // One 8-column shift step for the four slots of a wave (fast_rect with row-uniform operands in VGPRs).
-template <int KIND, bool XDROP>
+template <int KIND, bool TRACE, bool XDROP>
 __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& fc, int l, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
-                                          int vec_a, int vec_b, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, int loc_thr, QuadOut& o) {
+                                          int vec_a, int vec_b, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, int loc_thr,
+                                          uint32_t* __restrict__ tout, bool store, QuadOut& o) {
     const int offa = splat(off_add);
     int d = adds(Ad, offa), c = adds(Ac, offa);
     const int pd = adds(Pd, offa), pr = adds(Pr, offa);
@@ -44,7 +46,7 @@ __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& f
     *(int*)(Pl + 2 * l) = pd; *(int*)(Pl + QUAD_PR + 2 * l) = pr;
     o.corner_new = slot_bcast<3>(pd) >> 16;
     const ScoreKey<KIND> key = make_key<KIND>(vec_a, vec_b);
-    int dmax = 0;
+    int dmax = 0, tacc = 0;
     int dcol[STEP];
     short* last_base = l == 15 ? Pl + QUAD_B : sink;
 #pragma unroll
@@ -65,6 +67,16 @@ __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& f
         const s16x2 cs = as_s(add_row_shr1(pm, fc.lanem1KG));
         r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst_top);
         const int dn = vmax(d11, r);
+        if (TRACE) {   // the cell's four flags as sign bits of saturating differences, one nibble per column (see fast_rect)
+            const uint32_t sC = (uint32_t)subs(cn, dn), sR = (uint32_t)subs(r, dn), sCo = (uint32_t)subs(copen, cn), sRo = (uint32_t)subs(x, r);
+            const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);
+            const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);
+            tacc = (int)(((uint32_t)tacc >> 4) | (nib & 0xF000F000u));
+            if ((j & 3) == 3) {
+                if (store) tout[(j >> 2) * (QUAD_B / 2) + l] = (uint32_t)tacc;
+                tacc = 0;
+            }
+        }
         dmax = vmax(dmax, dn);
         dcol[j] = dn;
         d = dn; c = cn;
@@ -107,7 +119,7 @@ __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& f
     }
 }
 
-template <int KIND, bool XDROP>
+template <int KIND, bool TRACE, bool XDROP>
 __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), l = lane & 15, g = lane >> 4;
@@ -158,6 +170,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     // sequence bytes of the next step, fetched one step ahead for both possible directions (a pair's steps are a dependent
     // chain: without this every step of the batch's longest pair waits a memory round trip)
     int pf_qv = 0, pf_rv = 0; uint2 pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
+    // TRACE: the pair's trace stack (its own region of the arenas) and the stack heights of the checkpoint
+    uint32_t trace_top = 0, nblocks = 0, ck_tt = 0, ck_nb = 0, tcap = 0, bcap = 0;
+    uint32_t* tr = bp.trace_arena; BlockRec* bl = bp.blocks;
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter (wave-uniform)
     bool more = true;
 
@@ -188,6 +203,12 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
                 ck0 = (int)c->ckpt[0][l]; ck1 = (int)c->ckpt[1][l]; ck2 = (int)c->ckpt[2][l]; ck3 = (int)c->ckpt[3][l];
                 qp = bp.pool + bp.q_off[pair]; rp = bp.pool + bp.r_off[pair];
                 qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
+                if (TRACE) {
+                    trace_top = c->trace_top; nblocks = c->nblocks; ck_tt = c->ck_trace_top; ck_nb = c->ck_nblocks;
+                    const uint64_t t0 = bp.trace_off[pair], b0 = bp.blocks_off[pair];
+                    tr = bp.trace_arena + t0; bl = bp.blocks + b0;
+                    tcap = (uint32_t)min(bp.trace_off[pair + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[pair + 1] - b0, (uint64_t)0x7fffffffu);
+                }
                 pf_ok = false;
             }
             idle = pair == ~0u;
@@ -199,7 +220,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (QUAD_B - STEP);
         const uint32_t lenV = right ? qlen : rlen;
         // a step that could break early at the matrix edge (never with X-drop) is not ours: leave before it
-        const bool elig = XDROP || ri + QUAD_B <= lenV;
+        bool elig = XDROP || ri + QUAD_B <= lenV;
+        if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * QUAD_B / 8) + 64 <= tcap;   // (a step that would not fit is the per-pair kernel's to report)
         bool leave = !idle && (!elig || budget <= 1);
         const bool run = !idle && !leave;
         const int off_n = off_max;
@@ -223,7 +245,14 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         int Ad = right ? Dcol : Drow, Ac = right ? Ccol : Rrow, Pd = right ? Drow : Dcol, Pr = right ? Rrow : Ccol;
         QuadOut o;
         const int loc_thr = best_max - off_n + ZERO;
-        quad_rect<KIND, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add, run ? loc_thr : 0x7fffffff, o);
+        if (TRACE && run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
+            BlockRec br;
+            br.i = right ? ri : rj; br.j = right ? rj : ri; br.h = (uint16_t)(right ? QUAD_B : STEP); br.w = (uint16_t)(right ? STEP : QUAD_B);
+            br.trace_base = trace_top | (right ? 0x80000000u : 0u);
+            bl[nblocks] = br;
+        }
+        quad_rect<KIND, TRACE, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add, run ? loc_thr : 0x7fffffff,
+                                      tr + trace_top, run, o);
 
         // ---- what does the step call for? (scan_block.rs:332-558; nothing is committed yet)
         const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
@@ -246,6 +275,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
                     c->pair = pair; c->si = si; c->sj = sj; c->dir = dir; c->prev_dir = prev_dir; c->off = off; c->off_max = off_max; c->best_max = best_max;
                     c->y_drop_iter = y_drop; c->x_drop_iter = x_iter; c->D_corner = D_corner; c->best_i = best_i; c->best_j = best_j;
                     c->ck_i = ck_i; c->ck_j = ck_j; c->ck_off = ck_off; c->cells = cells0 + (unsigned long long)nsteps * (STEP * QUAD_B); c->step_budget = budget;
+                    if (TRACE) { c->trace_top = trace_top; c->nblocks = nblocks; c->ck_trace_top = ck_tt; c->ck_nblocks = ck_nb; c->status = 0; }
                 }
                 c->borders[0][l] = (uint32_t)Dcol; c->borders[1][l] = (uint32_t)Ccol; c->borders[2][l] = (uint32_t)Drow; c->borders[3][l] = (uint32_t)Rrow;
                 c->ckpt[0][l] = (uint32_t)ck0; c->ckpt[1][l] = (uint32_t)ck1; c->ckpt[2][l] = (uint32_t)ck2; c->ckpt[3][l] = (uint32_t)ck3;
@@ -257,12 +287,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             Dcol = right ? Ad : Pd; Ccol = right ? Ac : Pr; Drow = right ? Pd : Ad; Rrow = right ? Pr : Ac;
             off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = dir; D_corner = o.corner_new;
             nsteps++; budget--;
+            if (TRACE) { trace_top += STEP * QUAD_B / 8; nblocks++; }
             if (improve) {
                 if (XDROP) {   // scan_block.rs:370-404
                     best_i = right ? si + (uint32_t)o.row : si + (QUAD_B - STEP) + (uint32_t)o.col;
                     best_j = right ? sj + (QUAD_B - STEP) + (uint32_t)o.col : sj + (uint32_t)o.row;
                 }
-                if (QUAD_B < max_size) { ck_i = si; ck_j = sj; ck_off = off; ck0 = Dcol; ck1 = Ccol; ck2 = Drow; ck3 = Rrow; }
+                if (QUAD_B < max_size) {
+                    ck_i = si; ck_j = sj; ck_off = off; ck0 = Dcol; ck1 = Ccol; ck2 = Drow; ck3 = Rrow;
+                    if (TRACE) { ck_tt = trace_top; ck_nb = nblocks; }
+                }
                 best_max = off_max;
             }
             if (XDROP) x_iter = (off_max < best_max - x_drop) ? x_iter + 1 : 0;

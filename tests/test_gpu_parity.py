@@ -614,13 +614,14 @@ def test_percent_len_sizes_are_accepted(hip, oracle):
 
 
 @pytest.mark.parametrize("skip_quad", ["1", ""])
-@pytest.mark.parametrize("mode", [("x_drop",), ()])
+@pytest.mark.parametrize("mode", [("x_drop",), (), ("trace", "x_drop"), ("trace",)])
 def test_small_block_pipeline(hip, oracle, monkeypatch, mode, skip_quad):
-    """Score-only batches that start at 32 cells run in three passes: the per-pair kernel up to each pair's first plain shift
+    """Batches that start at 32 cells run in three passes: the per-pair kernel up to each pair's first plain shift
     step, k_quad (four pairs per wave, one per 16-lane DPP row) through the plain shift steps, the per-pair kernel again for
-    whatever else a pair needs (grow, termination, matrix edge); pairs travel between the passes as PairCont records. Forced on
-    small batches here; BA_QUAD_SKIP = 1 runs passes 1 and 3 alone (the record plumbing without k_quad). DNA, protein and byte
-    pairs, with growth (indels), tiny and empty sequences."""
+    whatever else a pair needs (grow, termination, matrix edge); pairs travel between the passes as PairCont records. With
+    TRACE every pair stacks its trace words and rectangle records in its own region of the arenas across the three passes and a
+    fourth kernel (k_walk) walks all paths, one pair per lane. Forced on small batches here; BA_QUAD_SKIP = 1 runs passes 1 and
+    3 alone (the record plumbing without k_quad). DNA, protein and byte pairs, with growth (indels), tiny and empty sequences."""
     monkeypatch.setenv("BA_FORCE_QUAD", "1")
     if skip_quad:
         monkeypatch.setenv("BA_QUAD_SKIP", "1")
@@ -635,6 +636,35 @@ def test_small_block_pipeline(hip, oracle, monkeypatch, mode, skip_quad):
     edge = synth.PairSet.from_lists([(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A" * 40, b"A" * 40), (b"ACGT" * 30, b"ACGT" * 30 + b"TTTT" * 20),
                                      (b"A" * 33, b"T" * 300), (b"ACGTNNNNACGT" * 5, b"ACGTACGT" * 6)] * 8)
     compare(hip, oracle, edge, S.NW1, (-2, -1), (32, 128), 20, mode)
+
+
+@pytest.mark.parametrize("margin", ["3", "60"])
+def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, monkeypatch, margin):
+    """The TRACE form of the small-block pipeline cuts the trace arena into one region per pair, sized for the pair's expected
+    stack; a pair that outgrows its region leaves k_quad, reports BA_ST_TRACE_OVERFLOW from the per-pair kernel and is re-run
+    with the reference's full bound inside the same ba_batch_run. Artificially small margins here; then the same batch object
+    is reloaded with other pairs (the regions are cut again inside the existing arenas)."""
+    monkeypatch.setenv("BA_FORCE_QUAD", "1")
+    monkeypatch.setenv("BA_TRACE_MARGIN_PCT", margin)
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    sets = [synth.make_pairs(500 - 60 * k, (300, 2500), (30, 250), 60, synth.DNA, seed=131 + k, indels=3, indel_len=(30, 300)) for k in range(2)]
+    b = hip.BatchAligner(NUC, (-5, -1), (32, 512), 80, mode, sets[0].pool, sets[0].q_off, sets[0].q_len, sets[0].r_off, sets[0].r_len)
+    for k, pairs in enumerate(sets):
+        if k:
+            b.reload(pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+        b.run()
+        res = b.results()
+        assert not res["status"].any()
+        assert b.retried() > 0 if margin == "3" else b.retried() >= 0
+        ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 512), 80, ("trace", "x_drop"), cigar_eq=True, threads=8)
+        assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["query_idx"], ref["query_idx"]) and np.array_equal(res["reference_idx"], ref["reference_idx"])
+        assert np.array_equal(res["cigar_len"], ref["cig_len"]) and int(res["cells"].sum()) == ref["cells"]
+        runs, off = b.cigars(res["cigar_len"])
+        for p in range(len(pairs)):
+            want = ref["cig_ops"][int(ref["cig_off"][p]): int(ref["cig_off"][p]) + int(ref["cig_len"][p])]
+            assert np.array_equal(runs[int(off[p]): int(off[p + 1])], want), (margin, k, p)
+        assert int(b.surviving_cells().sum()) > 0
+    b.close()
 
 
 @pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
