@@ -198,6 +198,10 @@ __device__ __forceinline__ void tb_fail(TbLane& t) { t.status |= ST_TRACEBACK_LO
 // what a walk costs the fill waves it shares a SIMD with: measured at config 3, 12 cells per call 1142 GCUPS, 8: 1145,
 // 6: 1154, 4: 1156, 3: 1154 (more calls per walk, each much shorter).
 constexpr int TB_CELLS_PER_STEP = 4;
+#ifndef BA_WALK_CELLS
+#define BA_WALK_CELLS 8
+#endif
+template <int CELLS = TB_CELLS_PER_STEP>
 __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned char* lrec,
                                         const unsigned char* lut, unsigned long long* tacc = nullptr) {
     const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
@@ -273,7 +277,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         // lane still walks in this call; a lane that is not alive computes on clamped indices and commits nothing.
         bool alive = true;
 #pragma unroll
-        for (int s = 0; s < TB_CELLS_PER_STEP; s++) {
+        for (int s = 0; s < CELLS; s++) {
             alive = alive && (t.i > 0 || t.j > 0) && t.i >= t.bi && t.j >= t.bj;
             const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
             const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
@@ -309,7 +313,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         }
         return;
     }
-    for (int s = 0; s < TB_CELLS_PER_STEP; s++) {
+    for (int s = 0; s < CELLS; s++) {
         if (!(t.i > 0 || t.j > 0) || !(t.i >= t.bi && t.j >= t.bj)) break;
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
         const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
@@ -469,15 +473,23 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     lds_sync();
     TbLane t{};
     bool walking = false, more = true;
+    uint32_t w_next = 0, w_end = 0;   // this wave's share of the batch order: 64 pairs per atomic (a returning atomic is a full memory
+                                      // round trip that every lane of the wave waits for: one per finished lane would double the walk time)
     for (;;) {
-        if (more && !__all(walking)) {
+        if (!__all(walking) && (more || w_next != w_end)) {
+            if (w_next == w_end) {
+                uint32_t base = 0;
+                if (is_lane(0)) base = atomicAdd(bp.work_counter, 64u);
+                base = (uint32_t)uni((int)base);
+                if (base >= bp.n) { more = false; base = 0; w_next = w_end = 0; }
+                else { w_next = base; w_end = min(base + 64u, bp.n); }
+            }
             const unsigned long long im = __ballot(!walking);
-            uint32_t base = 0;
-            if (is_lane(0)) base = atomicAdd(bp.work_counter, (uint32_t)__popcll(im));
-            base = (uint32_t)uni((int)base);
-            if (base + (uint32_t)__popcll(im) >= bp.n) more = false;
-            const uint32_t p = base + (uint32_t)__popcll(im & ((1ull << lane_id()) - 1ull));
-            if (!walking && p < bp.n) {
+            const uint32_t rank = (uint32_t)__popcll(im & ((1ull << lane_id()) - 1ull));
+            const uint32_t take = min((uint32_t)__popcll(im), w_end - w_next);
+            const uint32_t p = w_next + rank;
+            w_next += take;
+            if (!walking && rank < take) {
                 const SlotInfo si = bp.slot_info[p];
                 t = TbLane{};
                 t.qw0 = t.rw0 = 0xffffffffu; t.tw_ok = false;
@@ -493,7 +505,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
         }
         if (!__any(walking)) break;
         if (walking) {
-            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut);
+            if (t.i > 0 || t.j > 0) tb_step<BA_WALK_CELLS>(t, eq, bp.cig_ops, lrec, lut);   // (no fill wave shares the SIMD here: a call walks on while its window lasts)
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
                 bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
@@ -561,7 +573,10 @@ struct Aligner {
 
     // A shift step is taken by the register path unless its columns could break early at the end of the matrix
     // (scan_block.rs:1216-1224; never with X-drop): those go through place_rect, which implements the break.
-    __device__ __forceinline__ static bool fast_eligible(uint32_t ri, uint32_t B, uint32_t lenV) { return XDROP || ri + B <= lenV; }
+    // (the break needs both: vectors that reach past the end of their sequence and a column at or past the end of the other)
+    __device__ __forceinline__ static bool fast_eligible(uint32_t ri, uint32_t B, uint32_t lenV, uint32_t rj, uint32_t lenC) {
+        return XDROP || ri + B <= lenV || rj + STEP <= lenC;
+    }
 
     enum { RUN_EXIT_POST = 0, RUN_EXIT_TOP = 1, RUN_EXIT_FATAL = 2 };
     // A run of plain shift steps of a single-chunk block, borders in registers (see fast_rect). Entered with the first step
@@ -661,7 +676,7 @@ struct Aligner {
             dir = go_down ? DIR_DOWN : DIR_RIGHT;
 
             // ---- set up the next step (what the top of the driver loop does)
-            if (!fast_eligible(dir == DIR_RIGHT ? si : sj, B, dir == DIR_RIGHT ? qlen : rlen)) { run_exit = RUN_EXIT_TOP; break; }
+            if (!fast_eligible(dir == DIR_RIGHT ? si : sj, B, dir == DIR_RIGHT ? qlen : rlen, (dir == DIR_RIGHT ? sj : si) + B - STEP, dir == DIR_RIGHT ? rlen : qlen)) { run_exit = RUN_EXIT_TOP; break; }
             if (--step_budget == 0) { status |= ST_WATCHDOG; run_exit = RUN_EXIT_FATAL; break; }
 #ifdef BA_TIMING
             prof[16]++;
@@ -802,34 +817,9 @@ struct Aligner {
         }
     }
 
-    // Write this pair's loop-top state as a PairCont record (block of 32 cells: 16 lanes hold each border).
-    __device__ __forceinline__ void suspend(uint32_t pair, uint32_t si, uint32_t sj, int dir, int prev_dir, int off, int off_max, int best_max,
-                                            uint32_t y_drop_iter, int x_drop_iter, int D_corner, uint32_t step_budget) {
-        PairCont* c = coldp()->cont_out + pair;
-        const int lane = lane_id();
-        lds_sync();
-        if (is_lane(0)) {
-            coldp()->cont_out_flag[pair] = 1u;
-            c->pair = pair; c->si = si; c->sj = sj; c->dir = dir; c->prev_dir = prev_dir; c->off = off; c->off_max = off_max; c->best_max = best_max;
-            c->y_drop_iter = y_drop_iter; c->x_drop_iter = x_drop_iter; c->D_corner = D_corner;
-            c->best_i = (uint32_t)unpark<5>(parked); c->best_j = (uint32_t)unpark<6>(parked);
-            c->ck_i = (uint32_t)unpark<0>(parked); c->ck_j = (uint32_t)unpark<1>(parked); c->ck_off = unpark<2>(parked);
-            c->cells = cells; c->step_budget = step_budget;
-            if (TRACE) { c->trace_top = trace_top; c->nblocks = nblocks; c->ck_trace_top = (uint32_t)unpark<3>(parked); c->ck_nblocks = (uint32_t)unpark<4>(parked); c->status = status; }
-        }
-        if (lane < 16) {
-            c->borders[0][lane] = (uint32_t)*(const int*)(L.D_col + 2 * lane); c->borders[1][lane] = (uint32_t)*(const int*)(L.C_col + 2 * lane);
-            c->borders[2][lane] = (uint32_t)*(const int*)(L.D_row + 2 * lane); c->borders[3][lane] = (uint32_t)*(const int*)(L.R_row + 2 * lane);
-            if (ck_in_regs) { for (int k = 0; k < 4; k++) c->ckpt[k][lane] = (uint32_t)ck_reg[k]; }
-            else {   // (this wave's own checkpoint stores, read back past the L1: see restore_ckpt_borders)
-                const uint32_t ms = h_max_size;
-                for (int k = 0; k < 4; k++) c->ckpt[k][lane] = (uint32_t)ckpt_load(ckpt + k * ms + 2 * lane);
-            }
-        }
-    }
-
     // (always inlined: as a real call the Aligner object and everything it references would live in scratch memory)
     __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr) {
+        BA_TSTAMP(tq0);
         q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
         qlen = coldp()->q_len[pair_in]; rlen = coldp()->r_len[pair_in];
         const uint32_t min_size = coldp()->min_size, max_size = h_max_size;
@@ -908,6 +898,7 @@ struct Aligner {
             y_drop_iter = 0; pf_ok = false;
         };
         BA_TSTAMP(tr0);
+        BA_TADD(prof, 47, tq0, tr0);
         for (;;) {
             BA_TSTAMP(ts0);
             // ---- set up the next rectangle (one fill call site for all four kinds of rectangle)
@@ -943,15 +934,8 @@ struct Aligner {
             }
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
             BA_TSTAMP(tsa);
-            const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV);
+            const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
-            if (fast && block_size == 32 && coldp()->cont_mode == 1) {
-                // small-block batch, first pass: the pair leaves for the 4-pairs-per-wave kernel at its first register-path step.
-                // What is written is the state the top of this loop would start the step from (the set-up above is undone).
-                step_budget++; off = prev_off;
-                suspend(pair_in, si, sj, dir, prev_dir, off, off_max, best_max, y_drop_iter, x_drop_iter, D_corner, step_budget);
-                return;
-            }
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
             const bool spec = TRACE && chain && dir == DIR_GROW;   // this grow step runs without trace flags and location bookkeeping
@@ -1161,7 +1145,6 @@ struct Aligner {
         BA_TADD(prof, 15, tr0, tr1);
 #ifdef BA_TIMING
         prof[16] += steps;
-        if (coldp()->prof && is_lane(0)) for (int k = 0; k < 48; k++) if (k != 17 && !(k >= 20 && k < 32)) atomicAdd(coldp()->prof + k, prof[k]);
 #endif
         const uint32_t pair = (uint32_t)unpark<7>(parked), slot = (uint32_t)unpark<8>(parked);
         int score; uint32_t ri, rj;
@@ -1283,6 +1266,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
         uint32_t turn = 0;
         uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter: bp.work_chunk pairs per atomic
         for (;;) {
+            BA_TSTAMP(tk0);
             if (w_next == w_end) {
                 uint32_t v = 0;
                 if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
@@ -1292,9 +1276,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             }
             uint32_t pair = w_next++;
             const PairCont* rec = nullptr;
-            if (bp.cont_mode == 2) {   // only the pairs the small-block kernel left a record for are still in flight
-                if (!bp.cont_in_flag[pair]) continue;
-                rec = bp.cont_in + pair;
+            if (bp.cont_mode == 2) {   // after the small-block kernel: flag 1 = a record to resume from, 2 = still to be run from scratch, 0 = done
+                const uint32_t f = bp.cont_in_flag[pair];
+                if (!f) continue;
+                if (f == 1) rec = bp.cont_in + pair;
             }
             uint32_t slot = fill_wave * bp.slots_per_wave + turn;
             if (++turn == bp.slots_per_wave) turn = 0;
@@ -1324,7 +1309,15 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                 L.D_col = bw; L.C_col = bw + as; L.D_row = bw + 2 * as; L.R_row = bw + 3 * as;
                 al.big_top = bw + 4 * as;
             }
+            BA_TSTAMP(tk1);
             al.run(pair, slot, batch_traceback, rec);
+#ifdef BA_TIMING
+            {   // development: 44 = pair taken -> run() entered, 45 = run(), 46 = pairs, 47 = run() before its step loop
+                const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+                al.prof[44] += tk1 - tk0; al.prof[45] += tk2 - tk1; al.prof[46] += 1;
+                if (bp.prof && is_lane(0)) for (int k = 0; k < 48; k++) if (k != 17 && !(k >= 20 && k < 32) && !(k >= 40 && k < 44)) atomicAdd(bp.prof + k, al.prof[k]);
+            }
+#endif
         }
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());

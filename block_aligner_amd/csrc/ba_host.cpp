@@ -55,7 +55,8 @@ typedef hipError_t (*QuadFn)(int, int, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k0(int, int, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k1(int, int, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k2(int, int, hipStream_t, const BatchParams*);
-static const QuadFn g_launch_quad[3] = {ba_launch_quad_k0, ba_launch_quad_k1, ba_launch_quad_k2};
+extern "C" hipError_t ba_launch_quad_k3(int, int, hipStream_t, const BatchParams*);
+static const QuadFn g_launch_quad[4] = {ba_launch_quad_k0, ba_launch_quad_k1, ba_launch_quad_k2, ba_launch_quad_k3};
 static const LaunchFn g_launch_big[4] = {ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32};
 static const OccFn g_occ_big[4] = {ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32};
 constexpr int BA_PCLASS_BIG = 5;
@@ -201,7 +202,7 @@ struct BaBatch {
     bool ran = false, in_flight = false;
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
-    DevBuf contA, contB, cont_n;   // PairCont lists between the three launches of such a batch, and their counters
+    DevBuf contA, cont_n;       // the PairCont records between the two fill launches of such a batch, and their flags
     // pair-slot batch (a small-block batch with TRACE): every pair owns a region of the trace / record arenas for the whole
     // batch (offsets below, n + 1 entries each), the fill kernels only stack, and k_walk does all tracebacks at the end
     bool pipe = false;
@@ -576,7 +577,7 @@ static int batch_alloc_scratch(BaBatch* b) {
     BA_ALLOC(blocks, b->pipe ? b->pipe_recs * sizeof(BlockRec) : b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
     BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short) : 0);
-    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 512); BA_ALLOC(params_dev, sizeof(BatchParams));
+    BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
 #undef BA_ALLOC
     return 0;
@@ -655,14 +656,21 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // (Measured, score only: 1 kbp DNA at ~90 % identity, 200k pairs: 606 -> 1353 GCUPS. Protein pairs at 30..100 % identity leave
     // k_quad at their first grow and the two extra passes each bring a launch tail: 100k pairs 540 -> 485, 200k 589 -> 725,
     // 800k 597 -> 983. Hence amino-acid batches take the pipeline from 131072 pairs on; BA_FORCE_QUAD / BA_NO_QUAD override.)
-    b->quad = !profile && !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
+    b->quad = !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
               (getenv("BA_FORCE_QUAD") || n >= (kind == BA_KIND_AA ? 131072u : 2048u));
+    // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
+    // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
+    // blocks take it in place of the hand-off ring (50..500 positions, 20k pairs: 143 -> 158 GCUPS, 80k: 172 -> 225). Short
+    // sequence pairs do not: their walks are few hundred steps, cheapest done at once by the fill wave's lane 0 (protein pairs,
+    // 8k..65k pairs: 3 .. 20 % slower with k_walk, whose latest wave ends one longest-path walk after the fill).
     std::vector<uint64_t> toff, boff;
-    if (b->quad && trace) {   // with TRACE the pipeline needs every pair's trace stack resident until the end
-        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * (64 + 2 * sizeof(ba::PairCont) + 40);
-        if (getenv("BA_NO_TRACE_QUAD") || pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) b->quad = false;
-        else { b->pipe = true; b->pipe_words = toff[n] + toff[n] / 8; b->pipe_recs = boff[n] + boff[n] / 8; }   // (headroom for ba_batch_reload)
+    if (trace && !special_of(mode) && pc != BA_PCLASS_BIG && (b->quad || (profile && n >= 4096) || getenv("BA_FORCE_PIPE"))) {
+        const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * (64 + sizeof(ba::PairCont) + 40);
+        if (!getenv("BA_NO_PIPE") && !pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) {
+            b->pipe = true; b->pipe_words = toff[n] + toff[n] / 8; b->pipe_recs = boff[n] + boff[n] / 8;   // (headroom for ba_batch_reload)
+        }
     }
+    if (trace && !b->pipe) b->quad = false;   // with TRACE the pipeline needs every pair's trace stack resident until the end
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
     if (b->pipe) b->adaptive = true;
     b->cig_total = trace ? cig_total : 0;
@@ -677,7 +685,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     BA_ALLOC(cig_ops, b->cig_total * 4);
 #undef BA_ALLOC
     if (batch_alloc_scratch(b.get())) return nullptr;
-    if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->contB.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(2 * n * 4))) return nullptr;
+    if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(n * 4))) return nullptr;
     if (b->pipe && (b->trace_off.alloc((n + 1) * 8) || b->blocks_off.alloc((n + 1) * 8))) return nullptr;
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
@@ -735,6 +743,11 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
 
 // Enqueue one pass over the batch on its stream and return; batch_wait collects it. (Two batches on two streams
 // overlap; with ba_batch_reload the host packs the next set while the device aligns the current one.)
+static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves x 64 walking lanes each)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) return 1;
+    return std::min((b->n + 255u) / 256u, (uint32_t)prop.multiProcessorCount * 8u);
+}
 static int batch_launch(BaBatch* b) {
     if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");
     if (b->n == 0) return fail("the batch holds no pairs (its last reload failed)");
@@ -742,7 +755,7 @@ static int batch_launch(BaBatch* b) {
     if (!b->handle_mode) {   // (a handle's work counter arrives zeroed with its upload; it has no hand-off structures)
         HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
-        HIP_TRY(hipMemsetAsync(b->prof.p, 0, 512, b->stream));
+        HIP_TRY(hipMemsetAsync(b->prof.p, 0, 2048, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
         HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
     }
@@ -750,35 +763,32 @@ static int batch_launch(BaBatch* b) {
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : g_launch[special_of(b->mode)][b->kind][b->pclass];
     if (b->quad && b->n <= b->cap_n) {
-        // pass 1 (per-pair kernel): every pair up to its first register-path step at 32 cells -> list A;
-        // pass 2 (k_quad): plain shift steps, four pairs per wave, until a pair needs anything else -> list B;
-        // pass 3 (per-pair kernel): the pairs of list B to their end.
-        uint32_t* flagA = b->cont_n.as<uint32_t>(); uint32_t* flagB = flagA + b->cap_n;
-        HIP_TRY(hipMemsetAsync(flagA, 0, 2 * b->cap_n * 4, b->stream));
-        // TRACE (a pair-slot batch): the three fill launches only stack trace words and records in the pairs' regions;
-        // pass 4 (k_walk) walks every pair's path, one pair per lane.
+        // pass 1 (k_quad): every pair's first block and plain shift steps, four pairs per wave, until the pair needs anything
+        //                  else (a grow, termination, the early column break at the matrix edge) -> a record in the list;
+        // pass 2 (per-pair kernel): the pairs of the list to their end (and those k_quad could not start, from scratch).
+        // TRACE (a pair-slot batch): both fill launches only stack trace words and records in the pairs' regions;
+        // pass 3 (k_walk) walks every pair's path, one pair per lane.
         const int tr = (b->mode & BA_TRACE) ? 1 : 0;
-        BatchParams p1 = bp; p1.cont_mode = 1; p1.cont_out = b->contA.as<ba::PairCont>(); p1.cont_out_flag = flagA;
-        if (tr) p1.cig_ops = nullptr;
-        HIP_TRY(launch(tr, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
+        uint32_t* flagA = b->cont_n.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(flagA, 0, b->cap_n * 4, b->stream));
+        BatchParams p2 = bp; p2.cont_out = b->contA.as<ba::PairCont>(); p2.cont_out_flag = flagA;
+        p2.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
+        HIP_TRY(g_launch_quad[b->kind](tr, (b->mode & BA_X_DROP) != 0, b->stream, &p2));
         const ba::PairCont* last = b->contA.as<ba::PairCont>(); const uint32_t* last_flag = flagA;
-        if (!getenv("BA_QUAD_SKIP")) {   // (development switch: passes 1 and 3 only)
-            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
-            BatchParams p2 = bp; p2.cont_in = last; p2.cont_in_flag = last_flag; p2.cont_out = b->contB.as<ba::PairCont>(); p2.cont_out_flag = flagB;
-            p2.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
-            HIP_TRY(g_launch_quad[b->kind](tr, (b->mode & BA_X_DROP) != 0, b->stream, &p2));
-            last = b->contB.as<ba::PairCont>(); last_flag = flagB;
-        }
         HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
         BatchParams p3 = bp; p3.cont_mode = 2; p3.cont_in = last; p3.cont_in_flag = last_flag;
         if (tr) p3.cig_ops = nullptr;
         HIP_TRY(launch(tr, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p3));
         if (tr && bp.cig_ops) {
             HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, b->device));
-            const uint32_t need = (b->n + 255u) / 256u, full = (uint32_t)prop.multiProcessorCount * 8u;
-            HIP_TRY(ba_launch_walk(b->stream, &bp, std::min(need, full)));
+            HIP_TRY(ba_launch_walk(b->stream, &bp, walk_grid(b)));
+        }
+    } else if (b->pipe) {   // pair-slot batch: the fill stacks, k_walk walks
+        BatchParams p1 = bp; p1.cig_ops = nullptr;
+        HIP_TRY(launch(1, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
+        if (bp.cig_ops) {
+            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+            HIP_TRY(ba_launch_walk(b->stream, &bp, walk_grid(b)));
         }
     } else
     HIP_TRY(launch((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &bp));
@@ -980,9 +990,9 @@ int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
     HIP_TRY(hipMemcpy(runs, d_out.p, total * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-int ba_batch_prof(BaBatch* b, uint64_t out[64]) {   // development: phase timers of a -DBA_TIMING build
+int ba_batch_prof(BaBatch* b, uint64_t out[128]) {   // development: phase timers of a -DBA_TIMING build (second half: pass 3 of a small-block batch)
     if (!b) return fail("null batch");
-    HIP_TRY(hipMemcpy(out, b->prof.p, 512, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, b->prof.p, 1024, hipMemcpyDeviceToHost));
     return 0;
 }
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {
@@ -1367,7 +1377,7 @@ static int handle_prepare(BlockImpl* h) {
     if (b->hblk.alloc(b->cap_pool) || b->rblk.alloc(sizeof(HandleResult)) || b->matrix.alloc(1024) || b->cig_ops.alloc((trace ? b->cap_cig : 1) * 4) ||
         b->trace.alloc(b->trace_stride * 4) || b->blocks.alloc(b->blocks_stride * sizeof(BlockRec)) ||
         b->ckpt.alloc((size_t)ba::WAVES_PER_WG * 8 * max_size * sizeof(short)) ||
-        b->big.alloc(max_size > 2048 ? (size_t)ba::WAVES_PER_WG * ba::big_wave_shorts((uint32_t)max_size) * sizeof(short) : 0) || b->prof.alloc(512) || b->tb_ctrl.alloc(256) ||
+        b->big.alloc(max_size > 2048 ? (size_t)ba::WAVES_PER_WG * ba::big_wave_shorts((uint32_t)max_size) * sizeof(short) : 0) || b->prof.alloc(2048) || b->tb_ctrl.alloc(256) ||
         b->tb_queue.alloc(4) || b->slot_free.alloc(4) || b->slot_info.alloc(sizeof(ba::SlotInfo))) return 1;
     uint8_t* hb = b->hblk.as<uint8_t>(); uint8_t* rb = b->rblk.as<uint8_t>();
     b->pool.view(hb, b->cap_pool);   // the images' offsets are relative to the start of hblk

@@ -54,8 +54,8 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
     return xdrop ? occ1<false, true>(blocks_per_cu, lds) : occ1<false, false>(blocks_per_cu, lds);
 }
 
-#if BA_KIND != 3 && BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
-// four pairs per wave while the block is 32 cells (ba_quad.hpp): one kernel per sequence kind
+#if BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
+// four pairs per wave while the block is 32 cells (ba_quad.hpp): one kernel per kind
 #include "ba_quad.hpp"
 template <bool TRACE, bool XDROP>
 static hipError_t launch_quad(hipStream_t s, const ba::BatchParams& bp) {

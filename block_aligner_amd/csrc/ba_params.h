@@ -85,9 +85,10 @@ struct BatchParams {
     uint32_t* tb_ctrl;           // [0] tail (next entry to produce), [32] head (next entry to claim); separate cache lines
     uint32_t* slot_free;         // per slot: 1 = free, 0 = owned by a fill wave or a pending traceback
     SlotInfo* slot_info;         // per slot: what the traceback lane needs
-    // small-block batches (score only, min block 32): pairs move between kernels as PairCont records
-    uint32_t cont_mode;          // 0 plain; 1 suspend every pair at its first register-path step (-> cont_out); 2 resume from cont_in
-    // records are indexed by the pair's position in the batch; flag[p] != 0: pair p has a record (it is still in flight)
+    // small-block batches (min block 32): k_quad starts every pair and runs its plain shift steps at 32 cells; a pair that needs
+    // anything else leaves as a PairCont record (cont_out, indexed by the pair's position in the batch; cont_out_flag[p] = 1), a
+    // pair k_quad cannot start gets flag 2, a finished one stays 0. The per-pair kernel then runs with cont_mode = 2 over cont_in.
+    uint32_t cont_mode;          // 0 plain; 2 resume from cont_in / run flagged pairs from scratch
     const PairCont* cont_in; const uint32_t* cont_in_flag;
     PairCont* cont_out; uint32_t* cont_out_flag;
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)

@@ -6,12 +6,13 @@
 // DPP row ("slot"): row_shr DPP stays inside a row, so the column code of fast_rect carries over lane for lane; what is
 // wave-uniform there (offsets, direction, column bytes, the whole driver state) is row-uniform here and lives in VGPRs,
 // replicated across the slot's 16 lanes, and the driver decisions of scan_block.rs:332-558 are evaluated for all four slots at
-// once with vector compares and selects. A slot only ever executes PLAIN shift steps at 32 cells: whatever else a pair needs
-// (its first block, a grow, termination, the early column break at the matrix edge) is done by the per-pair kernel, before
-// and after: pairs arrive and leave as PairCont records (ba_params.h) holding the driver's state at the top of its loop.
-// A step whose outcome calls for anything but another shift is rolled back and the pair leaves with its pre-step state.
-// Sequence-sequence kinds. TRACE batches are pair-slot batches (ba_params.h): a pair's trace words and rectangle records go to
-// the pair's own region, which the per-pair kernel continues and k_walk reads after the last fill kernel.
+// once with vector compares and selects. A slot executes a pair's first block and then only PLAIN shift steps at 32 cells:
+// whatever else the pair needs (a grow, termination, the early column break at the matrix edge) is done by the per-pair kernel
+// afterwards: a pair leaves as a PairCont record (ba_params.h) holding the driver's state at the top of its loop; a step whose
+// outcome calls for anything but another shift is rolled back and the pair leaves with its pre-step state.
+// All four kinds (sequence-to-profile steps: QuadProfile below). TRACE batches are pair-slot batches (ba_params.h): a pair's
+// trace words and rectangle records go to the pair's own region, which the per-pair kernel continues and k_walk reads after
+// the last fill kernel.
 #pragma once
 #include "ba_driver.hpp"
 
@@ -34,11 +35,25 @@ __device__ __forceinline__ int sat16(int x) { return x < -32768 ? -32768 : (x > 
 
 struct QuadOut { int mx, row, col, act_max8, pas_max8, corner_new; };
 
+// Sequence-to-profile steps (place_block_profile_*, scan_block.rs:612-783). A slot's step runs along the query ("right": one
+// profile position per column, costs uniform in a column) or along the profile ("down": one query residue per column, costs per
+// row), and the four slots of a wave differ: every per-column operand is picked by v_perm with a per-lane selector, from the
+// column-packed registers (right) or from the lane's own pair (down).
+struct QuadProfile {
+    int A[4], B[4];                 // right: the 8 columns' scores of this lane's residues a / b (aa_pos rows); down: columns 2m / 2m + 1
+    int selE, selO;                 // score selectors for even / odd columns
+    int pgoC[4], pclC[4], pgoR[4];  // right: gap_open_C + extend, gap_close_C, gap_open_R of the 8 columns (packed); down: unused
+    int vgoC, vgoR, vclR;           // down: gap_open_R + extend, gap_open_C, gap_close_C of this lane's two rows (swapped roles,
+                                    // scan_block.rs:671-682); right: unused (vclR = 0)
+    int gselE, gselO;               // cost selectors: right = splat the even / odd half of the packed register, down = the lane's pair
+};
+
 // One 8-column shift step for the four slots of a wave (fast_rect with row-uniform operands in VGPRs).
 template <int KIND, bool TRACE, bool XDROP>
 __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& fc, int l, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
                                           int vec_a, int vec_b, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, int loc_thr,
-                                          uint32_t* __restrict__ tout, bool store, QuadOut& o) {
+                                          uint32_t* __restrict__ tout, bool store, bool first_cell, QuadOut& o, const QuadProfile* pq = nullptr) {
+    constexpr bool PROF = KIND == KIND_PROFILE;
     const int offa = splat(off_add);
     int d = adds(Ad, offa), c = adds(Ac, offa);
     const int pd = adds(Pd, offa), pr = adds(Pr, offa);
@@ -51,24 +66,37 @@ __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& f
     short* last_base = l == 15 ? Pl + QUAD_B : sink;
 #pragma unroll
     for (int j = 0; j < STEP; j++) {
-        const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
-        const int sc = fetch_score<KIND>(table, key, cb);
+        int sc, goC = fc.go2, goR = fc.ome2, clC = 0;
+        if constexpr (PROF) {
+            const int m = j >> 1;
+            sc = __builtin_amdgcn_perm(pq->B[m], pq->A[m], (j & 1) ? pq->selO : pq->selE);
+            const int gsel = (j & 1) ? pq->gselO : pq->gselE;
+            goC = __builtin_amdgcn_perm(pq->pgoC[m], pq->vgoC, gsel);
+            goR = __builtin_amdgcn_perm(pq->pgoR[m], pq->vgoR, gsel);
+            clC = __builtin_amdgcn_perm(pq->pclC[m], 0, gsel);
+        } else {
+            const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
+            sc = fetch_score<KIND>(table, key, cb);
+        }
         int prev = row_shr1_z(d);
         if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
         const int d00 = __builtin_amdgcn_alignbit(d, prev, 16);
         int d11 = adds(d00, sc);
-        const int copen = adds(d, fc.go2);
+        if (j == 0) d11 = first_cell ? (int)(((uint32_t)d11 & 0xffff0000u) | (uint32_t)ZERO) : d11;   // cell (0,0) starts from the relative zero (scan_block.rs:1130-1132)
+        const int copen = adds(d, goC);
         const int cn = vmax(adds(c, fc.ge2), copen);
-        d11 = vmax(d11, cn);
-        const int x = adds(d11, fc.ome2);
+        const int cend = PROF ? adds(cn, clC) : cn;          // C11_end (scan_block.rs:697-701)
+        d11 = vmax(d11, cend);
+        const int x = adds(d11, goR);
         const s16x2 t2 = as_s(adds(x, fc.ge2));
         int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
         const int pm = wave_prefix_max16((int)as_s(r).y - fc.laneKG);
         const s16x2 cs = as_s(add_row_shr1(pm, fc.lanem1KG));
         r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst_top);
-        const int dn = vmax(d11, r);
+        const int rend = PROF ? adds(r, pq->vclR) : r;       // R11_end (scan_block.rs:712-716)
+        const int dn = vmax(d11, rend);
         if (TRACE) {   // the cell's four flags as sign bits of saturating differences, one nibble per column (see fast_rect)
-            const uint32_t sC = (uint32_t)subs(cn, dn), sR = (uint32_t)subs(r, dn), sCo = (uint32_t)subs(copen, cn), sRo = (uint32_t)subs(x, r);
+            const uint32_t sC = (uint32_t)subs(cend, dn), sR = (uint32_t)subs(rend, dn), sCo = (uint32_t)subs(copen, cn), sRo = (uint32_t)subs(x, r);
             const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);
             const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);
             tacc = (int)(((uint32_t)tacc >> 4) | (nib & 0xF000F000u));
@@ -132,7 +160,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
                 ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
             }
         } else {
-            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_BYTES ? 2 : 0);   // PROFILE: scores live in the pair's image
             for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
         }
     }
@@ -173,11 +201,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     // TRACE: the pair's trace stack (its own region of the arenas) and the stack heights of the checkpoint
     uint32_t trace_top = 0, nblocks = 0, ck_tt = 0, ck_nb = 0, tcap = 0, bcap = 0;
     uint32_t* tr = bp.trace_arena; BlockRec* bl = bp.blocks;
+    // The first block (scan_block.rs:260-305 with prev_size = 0: one 32 x 32 rectangle) runs as four right steps of 8 columns
+    // over zeroed borders -- the same recurrences, the row border filling up as it shifts --: boot = sub-steps left; no driver
+    // decision is taken between them, their maxima combine (bmx, brow, bcol) and the last one is followed by the driver step of a grow.
+    int boot = 0, bmx = 0, brow = 0, bcol = 0;
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter (wave-uniform)
     bool more = true;
 
     for (;;) {
-        // ---- idle slots take the next records (positions without a record -- pairs already finished -- are skipped)
+        // ---- idle slots take the next pairs of the batch. A pair starts here, with its first block (boot, below); pairs shorter
+        // than a block in either dimension are the per-pair kernel's from the start (flag 2: no record, run it from scratch)
         bool idle = pair == ~0u;
         while (more && __any(idle)) {
             if (w_next == w_end) {
@@ -193,23 +226,27 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             const uint32_t idx = w_next + rank;
             const uint32_t take = min((uint32_t)__popcll(im), w_end - w_next);
             w_next += take;
-            const bool got = idle && rank < take && bp.cont_in_flag[idx] != 0;
-            if (got) {
-                const PairCont* c = bp.cont_in + idx;
-                pair = c->pair; si = c->si; sj = c->sj; dir = c->dir; prev_dir = c->prev_dir; off = c->off; off_max = c->off_max; best_max = c->best_max;
-                y_drop = c->y_drop_iter; x_iter = c->x_drop_iter; D_corner = c->D_corner; best_i = c->best_i; best_j = c->best_j;
-                ck_i = c->ck_i; ck_j = c->ck_j; ck_off = c->ck_off; cells0 = c->cells; budget = c->step_budget; nsteps = 0;
-                Dcol = (int)c->borders[0][l]; Ccol = (int)c->borders[1][l]; Drow = (int)c->borders[2][l]; Rrow = (int)c->borders[3][l];
-                ck0 = (int)c->ckpt[0][l]; ck1 = (int)c->ckpt[1][l]; ck2 = (int)c->ckpt[2][l]; ck3 = (int)c->ckpt[3][l];
-                qp = bp.pool + bp.q_off[pair]; rp = bp.pool + bp.r_off[pair];
-                qlen = bp.q_len[pair]; rlen = bp.r_len[pair];
-                if (TRACE) {
-                    trace_top = c->trace_top; nblocks = c->nblocks; ck_tt = c->ck_trace_top; ck_nb = c->ck_nblocks;
-                    const uint64_t t0 = bp.trace_off[pair], b0 = bp.blocks_off[pair];
-                    tr = bp.trace_arena + t0; bl = bp.blocks + b0;
-                    tcap = (uint32_t)min(bp.trace_off[pair + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[pair + 1] - b0, (uint64_t)0x7fffffffu);
+            if (idle && rank < take) {
+                qlen = bp.q_len[idx]; rlen = bp.r_len[idx];
+                if (qlen < (uint32_t)QUAD_B || rlen < (uint32_t)QUAD_B) { if (l == 0) bp.cont_out_flag[idx] = 2u; }
+                else {
+                    pair = idx;
+                    // the state Block::align starts from (scan_block.rs:123-146), seen as four right steps of 8 columns that
+                    // end with the block at (0, 0): borders MIN = 0, no offset yet
+                    si = 0; sj = (uint32_t)-(QUAD_B - STEP); dir = DIR_RIGHT; prev_dir = DIR_GROW; off = 0; off_max = 0; best_max = 0;
+                    y_drop = 0; x_iter = 0; D_corner = 0; best_i = 0; best_j = 0; ck_i = 0; ck_j = 0; ck_off = 0; cells0 = 0; nsteps = 0;
+                    budget = 64u * ((qlen + rlen) / STEP + 64u);   // the per-pair kernel's watchdog
+                    Dcol = 0; Ccol = 0; Drow = 0; Rrow = 0; ck0 = 0; ck1 = 0; ck2 = 0; ck3 = 0;
+                    boot = QUAD_B / STEP; bmx = 0; brow = 0; bcol = 0;
+                    qp = bp.pool + bp.q_off[pair]; rp = bp.pool + bp.r_off[pair];
+                    if (TRACE) {
+                        trace_top = 0; nblocks = 0; ck_tt = 0; ck_nb = 0;
+                        const uint64_t t0 = bp.trace_off[pair], b0 = bp.blocks_off[pair];
+                        tr = bp.trace_arena + t0; bl = bp.blocks + b0;
+                        tcap = (uint32_t)min(bp.trace_off[pair + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[pair + 1] - b0, (uint64_t)0x7fffffffu);
+                    }
+                    pf_ok = false;
                 }
-                pf_ok = false;
             }
             idle = pair == ~0u;
         }
@@ -218,17 +255,55 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         // ---- the step every live slot is about to take
         const bool right = dir == DIR_RIGHT;
         const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (QUAD_B - STEP);
-        const uint32_t lenV = right ? qlen : rlen;
-        // a step that could break early at the matrix edge (never with X-drop) is not ours: leave before it
-        bool elig = XDROP || ri + QUAD_B <= lenV;
+        const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
+        // a step that could break early at the matrix edge (vectors past the end of their sequence and a column at or past
+        // the end of the other; never with X-drop) is not ours: leave before it
+        bool elig = XDROP || ri + QUAD_B <= lenV || rj + STEP <= lenC;
         if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * QUAD_B / 8) + 64 <= tcap;   // (a step that would not fit is the per-pair kernel's to report)
         bool leave = !idle && (!elig || budget <= 1);
         const bool run = !idle && !leave;
         const int off_n = off_max;
         const int off_add = sat16(off - off_n);
         const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
+        int vc = 0; uint32_t cb_lo = 0, cb_hi = 0;
+        QuadProfile pq{};
+        if constexpr (KIND == KIND_PROFILE) {
+            // rp = the pair's AAProfile image (ba_params.h): scores from the transposed table aa_pos[residue][position], the
+            // per-position gap costs behind it. Right: 8 positions (columns) of this lane's two residues; down: this lane's two
+            // positions (rows) for each of the 8 column residues.
+            if (run) {
+                const uint32_t P = profile_positions(rlen, max_size);
+                const short* aa_pos = (const short*)(rp + (uint64_t)P * 32);
+                const short* goCp = aa_pos + (uint64_t)P * 32; const short* clCp = goCp + P; const short* goRp = clCp + P;
+                if (right) {
+                    const int v2 = (int)*(const unsigned short*)(qp + ri + 2 * l);
+                    uint4 ga, gb, g1, g2, g3;
+                    __builtin_memcpy(&ga, aa_pos + (uint64_t)(v2 & 31) * P + rj, 16); __builtin_memcpy(&gb, aa_pos + (uint64_t)((v2 >> 8) & 31) * P + rj, 16);
+                    __builtin_memcpy(&g1, goCp + rj, 16); __builtin_memcpy(&g2, clCp + rj, 16); __builtin_memcpy(&g3, goRp + rj, 16);
+                    pq.A[0] = (int)ga.x; pq.A[1] = (int)ga.y; pq.A[2] = (int)ga.z; pq.A[3] = (int)ga.w;
+                    pq.B[0] = (int)gb.x; pq.B[1] = (int)gb.y; pq.B[2] = (int)gb.z; pq.B[3] = (int)gb.w;
+                    pq.pgoC[0] = adds((int)g1.x, fc.ge2); pq.pgoC[1] = adds((int)g1.y, fc.ge2); pq.pgoC[2] = adds((int)g1.z, fc.ge2); pq.pgoC[3] = adds((int)g1.w, fc.ge2);
+                    pq.pclC[0] = (int)g2.x; pq.pclC[1] = (int)g2.y; pq.pclC[2] = (int)g2.z; pq.pclC[3] = (int)g2.w;
+                    pq.pgoR[0] = (int)g3.x; pq.pgoR[1] = (int)g3.y; pq.pgoR[2] = (int)g3.z; pq.pgoR[3] = (int)g3.w;
+                    pq.selE = 0x05040100; pq.selO = 0x07060302; pq.gselE = 0x05040504; pq.gselO = 0x07060706;
+                } else {
+                    const uint2 cb = *(const uint2*)(qp + rj);
+                    int gs[STEP];
+#pragma unroll
+                    for (int k = 0; k < STEP; k++) {
+                        const uint32_t cbyte = ((k < 4 ? cb.x : cb.y) >> (8 * (k & 3))) & 31u;
+                        gs[k] = *(const int*)(aa_pos + (uint64_t)cbyte * P + ri + 2 * l);
+                    }
+                    const int w1 = *(const int*)(goRp + ri + 2 * l), w2 = *(const int*)(goCp + ri + 2 * l), w3 = *(const int*)(clCp + ri + 2 * l);
+#pragma unroll
+                    for (int m = 0; m < 4; m++) { pq.A[m] = gs[2 * m]; pq.B[m] = gs[2 * m + 1]; }
+                    pq.vgoC = adds(w1, fc.ge2); pq.vgoR = w2; pq.vclR = w3;
+                    pq.selE = 0x03020100; pq.selO = 0x07060504; pq.gselE = pq.gselO = 0x03020100;
+                }
+            }
+        } else {
         const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
-        int vc = right ? pf_qv : pf_rv; uint32_t cb_lo = right ? pf_rc.x : pf_qc.x, cb_hi = right ? pf_rc.y : pf_qc.y;
+        vc = right ? pf_qv : pf_rv; cb_lo = right ? pf_rc.x : pf_qc.x; cb_hi = right ? pf_rc.y : pf_qc.y;
         if (__any(run && !pf_ok)) {   // a slot that has just taken a pair
             if (run && !pf_ok) {
                 vc = *(const unsigned short*)(Vp + ri + 2 * l);
@@ -238,21 +313,29 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         }
         asm volatile("" : "+v"(vc));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
         if (run) {                      // for the step after this one, whichever way it goes
-            pf_qv = *(const unsigned short*)(qp + si + 2 * l); pf_rv = *(const unsigned short*)(rp + sj + 2 * l);
-            pf_qc = *(const uint2*)(qp + si + QUAD_B); pf_rc = *(const uint2*)(rp + sj + QUAD_B);
+            pf_qv = *(const unsigned short*)(qp + si + 2 * l); pf_rv = *(const unsigned short*)(rp + (boot > 1 ? 0u : sj) + 2 * l);   // (first block: sj is not a position yet)
+            pf_qc = *(const uint2*)(qp + si + QUAD_B); pf_rc = *(const uint2*)(rp + (uint32_t)(sj + QUAD_B));   // (32-bit sum: sj is "negative" during the first block)
             pf_ok = true;
+        }
         }
         int Ad = right ? Dcol : Drow, Ac = right ? Ccol : Rrow, Pd = right ? Drow : Dcol, Pr = right ? Rrow : Ccol;
         QuadOut o;
         const int loc_thr = best_max - off_n + ZERO;
-        if (TRACE && run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
-            BlockRec br;
-            br.i = right ? ri : rj; br.j = right ? rj : ri; br.h = (uint16_t)(right ? QUAD_B : STEP); br.w = (uint16_t)(right ? STEP : QUAD_B);
+        constexpr int NBOOT = QUAD_B / STEP;
+        if (TRACE && run && l == 0 && (boot == 0 || boot == NBOOT)) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,284)
+            BlockRec br;   // (the first block: one record for the 32 x 32 rectangle, its four sub-steps' trace words are contiguous)
+            br.i = right ? ri : rj; br.j = right ? rj : ri; br.h = (uint16_t)(right ? QUAD_B : STEP); br.w = (uint16_t)(right ? (boot ? QUAD_B : STEP) : QUAD_B);
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
             bl[nblocks] = br;
         }
-        quad_rect<KIND, TRACE, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add, run ? loc_thr : 0x7fffffff,
-                                      tr + trace_top, run, o);
+        quad_rect<KIND, TRACE, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add,
+                                      run ? (boot ? -1 : loc_thr) : 0x7fffffff, tr + trace_top, run, run && boot == NBOOT && l == 0, o, &pq);
+        if (boot) {   // the first block's maximum so far: largest value, then smallest row % 16, largest column, largest row (later sub-steps hold the larger columns)
+            const bool take = boot == NBOOT || o.mx > bmx || (o.mx == bmx && (o.row & 15) <= (brow & 15));
+            bmx = take ? o.mx : bmx; brow = take ? o.row : brow; bcol = take ? (NBOOT - boot) * STEP + o.col : bcol;
+            o.mx = bmx; o.row = brow;
+        }
+        const bool bsub = run && boot > 1, blast = run && boot == 1;
 
         // ---- what does the step call for? (scan_block.rs:332-558; nothing is committed yet)
         const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
@@ -263,8 +346,17 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         bool stop = q_out && r_out;                                                                   // end of the matrix
         if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
         stop = stop || (!q_out && !r_out && 2 * QUAD_B <= max_size && new_y > QUAD_B / STEP - 1);    // grow
-        const bool commit = run && !stop;
-        leave = leave || (run && stop);
+        // the first block: no decisions between its sub-steps; after the last one anything but a plain shift step (an empty
+        // improvement -- the driver would grow at once --, the end of the matrix) sends the pair to the per-pair kernel, from scratch
+        const bool fresh = blast && (stop || !improve);
+        const bool commit = run && !stop && !bsub && !fresh;
+        leave = leave || (run && stop && !bsub && !blast);
+        if (fresh) { if (l == 0) bp.cont_out_flag[pair] = 2u; pair = ~0u; boot = 0; }
+        if (bsub) {
+            Dcol = Ad; Ccol = Ac; Drow = Pd; Rrow = Pr;
+            sj += STEP; nsteps++; boot--;
+            if (TRACE) trace_top += STEP * QUAD_B / 8;
+        }
 
         // ---- slots that leave: their state as it was at the top of this step
         if (__any(leave)) {
@@ -285,13 +377,14 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         // ---- slots that go on: commit the step
         if (commit) {
             Dcol = right ? Ad : Pd; Ccol = right ? Ac : Pr; Drow = right ? Pd : Ad; Rrow = right ? Pr : Ac;
-            off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = dir; D_corner = o.corner_new;
+            off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = blast ? DIR_GROW : dir; D_corner = blast ? 0 : o.corner_new;
             nsteps++; budget--;
             if (TRACE) { trace_top += STEP * QUAD_B / 8; nblocks++; }
             if (improve) {
                 if (XDROP) {   // scan_block.rs:370-404
                     best_i = right ? si + (uint32_t)o.row : si + (QUAD_B - STEP) + (uint32_t)o.col;
                     best_j = right ? sj + (QUAD_B - STEP) + (uint32_t)o.col : sj + (uint32_t)o.row;
+                    if (blast) best_j = (uint32_t)bcol;
                 }
                 if (QUAD_B < max_size) {
                     ck_i = si; ck_j = sj; ck_off = off; ck0 = Dcol; ck1 = Ccol; ck2 = Drow; ck3 = Rrow;
@@ -303,6 +396,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             const bool go_down = r_out || (!q_out && down_max > right_max);
             si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
             dir = go_down ? DIR_DOWN : DIR_RIGHT;
+            boot = 0;
         }
     }
 }

@@ -170,11 +170,21 @@ def _pssm_case(rng, length, block_max):
     return q, p
 
 
+@pytest.mark.parametrize("pipe", ["", "1", "quad"])
 @pytest.mark.parametrize("mode", [(), ("x_drop",), ("trace",), ("trace", "x_drop")])
 @pytest.mark.parametrize("size", [(16, 16), (32, 128), (32, 256), (128, 1024)])
-def test_profile_batch(hip, oracle, mode, size):
+def test_profile_batch(hip, oracle, monkeypatch, mode, size, pipe):
     """Sequence-to-profile alignment (place_block_profile_*, scan_block.rs:612-783) as a batch: every pair has its own
-    PSSM and per-position gap open / close costs; compared with the oracle pair by pair."""
+    PSSM and per-position gap open / close costs; compared with the oracle pair by pair. pipe: the pair-slot form large TRACE
+    batches take (a trace region per pair, all paths walked by k_walk after the fill), forced on this small batch."""
+    if pipe == "quad":   # the small-block pipeline (k_quad: four pairs per wave at 32 cells), forced on this small batch
+        if size[0] != 32:
+            pytest.skip("the small-block pipeline starts at 32 cells")
+        monkeypatch.setenv("BA_FORCE_QUAD", "1")
+    elif pipe:
+        if "trace" not in mode:
+            pytest.skip("pair-slot batches are TRACE batches")
+        monkeypatch.setenv("BA_FORCE_PIPE", "1")
     rng = np.random.default_rng(41 + size[1] + len(mode))
     cases = [_pssm_case(rng, int(rng.integers(1, 500)), size[1]) for _ in range(120)]
     cases.append((b"", cases[0][1]))
@@ -613,18 +623,15 @@ def test_percent_len_sizes_are_accepted(hip, oracle):
     compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 4096), 0, ("trace",), cigar_eq=False)
 
 
-@pytest.mark.parametrize("skip_quad", ["1", ""])
 @pytest.mark.parametrize("mode", [("x_drop",), (), ("trace", "x_drop"), ("trace",)])
-def test_small_block_pipeline(hip, oracle, monkeypatch, mode, skip_quad):
-    """Batches that start at 32 cells run in three passes: the per-pair kernel up to each pair's first plain shift
-    step, k_quad (four pairs per wave, one per 16-lane DPP row) through the plain shift steps, the per-pair kernel again for
-    whatever else a pair needs (grow, termination, matrix edge); pairs travel between the passes as PairCont records. With
-    TRACE every pair stacks its trace words and rectangle records in its own region of the arenas across the three passes and a
-    fourth kernel (k_walk) walks all paths, one pair per lane. Forced on small batches here; BA_QUAD_SKIP = 1 runs passes 1 and
-    3 alone (the record plumbing without k_quad). DNA, protein and byte pairs, with growth (indels), tiny and empty sequences."""
+def test_small_block_pipeline(hip, oracle, monkeypatch, mode):
+    """Batches that start at 32 cells run in two fill passes: k_quad (four pairs per wave, one per 16-lane DPP row) starts every
+    pair -- its first block as four 8-column sub-steps -- and runs its plain shift steps; the per-pair kernel then does whatever
+    else a pair needs (grow, termination, matrix edge; pairs shorter than a block from scratch); pairs travel between the passes
+    as PairCont records. With TRACE every pair stacks its trace words and rectangle records in its own region of the arenas
+    across the passes and a last kernel (k_walk) walks all paths, one pair per lane. Forced on small batches here. DNA, protein
+    and byte pairs, with growth (indels), tiny and empty sequences."""
     monkeypatch.setenv("BA_FORCE_QUAD", "1")
-    if skip_quad:
-        monkeypatch.setenv("BA_QUAD_SKIP", "1")
     dna = synth.make_pairs(700, (0, 1500), (0, 150), 40, synth.DNA, seed=61, indels=1, indel_len=(10, 120))
     for size in [(32, 32), (32, 64), (32, 256), (32, 2048)]:
         compare(hip, oracle, dna, NUC, (-5, -1), size, 60, mode)
@@ -638,6 +645,18 @@ def test_small_block_pipeline(hip, oracle, monkeypatch, mode, skip_quad):
     compare(hip, oracle, edge, S.NW1, (-2, -1), (32, 128), 20, mode)
 
 
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
+def test_pair_slot_batches_without_small_blocks(hip, oracle, monkeypatch, mode):
+    """TRACE batches of many short pairs keep every pair's trace stack in its own region and walk all paths after the fill
+    (k_walk, one pair per lane) whatever their block range; forced on small batches here."""
+    monkeypatch.setenv("BA_FORCE_PIPE", "1")
+    dna = synth.make_pairs(400, (0, 1200), (0, 120), 40, synth.DNA, seed=71, indels=1, indel_len=(10, 120))
+    for size in [(16, 16), (64, 512), (128, 128), (128, 2048)]:
+        compare(hip, oracle, dna, NUC, (-5, -1), size, 60, mode)
+    prot = synth.make_pairs(400, (22, 900), (0, 250), 0, synth.AMINO, seed=72)
+    compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 256), 40, mode, cigar_eq=False)
+
+
 @pytest.mark.parametrize("margin", ["3", "60"])
 def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, monkeypatch, margin):
     """The TRACE form of the small-block pipeline cuts the trace arena into one region per pair, sized for the pair's expected
@@ -647,7 +666,7 @@ def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, monkeypatch, 
     monkeypatch.setenv("BA_FORCE_QUAD", "1")
     monkeypatch.setenv("BA_TRACE_MARGIN_PCT", margin)
     mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
-    sets = [synth.make_pairs(500 - 60 * k, (300, 2500), (30, 250), 60, synth.DNA, seed=131 + k, indels=3, indel_len=(30, 300)) for k in range(2)]
+    sets = [synth.make_pairs(500 - 100 * k, (300, 2500 - 500 * k), (30, 250), 60, synth.DNA, seed=131 + k, indels=3, indel_len=(30, 300)) for k in range(2)]
     b = hip.BatchAligner(NUC, (-5, -1), (32, 512), 80, mode, sets[0].pool, sets[0].q_off, sets[0].q_len, sets[0].r_off, sets[0].r_len)
     for k, pairs in enumerate(sets):
         if k:

@@ -12,7 +12,7 @@ pairs = synth.make_pairs(n, 10000, 1000, 500, synth.DNA, seed=1234)
 mode = H.X_DROP | ((H.TRACE | H.CIGAR_EQ) if trace else 0)
 b = H.BatchAligner(S.NucMatrix.new_simple(2, -3), (-5, -1), (128, maxb), 100, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
 b.run(); ms = b.run()
-prof = np.zeros(64, np.uint64)
+prof = np.zeros(128, np.uint64)
 H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
 H.lib().ba_batch_prof(b._h, prof.ctypes.data)
 names = {0: "fast prologue", 1: "fast columns", 2: "fast epilogue", 4: "generic<=128 prologue", 5: "generic<=128 columns", 6: "generic<=128 epilogue",
