@@ -473,6 +473,9 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     lds_sync();
     TbLane t{};
     bool walking = false, more = true;
+    // small-block batches walk in two launches: the pairs k_quad finished (cont_mode 1: flag 0) while the per-pair kernel is still
+    // at work on the others, then those (cont_mode 2). 0: every pair.
+    const uint32_t filter = bp.cont_mode;
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the batch order: 64 pairs per atomic (a returning atomic is a full memory
                                       // round trip that every lane of the wave waits for: one per finished lane would double the walk time)
     for (;;) {
@@ -489,7 +492,9 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             const uint32_t take = min((uint32_t)__popcll(im), w_end - w_next);
             const uint32_t p = w_next + rank;
             w_next += take;
-            if (!walking && rank < take) {
+            bool mine = !walking && rank < take;
+            if (filter && mine) mine = (bp.cont_in_flag[p] == 0) == (filter == 1);
+            if (mine) {
                 const SlotInfo si = bp.slot_info[p];
                 t = TbLane{};
                 t.qw0 = t.rw0 = 0xffffffffu; t.tw_ok = false;

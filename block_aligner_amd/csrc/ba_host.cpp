@@ -183,8 +183,8 @@ struct DevBuf {
 
 struct BaBatch {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: pair-slot small-block batches (see batch_launch)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     int kind = 0; uint32_t mode = 0;
     uint32_t n = 0, min_size = 0, max_size = 0, pclass = 0;
     int gap_open = 0, gap_extend = 0, x_drop = 0;
@@ -238,6 +238,9 @@ struct BaBatch {
     ~BaBatch() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -687,6 +690,10 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (batch_alloc_scratch(b.get())) return nullptr;
     if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(n * 4))) return nullptr;
     if (b->pipe && (b->trace_off.alloc((n + 1) * 8) || b->blocks_off.alloc((n + 1) * 8))) return nullptr;
+    if (b->pipe && b->quad && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
+                               hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess)) {
+        fail("hipStreamCreate / hipEventCreate failed"); return nullptr;
+    }
     lap("device allocation");
 #define BA_H2D(buf, src, bytes) if (hipMemcpy(b->buf.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy H2D failed"); return nullptr; }
     BA_H2D(q_off, qo.data(), n * 8); BA_H2D(q_len, ql.data(), n * 4);
@@ -775,13 +782,23 @@ static int batch_launch(BaBatch* b) {
         p2.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
         HIP_TRY(g_launch_quad[b->kind](tr, (b->mode & BA_X_DROP) != 0, b->stream, &p2));
         const ba::PairCont* last = b->contA.as<ba::PairCont>(); const uint32_t* last_flag = flagA;
-        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 4, b->stream));
         BatchParams p3 = bp; p3.cont_mode = 2; p3.cont_in = last; p3.cont_in_flag = last_flag;
         if (tr) p3.cig_ops = nullptr;
+        const bool walk = tr && bp.cig_ops;
+        if (walk) {   // the paths of the pairs k_quad finished are walked on a second stream while the per-pair kernel runs
+            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+            BatchParams w1 = bp; w1.cont_mode = 1; w1.cont_in_flag = flagA; w1.work_counter = b->counter.as<uint32_t>() + 8;   // (zeroed with the first counter above)
+            HIP_TRY(ba_launch_walk(b->stream2, &w1, walk_grid(b)));
+            HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
+        }
         HIP_TRY(launch(tr, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p3));
-        if (tr && bp.cig_ops) {
-            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
-            HIP_TRY(ba_launch_walk(b->stream, &bp, walk_grid(b)));
+        if (walk) {
+            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 4, b->stream));
+            BatchParams w2 = bp; w2.cont_mode = 2; w2.cont_in_flag = flagA;
+            HIP_TRY(ba_launch_walk(b->stream, &w2, walk_grid(b)));
+            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
         }
     } else if (b->pipe) {   // pair-slot batch: the fill stacks, k_walk walks
         BatchParams p1 = bp; p1.cig_ops = nullptr;

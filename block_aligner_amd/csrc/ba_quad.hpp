@@ -52,7 +52,7 @@ struct QuadProfile {
 template <int KIND, bool TRACE, bool XDROP>
 __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& fc, int l, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
                                           int vec_a, int vec_b, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, int loc_thr,
-                                          uint32_t* __restrict__ tout, bool store, bool first_cell, QuadOut& o, const QuadProfile* pq = nullptr) {
+                                          uint32_t* __restrict__ tout, bool store, bool first_cell, QuadOut& o, int (&dcol)[STEP], const QuadProfile* pq = nullptr) {
     constexpr bool PROF = KIND == KIND_PROFILE;
     const int offa = splat(off_add);
     int d = adds(Ad, offa), c = adds(Ac, offa);
@@ -62,7 +62,6 @@ __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& f
     o.corner_new = slot_bcast<3>(pd) >> 16;
     const ScoreKey<KIND> key = make_key<KIND>(vec_a, vec_b);
     int dmax = 0, tacc = 0;
-    int dcol[STEP];
     short* last_base = l == 15 ? Pl + QUAD_B : sink;
 #pragma unroll
     for (int j = 0; j < STEP; j++) {
@@ -258,7 +257,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
         // a step that could break early at the matrix edge (vectors past the end of their sequence and a column at or past
         // the end of the other; never with X-drop) is not ours: leave before it
-        bool elig = XDROP || ri + QUAD_B <= lenV || rj + STEP <= lenC;
+        // -- except the step that ends a global alignment (both at once: the block has reached the last row and the last column):
+        // that one is finished here, see `fin` below
+        const bool q_out = si + QUAD_B > qlen, r_out = sj + QUAD_B > rlen;
+        bool elig = XDROP || ri + QUAD_B <= lenV || rj + STEP <= lenC || (boot == 0 && q_out && r_out);
         if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * QUAD_B / 8) + 64 <= tcap;   // (a step that would not fit is the per-pair kernel's to report)
         bool leave = !idle && (!elig || budget <= 1);
         const bool run = !idle && !leave;
@@ -320,6 +322,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         }
         int Ad = right ? Dcol : Drow, Ac = right ? Ccol : Rrow, Pd = right ? Drow : Dcol, Pr = right ? Rrow : Ccol;
         QuadOut o;
+        int dcol[STEP];
         const int loc_thr = best_max - off_n + ZERO;
         constexpr int NBOOT = QUAD_B / STEP;
         if (TRACE && run && l == 0 && (boot == 0 || boot == NBOOT)) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,284)
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             bl[nblocks] = br;
         }
         quad_rect<KIND, TRACE, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add,
-                                      run ? (boot ? -1 : loc_thr) : 0x7fffffff, tr + trace_top, run, run && boot == NBOOT && l == 0, o, &pq);
+                                      run ? (boot ? -1 : loc_thr) : 0x7fffffff, tr + trace_top, run, run && boot == NBOOT && l == 0, o, dcol, &pq);
         if (boot) {   // the first block's maximum so far: largest value, then smallest row % 16, largest column, largest row (later sub-steps hold the larger columns)
             const bool take = boot == NBOOT || o.mx > bmx || (o.mx == bmx && (o.row & 15) <= (brow & 15));
             bmx = take ? o.mx : bmx; brow = take ? o.row : brow; bcol = take ? (NBOOT - boot) * STEP + o.col : bcol;
@@ -342,7 +345,6 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         const int new_off_max = off_n + o.mx - ZERO;
         const bool improve = new_off_max > best_max;
         const uint32_t new_y = improve ? 0u : y_drop + 1;
-        const bool q_out = si + QUAD_B > qlen, r_out = sj + QUAD_B > rlen;
         bool stop = q_out && r_out;                                                                   // end of the matrix
         if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
         stop = stop || (!q_out && !r_out && 2 * QUAD_B <= max_size && new_y > QUAD_B / STEP - 1);    // grow
@@ -350,7 +352,30 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         // improvement -- the driver would grow at once --, the end of the matrix) sends the pair to the per-pair kernel, from scratch
         const bool fresh = blast && (stop || !improve);
         const bool commit = run && !stop && !bsub && !fresh;
-        leave = leave || (run && stop && !bsub && !blast);
+        // The last step of a global alignment: its columns stop at the end of the column sequence (scan_block.rs:1216-1224; the
+        // trace index still advances over the whole rectangle), and the score is the vector border's entry at the end of the
+        // vector sequence after the last computed column (scan_block.rs:560-570). The pair is complete: results are written here.
+        const bool fin = !XDROP && run && boot == 0 && q_out && r_out;
+        if (!XDROP && __any(fin)) {
+            const uint32_t ncols = lenC - rj + 1;   // 1 .. 8 (columns rj .. lenC)
+            int dsel = dcol[0];
+#pragma unroll
+            for (int k = 1; k < STEP; k++) dsel = ncols == (uint32_t)(k + 1) ? dcol[k] : dsel;
+            const uint32_t idx = lenV - ri;         // 0 .. 31: both ends are inside the block
+            const int v = __builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 48u) + (idx >> 1)) << 2, dsel);
+            const int sc16 = (idx & 1) ? v >> 16 : (int)(short)v;
+            if (fin && l == 0) {
+                bp.score[pair] = off_n + sc16 - ZERO; bp.query_idx[pair] = qlen; bp.reference_idx[pair] = rlen;
+                if (bp.cells) bp.cells[pair] = cells0 + (unsigned long long)nsteps * (STEP * QUAD_B) + (unsigned long long)ncols * QUAD_B;
+                if (bp.status) bp.status[pair] = 0;
+                if (bp.nblocks_out) bp.nblocks_out[pair] = TRACE ? nblocks + 1 : 0;
+                if (bp.trace_words_out) bp.trace_words_out[pair] = TRACE ? trace_top + STEP * QUAD_B / 8 : 0;
+                if (bp.slot_out) bp.slot_out[pair] = pair;
+                if (TRACE) bp.slot_info[pair] = SlotInfo{pair, nblocks + 1, qlen, rlen};
+            }
+            if (fin) pair = ~0u;
+        }
+        leave = leave || (run && stop && !bsub && !blast && !fin);
         if (fresh) { if (l == 0) bp.cont_out_flag[pair] = 2u; pair = ~0u; boot = 0; }
         if (bsub) {
             Dcol = Ad; Ccol = Ac; Drow = Pd; Rrow = Pr;
