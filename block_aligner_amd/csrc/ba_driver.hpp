@@ -494,8 +494,9 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             w_next += take;
             bool mine = !walking && rank < take;
             if (filter && mine) mine = (bp.cont_in_flag[p] == 0) == (filter == 1);
+            SlotInfo si{0, 0, 0, 0};
+            if (mine) { si = bp.slot_info[p]; mine = si.nblocks != ~0u; }   // (~0: the per-pair kernel has walked this path itself)
             if (mine) {
-                const SlotInfo si = bp.slot_info[p];
                 t = TbLane{};
                 t.qw0 = t.rw0 = 0xffffffffu; t.tw_ok = false;
                 t.slot = p; t.pair = p; t.i = si.end_i; t.j = si.end_j; t.bidx = si.nblocks;
@@ -870,20 +871,27 @@ struct Aligner {
 #endif
         if (resume) {   // a pair that comes back from the small-block kernel: its state at the top of the loop
             const int lane = lane_id();
-            si = resume->si; sj = resume->sj; dir = resume->dir; prev_dir = resume->prev_dir; off = resume->off; off_max = resume->off_max;
-            best_max = resume->best_max; y_drop_iter = resume->y_drop_iter; x_drop_iter = resume->x_drop_iter; D_corner = resume->D_corner;
-            cells = resume->cells; step_budget = resume->step_budget;
-            park<5>(parked, (int)resume->best_i); park<6>(parked, (int)resume->best_j);
-            park<0>(parked, (int)resume->ck_i); park<1>(parked, (int)resume->ck_j); park<2>(parked, resume->ck_off);
+            // The record may have been written while this kernel was already running (queue mode, see k_align): loads that bypass
+            // this CU's L1 (agent-scope relaxed = sc1, served by L2, where the producer's release has put the record) -- and never
+            // the scalar cache, whose lines may predate the record: one vector load of the 24 header words, lane k holding word k.
+            const int hdr = lane < 24 ? (int)__hip_atomic_load((const uint32_t*)resume + lane, BA_RLX_AGENT) : 0;
+#define BA_HDR(k) __builtin_amdgcn_readlane(hdr, k)
+            si = (uint32_t)BA_HDR(1); sj = (uint32_t)BA_HDR(2); dir = BA_HDR(3); prev_dir = BA_HDR(4); off = BA_HDR(5); off_max = BA_HDR(6);
+            best_max = BA_HDR(7); y_drop_iter = (uint32_t)BA_HDR(8); x_drop_iter = BA_HDR(9); D_corner = BA_HDR(10);
+            cells = (unsigned long long)(uint32_t)BA_HDR(16) | ((unsigned long long)(uint32_t)BA_HDR(17) << 32); step_budget = (uint32_t)BA_HDR(18);
+            park<5>(parked, BA_HDR(11)); park<6>(parked, BA_HDR(12));
+            park<0>(parked, BA_HDR(13)); park<1>(parked, BA_HDR(14)); park<2>(parked, BA_HDR(15));
             if (TRACE) {
-                trace_top = resume->trace_top; nblocks = resume->nblocks; status = resume->status;
-                park<3>(parked, (int)resume->ck_trace_top); park<4>(parked, (int)resume->ck_nblocks);
+                trace_top = (uint32_t)BA_HDR(19); nblocks = (uint32_t)BA_HDR(20); status = (uint32_t)BA_HDR(23);
+                park<3>(parked, BA_HDR(21)); park<4>(parked, BA_HDR(22));
             }
+#undef BA_HDR
             if (lane < 16) {
-                *(int*)(L.D_col + 2 * lane) = (int)resume->borders[0][lane]; *(int*)(L.C_col + 2 * lane) = (int)resume->borders[1][lane];
-                *(int*)(L.D_row + 2 * lane) = (int)resume->borders[2][lane]; *(int*)(L.R_row + 2 * lane) = (int)resume->borders[3][lane];
-                ck_reg[0] = (int)resume->ckpt[0][lane]; ck_reg[1] = (int)resume->ckpt[1][lane];
-                ck_reg[2] = (int)resume->ckpt[2][lane]; ck_reg[3] = (int)resume->ckpt[3][lane];
+#define BA_REC(field, k) (int)__hip_atomic_load(&resume->field[k][lane], BA_RLX_AGENT)
+                *(int*)(L.D_col + 2 * lane) = BA_REC(borders, 0); *(int*)(L.C_col + 2 * lane) = BA_REC(borders, 1);
+                *(int*)(L.D_row + 2 * lane) = BA_REC(borders, 2); *(int*)(L.R_row + 2 * lane) = BA_REC(borders, 3);
+                ck_reg[0] = BA_REC(ckpt, 0); ck_reg[1] = BA_REC(ckpt, 1); ck_reg[2] = BA_REC(ckpt, 2); ck_reg[3] = BA_REC(ckpt, 3);
+#undef BA_REC
             }
             ck_in_regs = true;
             lds_sync();
@@ -1171,7 +1179,9 @@ struct Aligner {
             hand_off(slot, pair, ri, rj);
             return;
         }
-        if (TRACE && coldp()->cig_ops && !status) {
+        // pair-slot batches: pairs shorter than inline_len2 leave their paths to k_walk (one pair per lane) instead of this wave's lane 0
+        const bool walk_later = TRACE && coldp()->trace_off && qlen + rlen < coldp()->inline_len2;
+        if (TRACE && coldp()->cig_ops && !status && !walk_later) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
@@ -1190,7 +1200,7 @@ struct Aligner {
             if (coldp()->nblocks_out) coldp()->nblocks_out[pair] = nblocks;
             if (coldp()->trace_words_out) coldp()->trace_words_out[pair] = trace_top;
             if (coldp()->slot_out) coldp()->slot_out[pair] = slot;
-            if (TRACE && coldp()->trace_off) coldp()->slot_info[pair] = SlotInfo{pair, nblocks, ri, rj};   // pair-slot batches: walked by k_walk
+            if (TRACE && coldp()->trace_off) coldp()->slot_info[pair] = SlotInfo{pair, walk_later ? nblocks : ~0u, ri, rj};   // pair-slot batches: k_walk's task (~0: nothing left to walk)
         }
     }
 };
@@ -1270,21 +1280,51 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
         const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
         uint32_t turn = 0;
         uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter: bp.work_chunk pairs per atomic
+        bool closing = false;             // queue mode: every producer wave has been seen done
         for (;;) {
             BA_TSTAMP(tk0);
-            if (w_next == w_end) {
+            if (bp.cont_mode != 2 && w_next == w_end) {
                 uint32_t v = 0;
                 if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
                 w_next = (uint32_t)uni((int)v);
                 if (w_next >= bp.n) break;
                 w_end = min(w_next + bp.work_chunk, bp.n);
             }
-            uint32_t pair = w_next++;
+            uint32_t pair = bp.cont_mode == 2 ? 0u : w_next++;
             const PairCont* rec = nullptr;
-            if (bp.cont_mode == 2) {   // after the small-block kernel: flag 1 = a record to resume from, 2 = still to be run from scratch, 0 = done
-                const uint32_t f = bp.cont_in_flag[pair];
-                if (!f) continue;
-                if (f == 1) rec = bp.cont_in + pair;
+            if (bp.cont_mode == 2) {
+                // Small-block batches: the pairs k_quad could not finish arrive through a queue while it is still running (entry =
+                // 1 + 2 * pair + (1 if the pair is to be run from scratch, else resume from its record)). A ticket is a queue position;
+                // the wave waits for its entry, and leaves once every producer wave is done and the queue ends before the ticket.
+                if (w_next >= w_end) {   // one ticket while the producers run -- an entry is work waiting --, eight once they are done
+                    const uint32_t chunk = closing ? 8u : 1u;
+                    uint32_t t0 = 0;
+                    if (is_lane(0)) t0 = __hip_atomic_fetch_add(bp.cq_ctrl + 16, chunk, BA_RLX_AGENT);
+                    w_next = (uint32_t)uni((int)t0); w_end = w_next + chunk;
+                }
+                const uint32_t ticket = w_next++;
+                if (ticket >= bp.n) break;   // (at most one entry per pair)
+                uint32_t e = 0, spins = 0;
+                for (;;) {
+                    uint32_t v = 0, done = 0;
+                    if (is_lane(0)) { v = __hip_atomic_load(bp.cq_queue + ticket, BA_RLX_AGENT); done = __hip_atomic_load(bp.cq_ctrl + 32, BA_RLX_AGENT); }
+                    v = (uint32_t)uni((int)v); done = (uint32_t)uni((int)done);
+                    if (v) { e = v; break; }
+                    if (closing) {   // all producers were done before this read found the entry still empty: is the queue shorter than the ticket?
+                        uint32_t tail = 0;
+                        if (is_lane(0)) tail = __hip_atomic_load(bp.cq_ctrl, BA_RLX_AGENT);
+                        if (ticket >= (uint32_t)uni((int)tail)) break;
+                    }
+                    if (done >= bp.cq_producers) { closing = true; continue; }
+                    if (++spins > (1u << 21)) {   // several seconds without the producers finishing: report, do not hang
+                        if (is_lane(0)) __hip_atomic_store(bp.cq_ctrl + 48, 1u, BA_RLX_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                if (!e) break;
+                pair = (e - 1u) >> 1;   // (the record, released before its entry, is read past this CU's L1: see run())
+                if (!((e - 1u) & 1u)) rec = bp.cont_in + pair;
             }
             uint32_t slot = fill_wave * bp.slots_per_wave + turn;
             if (++turn == bp.slots_per_wave) turn = 0;
@@ -1307,7 +1347,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
             if (TRACE && bp.trace_off) { al.trace = bp.trace_arena + bp.trace_off[pair]; al.blocks = bp.blocks + bp.blocks_off[pair]; }
-            al.ckpt = bp.ckpt + (uint64_t)fill_wave * 8 * bp.max_size;   // (second half: the base of a chain of speculative grows)
+            al.ckpt = bp.ckpt + (uint64_t)(fill_wave + bp.ckpt_wave0) * 8 * bp.max_size;   // (second half: the base of a chain of speculative grows)
             if (kBig) {   // the four borders live in this wave's slice of the big arena, not in LDS
                 short* bw = bp.big + (uint64_t)fill_wave * big_wave_shorts(bp.max_size);
                 const uint64_t as = big_array_shorts(bp.max_size);

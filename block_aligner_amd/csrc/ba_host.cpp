@@ -51,11 +51,17 @@ typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 // [special modes?][kind][block class]
 static const LaunchFn g_launch[2][4][5] = {{BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)}, {BA_SROW(0), BA_SROW(1), BA_SROW(2), BA_SROW(3)}};
 static const OccFn g_occ[2][4][5] = {{BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)}, {BA_SOROW(0), BA_SOROW(1), BA_SOROW(2), BA_SOROW(3)}};
-typedef hipError_t (*QuadFn)(int, int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k0(int, int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k1(int, int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k2(int, int, hipStream_t, const BatchParams*);
-extern "C" hipError_t ba_launch_quad_k3(int, int, hipStream_t, const BatchParams*);
+typedef hipError_t (*QuadFn)(int, int, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k0(int, int, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k1(int, int, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k2(int, int, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_quad_k3(int, int, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_quad_grid_k0(int, int, unsigned*);
+extern "C" hipError_t ba_quad_grid_k1(int, int, unsigned*);
+extern "C" hipError_t ba_quad_grid_k2(int, int, unsigned*);
+extern "C" hipError_t ba_quad_grid_k3(int, int, unsigned*);
+typedef hipError_t (*QuadGridFn)(int, int, unsigned*);
+static const QuadGridFn g_quad_grid[4] = {ba_quad_grid_k0, ba_quad_grid_k1, ba_quad_grid_k2, ba_quad_grid_k3};
 static const QuadFn g_launch_quad[4] = {ba_launch_quad_k0, ba_launch_quad_k1, ba_launch_quad_k2, ba_launch_quad_k3};
 static const LaunchFn g_launch_big[4] = {ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32};
 static const OccFn g_occ_big[4] = {ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32};
@@ -202,7 +208,9 @@ struct BaBatch {
     bool ran = false, in_flight = false;
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
-    DevBuf contA, cont_n;       // the PairCont records between the two fill launches of such a batch, and their flags
+    DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
+    DevBuf cq_queue, cq_ctrl;   // the queue those pairs travel through (ba_params.h)
+    uint32_t quad_grid = 0, cq_grid = 0;   // workgroups of k_quad / of the per-pair kernel that runs beside it
     // pair-slot batch (a small-block batch with TRACE): every pair owns a region of the trace / record arenas for the whole
     // batch (offsets below, n + 1 entries each), the fill kernels only stack, and k_walk does all tracebacks at the end
     bool pipe = false;
@@ -520,6 +528,11 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
     }
     b->grid = (uint32_t)grid;
+    b->cq_grid = 0;
+    if (b->quad) {   // the per-pair kernel beside k_quad: one workgroup per CU, so that k_quad always finds room next to it
+        b->cq_grid = (uint32_t)std::min<uint64_t>(grid, (uint64_t)prop.multiProcessorCount);
+        if (const char* env = getenv("BA_CQ_GRID")) { int v = atoi(env); if (v > 0) b->cq_grid = (uint32_t)std::min<uint64_t>(grid, (uint64_t)v); }
+    }
     // TRACE batches big enough to keep them busy get dedicated traceback waves (ba_driver.hpp traceback_consumer)
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
     b->tb_stride = 0; b->slots_per_wave = 1;
@@ -578,7 +591,7 @@ static int batch_alloc_scratch(BaBatch* b) {
 #define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return 1
     BA_ALLOC(trace, b->pipe ? b->pipe_words * 4 : b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->pipe ? b->pipe_recs * sizeof(BlockRec) : b->blocks_stride * sizeof(BlockRec) * b->slots);
-    BA_ALLOC(ckpt, (size_t)b->grid * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
+    BA_ALLOC(ckpt, (size_t)(b->grid + b->cq_grid) * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
     BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short) : 0);
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
@@ -690,7 +703,11 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (batch_alloc_scratch(b.get())) return nullptr;
     if (b->quad && (b->contA.alloc(n * sizeof(ba::PairCont)) || b->cont_n.alloc(n * 4))) return nullptr;
     if (b->pipe && (b->trace_off.alloc((n + 1) * 8) || b->blocks_off.alloc((n + 1) * 8))) return nullptr;
-    if (b->pipe && b->quad && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
+    if (b->quad) {
+        if (b->cq_queue.alloc(n * 4) || b->cq_ctrl.alloc(256)) return nullptr;
+        if (g_quad_grid[kind](trace ? 1 : 0, (mode & BA_X_DROP) ? 1 : 0, &b->quad_grid) != hipSuccess || !b->quad_grid) { fail("occupancy query failed for the small-block kernel"); return nullptr; }
+    }
+    if (b->quad && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
                                hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess)) {
         fail("hipStreamCreate / hipEventCreate failed"); return nullptr;
     }
@@ -770,38 +787,50 @@ static int batch_launch(BaBatch* b) {
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : g_launch[special_of(b->mode)][b->kind][b->pclass];
     if (b->quad && b->n <= b->cap_n) {
-        // pass 1 (k_quad): every pair's first block and plain shift steps, four pairs per wave, until the pair needs anything
-        //                  else (a grow, termination, the early column break at the matrix edge) -> a record in the list;
-        // pass 2 (per-pair kernel): the pairs of the list to their end (and those k_quad could not start, from scratch).
-        // TRACE (a pair-slot batch): both fill launches only stack trace words and records in the pairs' regions;
-        // pass 3 (k_walk) walks every pair's path, one pair per lane.
-        const int tr = (b->mode & BA_TRACE) ? 1 : 0;
+        // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
+        // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a
+        // queue to the per-pair kernel: one small launch of it runs beside k_quad on a second stream (the longest pairs come
+        // first and leave early: their remaining steps are a long serial chain best started at once), a full-size one after it.
+        // TRACE (a pair-slot batch): k_quad only stacks trace words; the paths of the pairs it finished are walked by k_walk, one
+        // pair per lane, the per-pair kernel walks its own pairs' paths at once.
+        const int tr = (b->mode & BA_TRACE) ? 1 : 0, xd = (b->mode & BA_X_DROP) ? 1 : 0;
         uint32_t* flagA = b->cont_n.as<uint32_t>();
-        HIP_TRY(hipMemsetAsync(flagA, 0, b->cap_n * 4, b->stream));
-        BatchParams p2 = bp; p2.cont_out = b->contA.as<ba::PairCont>(); p2.cont_out_flag = flagA;
-        p2.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
-        HIP_TRY(g_launch_quad[b->kind](tr, (b->mode & BA_X_DROP) != 0, b->stream, &p2));
-        const ba::PairCont* last = b->contA.as<ba::PairCont>(); const uint32_t* last_flag = flagA;
-        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 4, b->stream));
-        BatchParams p3 = bp; p3.cont_mode = 2; p3.cont_in = last; p3.cont_in_flag = last_flag;
-        if (tr) p3.cig_ops = nullptr;
-        const bool walk = tr && bp.cig_ops;
-        if (walk) {   // the paths of the pairs k_quad finished are walked on a second stream while the per-pair kernel runs
-            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+        HIP_TRY(hipMemsetAsync(flagA, 0, (size_t)b->n * 4, b->stream));
+        HIP_TRY(hipMemsetAsync(b->cq_queue.p, 0, (size_t)b->n * 4, b->stream));
+        HIP_TRY(hipMemsetAsync(b->cq_ctrl.p, 0, 256, b->stream));
+        HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+        BatchParams pq = bp; pq.cont_out = b->contA.as<ba::PairCont>(); pq.cont_out_flag = flagA;
+        pq.cq_queue = b->cq_queue.as<uint32_t>(); pq.cq_ctrl = b->cq_ctrl.as<uint32_t>(); pq.cq_producers = b->quad_grid * ba::WAVES_PER_WG;
+        pq.work_chunk = 4;   // (one position per slot: pairs come longest first, and a long chunk would queue the longest pairs on one wave)
+        HIP_TRY(g_launch_quad[b->kind](tr, xd, b->quad_grid, b->stream, &pq));
+        // (the pairs that reach the per-pair kernel -- with X-drop all of them, since termination is not a plain shift step: their
+        // paths go to a second k_walk; without, only the pairs that grow: lane 0 walks each at once, nothing is left for the end)
+        const bool walk2 = tr && bp.cig_ops && xd;
+        pq.inline_len2 = walk2 ? ~0u : 0u;
+        BatchParams pc = pq; pc.cont_mode = 2; pc.cont_in = b->contA.as<ba::PairCont>(); pc.cont_in_flag = flagA; pc.cont_out = nullptr; pc.cont_out_flag = nullptr;
+        // Beside k_quad -- global alignments only: there the pairs that leave are the ones that grow, few and each a long serial
+        // chain (protein pairs, 400k: 905 -> 1350 GCUPS; PSSM 80k: 349 -> 432); with X-drop every pair leaves and the per-pair
+        // kernel has a full machine's worth of work after k_quad anyway (1 kbp DNA: 1320 -> 1226 with the side launch).
+        // (launched after k_quad: a kernel that only waits must never be the one that holds the device)
+        const bool beside = (!xd || getenv("BA_CQ_BESIDE")) && !getenv("BA_CQ_AFTER");
+        if (beside) {
+            BatchParams pa = pc; pa.ckpt_wave0 = b->grid * ba::WAVES_PER_WG;
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
-            BatchParams w1 = bp; w1.cont_mode = 1; w1.cont_in_flag = flagA; w1.work_counter = b->counter.as<uint32_t>() + 8;   // (zeroed with the first counter above)
-            HIP_TRY(ba_launch_walk(b->stream2, &w1, walk_grid(b)));
+            HIP_TRY(launch(tr, xd, b->cq_grid, b->lds, b->stream2, &pa));
             HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
         }
-        HIP_TRY(launch(tr, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p3));
-        if (walk) {
-            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 4, b->stream));
-            BatchParams w2 = bp; w2.cont_mode = 2; w2.cont_in_flag = flagA;
+        if (tr && bp.cig_ops) {
+            BatchParams w1 = bp; w1.cont_mode = 1; w1.cont_in_flag = flagA; w1.work_counter = b->counter.as<uint32_t>() + 8;   // (its own counter, zeroed above)
+            HIP_TRY(ba_launch_walk(b->stream, &w1, walk_grid(b)));
+        }
+        HIP_TRY(launch(tr, xd, b->grid, b->lds, b->stream, &pc));
+        if (beside) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+        if (walk2) {
+            BatchParams w2 = bp; w2.cont_mode = 2; w2.cont_in_flag = flagA; w2.work_counter = b->counter.as<uint32_t>() + 12;
             HIP_TRY(ba_launch_walk(b->stream, &w2, walk_grid(b)));
-            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
         }
     } else if (b->pipe) {   // pair-slot batch: the fill stacks, k_walk walks
-        BatchParams p1 = bp; p1.cig_ops = nullptr;
+        BatchParams p1 = bp; p1.cig_ops = nullptr; p1.inline_len2 = ~0u;
         HIP_TRY(launch(1, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
         if (bp.cig_ops) {
             HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
@@ -867,6 +896,11 @@ static int batch_wait(BaBatch* b, float* kernel_ms) {
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));
     b->in_flight = false;
     b->retried = 0;
+    if (b->quad) {
+        uint32_t gave_up = 0;
+        HIP_TRY(hipMemcpy(&gave_up, b->cq_ctrl.as<uint32_t>() + 48, 4, hipMemcpyDeviceToHost));
+        if (gave_up) return fail("a per-pair kernel gave up waiting for the small-block kernel's queue");
+    }
     if (b->adaptive) {   // pairs whose trace stack outgrew the expected size: once more, with the reference's full bound
         std::vector<uint32_t> st(b->n), again;
         if (d2h(b->status, st.data(), b->n)) return 1;

@@ -58,7 +58,7 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
 // four pairs per wave while the block is 32 cells (ba_quad.hpp): one kernel per kind
 #include "ba_quad.hpp"
 template <bool TRACE, bool XDROP>
-static hipError_t launch_quad(hipStream_t s, const ba::BatchParams& bp) {
+static hipError_t quad_grid(unsigned* grid) {
     const unsigned lds = ba::lds_table_bytes_h(BA_KIND) + ba::WAVES_PER_WG * 4 * ba::QUAD_SLOT_BYTES;
     int per_cu = 0, dev = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba::k_quad<BA_KIND, TRACE, XDROP>, ba::WAVES_PER_WG * 64, lds);
@@ -67,12 +67,23 @@ static hipError_t launch_quad(hipStream_t s, const ba::BatchParams& bp) {
     if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
-    ba::k_quad<BA_KIND, TRACE, XDROP><<<dim3(prop.multiProcessorCount * per_cu), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    *grid = (unsigned)(prop.multiProcessorCount * per_cu);
+    return hipSuccess;
+}
+template <bool TRACE, bool XDROP>
+static hipError_t launch_quad(unsigned grid, hipStream_t s, const ba::BatchParams& bp) {
+    const unsigned lds = ba::lds_table_bytes_h(BA_KIND) + ba::WAVES_PER_WG * 4 * ba::QUAD_SLOT_BYTES;
+    ba::k_quad<BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
     return hipGetLastError();
 }
-extern "C" hipError_t BA_CAT(ba_launch_quad_k, BA_KIND, , )(int trace, int xdrop, hipStream_t s, const ba::BatchParams* bp) {
-    if (trace) return xdrop ? launch_quad<true, true>(s, *bp) : launch_quad<true, false>(s, *bp);
-    return xdrop ? launch_quad<false, true>(s, *bp) : launch_quad<false, false>(s, *bp);
+// grid: workgroups, from ba_quad_grid_k* (bp->cq_producers must be grid * WAVES_PER_WG)
+extern "C" hipError_t BA_CAT(ba_launch_quad_k, BA_KIND, , )(int trace, int xdrop, unsigned grid, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch_quad<true, true>(grid, s, *bp) : launch_quad<true, false>(grid, s, *bp);
+    return xdrop ? launch_quad<false, true>(grid, s, *bp) : launch_quad<false, false>(grid, s, *bp);
+}
+extern "C" hipError_t BA_CAT(ba_quad_grid_k, BA_KIND, , )(int trace, int xdrop, unsigned* grid) {
+    if (trace) return xdrop ? quad_grid<true, true>(grid) : quad_grid<true, false>(grid);
+    return xdrop ? quad_grid<false, true>(grid) : quad_grid<false, false>(grid);
 }
 #endif
 

@@ -87,10 +87,17 @@ struct BatchParams {
     SlotInfo* slot_info;         // per slot: what the traceback lane needs
     // small-block batches (min block 32): k_quad starts every pair and runs its plain shift steps at 32 cells; a pair that needs
     // anything else leaves as a PairCont record (cont_out, indexed by the pair's position in the batch; cont_out_flag[p] = 1), a
-    // pair k_quad cannot start gets flag 2, a finished one stays 0. The per-pair kernel then runs with cont_mode = 2 over cont_in.
-    uint32_t cont_mode;          // 0 plain; 2 resume from cont_in / run flagged pairs from scratch
+    // pair k_quad cannot start gets flag 2, a finished one stays 0; every flagged pair is also appended to the queue cq_*, which
+    // per-pair kernels launched with cont_mode = 2 drain -- one of them while k_quad is still running.
+    uint32_t cont_mode;          // k_align: 0 plain, 2 take pairs from the queue (resume from cont_in / from scratch).
+                                 // k_walk: 0 every pair, 1 only the pairs with cont_in_flag 0 (finished by k_quad)
     const PairCont* cont_in; const uint32_t* cont_in_flag;
     PairCont* cont_out; uint32_t* cont_out_flag;
+    uint32_t* cq_queue;          // n entries: 1 + 2 * pair + (1: run from scratch), 0 = not yet written
+    uint32_t* cq_ctrl;           // [0] tail (entries appended), [16] head (tickets handed out), [32] producer waves done, [48] consumer gave up
+    uint32_t cq_producers;       // k_quad waves of the launch
+    uint32_t inline_len2;        // pair-slot batches, per-pair kernel: pairs with |q| + |r| >= this walk their paths at once (lane 0), shorter ones leave them to k_walk
+    uint32_t ckpt_wave0;         // this launch's first wave in the checkpoint arena (two per-pair kernels of one batch run side by side)
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;

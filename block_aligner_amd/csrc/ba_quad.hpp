@@ -100,7 +100,7 @@ __device__ __forceinline__ void quad_rect(const char* table, const FillConsts& f
             const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);
             tacc = (int)(((uint32_t)tacc >> 4) | (nib & 0xF000F000u));
             if ((j & 3) == 3) {
-                if (store) tout[(j >> 2) * (QUAD_B / 2) + l] = (uint32_t)tacc;
+                if (store) __hip_atomic_store(tout + (j >> 2) * (QUAD_B / 2) + l, (uint32_t)tacc, BA_RLX_AGENT);   // (through the L2: see k_quad's wt())
                 tacc = 0;
             }
         }
@@ -207,6 +207,15 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter (wave-uniform)
     bool more = true;
 
+    // What a pair's next kernel reads while this one is still running (records, trace words, rectangle records) is written with
+    // agent-scope stores: they go through this XCD's L2 to memory, so that publishing a record needs no release fence -- which
+    // would write back every dirty line of the L2 -- only the wait for the stores' completion.
+    auto wt = [](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, BA_RLX_AGENT); };
+    // a pair for the per-pair kernel: its queue entry (1 + 2 * pair + from-scratch bit), ba_params.h
+    auto enqueue = [&](uint32_t entry) {
+        const uint32_t pos = __hip_atomic_fetch_add(bp.cq_ctrl, 1u, BA_RLX_AGENT);
+        __hip_atomic_store(bp.cq_queue + pos, entry, BA_RLX_AGENT);
+    };
     for (;;) {
         // ---- idle slots take the next pairs of the batch. A pair starts here, with its first block (boot, below); pairs shorter
         // than a block in either dimension are the per-pair kernel's from the start (flag 2: no record, run it from scratch)
@@ -227,7 +236,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             w_next += take;
             if (idle && rank < take) {
                 qlen = bp.q_len[idx]; rlen = bp.r_len[idx];
-                if (qlen < (uint32_t)QUAD_B || rlen < (uint32_t)QUAD_B) { if (l == 0) bp.cont_out_flag[idx] = 2u; }
+                if (qlen < (uint32_t)QUAD_B || rlen < (uint32_t)QUAD_B) { if (l == 0) { bp.cont_out_flag[idx] = 2u; enqueue(2u * idx + 2u); } }
                 else {
                     pair = idx;
                     // the state Block::align starts from (scan_block.rs:123-146), seen as four right steps of 8 columns that
@@ -329,7 +338,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             BlockRec br;   // (the first block: one record for the 32 x 32 rectangle, its four sub-steps' trace words are contiguous)
             br.i = right ? ri : rj; br.j = right ? rj : ri; br.h = (uint16_t)(right ? QUAD_B : STEP); br.w = (uint16_t)(right ? (boot ? QUAD_B : STEP) : QUAD_B);
             br.trace_base = trace_top | (right ? 0x80000000u : 0u);
-            bl[nblocks] = br;
+            uint32_t* w = (uint32_t*)(bl + nblocks);
+            wt(w, br.i); wt(w + 1, br.j); wt(w + 2, (uint32_t)br.h | ((uint32_t)br.w << 16)); wt(w + 3, br.trace_base);
         }
         quad_rect<KIND, TRACE, XDROP>(smem, fc, l, Ad, Ac, Pd, Pr, Pl, sink, vc & 0xff, (vc >> 8) & 0xff, cb_lo, cb_hi, corner, off_add,
                                       run ? (boot ? -1 : loc_thr) : 0x7fffffff, tr + trace_top, run, run && boot == NBOOT && l == 0, o, dcol, &pq);
@@ -376,7 +386,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             if (fin) pair = ~0u;
         }
         leave = leave || (run && stop && !bsub && !blast && !fin);
-        if (fresh) { if (l == 0) bp.cont_out_flag[pair] = 2u; pair = ~0u; boot = 0; }
+        if (fresh) { if (l == 0) { bp.cont_out_flag[pair] = 2u; enqueue(2u * pair + 2u); } pair = ~0u; boot = 0; }
         if (bsub) {
             Dcol = Ad; Ccol = Ac; Drow = Pd; Rrow = Pr;
             sj += STEP; nsteps++; boot--;
@@ -386,18 +396,28 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
         // ---- slots that leave: their state as it was at the top of this step
         if (__any(leave)) {
             if (leave) {
+                // (agent-scope stores, see wt(): the per-pair kernel that takes the record may already be running, on another XCD)
                 PairCont* c = bp.cont_out + pair;
-                if (l == 0) {
-                    bp.cont_out_flag[pair] = 1u;
-                    c->pair = pair; c->si = si; c->sj = sj; c->dir = dir; c->prev_dir = prev_dir; c->off = off; c->off_max = off_max; c->best_max = best_max;
-                    c->y_drop_iter = y_drop; c->x_drop_iter = x_iter; c->D_corner = D_corner; c->best_i = best_i; c->best_j = best_j;
-                    c->ck_i = ck_i; c->ck_j = ck_j; c->ck_off = ck_off; c->cells = cells0 + (unsigned long long)nsteps * (STEP * QUAD_B); c->step_budget = budget;
-                    if (TRACE) { c->trace_top = trace_top; c->nblocks = nblocks; c->ck_trace_top = ck_tt; c->ck_nblocks = ck_nb; c->status = 0; }
+                uint32_t* w = (uint32_t*)c;   // the 24 header words: lane k of the slot writes words k and 16 + k
+                const unsigned long long cells = cells0 + (unsigned long long)nsteps * (STEP * QUAD_B);
+                uint32_t h0 = 0, h1 = 0;
+                switch (l) {
+                    case 0: h0 = pair; h1 = (uint32_t)cells; break;            case 1: h0 = si; h1 = (uint32_t)(cells >> 32); break;
+                    case 2: h0 = sj; h1 = budget; break;                        case 3: h0 = (uint32_t)dir; h1 = trace_top; break;
+                    case 4: h0 = (uint32_t)prev_dir; h1 = nblocks; break;       case 5: h0 = (uint32_t)off; h1 = ck_tt; break;
+                    case 6: h0 = (uint32_t)off_max; h1 = ck_nb; break;          case 7: h0 = (uint32_t)best_max; h1 = 0; break;
+                    case 8: h0 = y_drop; break;       case 9: h0 = (uint32_t)x_iter; break;   case 10: h0 = (uint32_t)D_corner; break;
+                    case 11: h0 = best_i; break;      case 12: h0 = best_j; break;            case 13: h0 = ck_i; break;
+                    case 14: h0 = ck_j; break;        default: h0 = (uint32_t)ck_off; break;
                 }
-                c->borders[0][l] = (uint32_t)Dcol; c->borders[1][l] = (uint32_t)Ccol; c->borders[2][l] = (uint32_t)Drow; c->borders[3][l] = (uint32_t)Rrow;
-                c->ckpt[0][l] = (uint32_t)ck0; c->ckpt[1][l] = (uint32_t)ck1; c->ckpt[2][l] = (uint32_t)ck2; c->ckpt[3][l] = (uint32_t)ck3;
-                pair = ~0u;
+                wt(w + l, h0);
+                if (l < 8) wt(w + 16 + l, h1);
+                if (l == 0) bp.cont_out_flag[pair] = 1u;
+                wt(&c->borders[0][l], (uint32_t)Dcol); wt(&c->borders[1][l], (uint32_t)Ccol); wt(&c->borders[2][l], (uint32_t)Drow); wt(&c->borders[3][l], (uint32_t)Rrow);
+                wt(&c->ckpt[0][l], (uint32_t)ck0); wt(&c->ckpt[1][l], (uint32_t)ck1); wt(&c->ckpt[2][l], (uint32_t)ck2); wt(&c->ckpt[3][l], (uint32_t)ck3);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the records (and the pairs' trace words) have arrived before their queue entries go out
+            if (leave) { if (l == 0) enqueue(2u * pair + 1u); pair = ~0u; }
         }
         // ---- slots that go on: commit the step
         if (commit) {
@@ -424,6 +444,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
             boot = 0;
         }
     }
+    // this producer is done: every entry of the wave is in the queue before the count says so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(bp.cq_ctrl + 32, 1u, BA_RLX_AGENT);
 }
 
 }  // namespace ba
