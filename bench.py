@@ -279,7 +279,7 @@ def main():
                 secondary.append(secondary_line(np, H, W, o, c4, cores))
                 c4.mode = ("trace",); c4.name += ", traceback"
                 secondary.append(secondary_line(np, H, W, o, c4, cores))
-                secondary.append(secondary_line(np, H, W, o, W.config5(20000), cores))
+                secondary.append(secondary_line(np, H, W, o, W.config5(80000), cores))
         out = {
             "metric": "GCUPS (DP cells/s) on 10 kbp DNA X-drop batch; bit-exact score+CIGAR vs AVX2",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -173,10 +173,10 @@ struct TbLane {
     uint64_t wp, lo;
     const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
     uint32_t bi, bj, tbase, zoff, nch, nl; bool right, in_rect;
-    // look-ahead state: the next rectangle record; what the LDS record of this lane currently holds: a 5-lane x
+    // look-ahead state: the next rectangle records; what the LDS record of this lane currently holds: a 5-lane x
     // 2-column-group window of trace words (chunk tw_chunk, column groups tw_g and tw_g - 1, lanes from tw_lane0) and
     // 16-byte windows of both sequences ([qw0, qw0 + 16), [rw0, rw0 + 16); 0xffffffff = empty)
-    uint4 nrec; bool nrec_ok;
+    uint4 nrec[4]; uint32_t nq;   // the next nq records of the stack (below bidx), fetched ahead
     uint32_t tw_chunk, tw_g, tw_lane0; bool tw_ok;
     uint32_t qw0, rw0;
 };
@@ -201,29 +201,49 @@ constexpr int TB_CELLS_PER_STEP = 4;
 #ifndef BA_WALK_CELLS
 #define BA_WALK_CELLS 8
 #endif
-template <int CELLS = TB_CELLS_PER_STEP>
+// DEPTH: rectangle records fetched ahead. A path skips rectangles (a right strip's left neighbour on the path is an earlier right
+// strip, the down strips in between are not on it): with DEPTH > 1 a call walks down the stack past them instead of spending one
+// call -- one memory round trip of its wave -- on each.
+template <int CELLS = TB_CELLS_PER_STEP, int DEPTH = 1>
 __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned char* lrec,
                                         const unsigned char* lut, unsigned long long* tacc = nullptr) {
     const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
     BA_TSTAMP(ts0);
     bool fresh = true;   // LOCAL_START only: may this call still issue a direct load?
     if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
-        if (t.bidx == 0) { tb_fail(t); return; }
-        t.bidx--;
-        const uint4 rec = t.nrec_ok ? t.nrec : *(const uint4*)(t.blocks + t.bidx);
-        t.nrec_ok = t.bidx > 0;
-        if (t.nrec_ok) t.nrec = *(const uint4*)(t.blocks + t.bidx - 1);
-        t.bi = rec.x; t.bj = rec.y;
-        const uint32_t h = rec.z & 0xffffu, w = rec.z >> 16;
-        t.in_rect = t.i >= t.bi && t.j >= t.bj;
-        t.zoff = h * w / 8;
-        t.right = rec.w >> 31;
-        t.tbase = rec.w & 0x3fffffffu;
-        const uint32_t Hv = t.right ? h : w;
-        t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
+        bool found = false, untraced = false;
+#pragma unroll
+        for (int a = 0; a < DEPTH; a++) {
+            if (!found && (a == 0 || t.nq)) {   // (beyond the first record only out of the look-ahead queue: one round of memory latency per call)
+                if (t.bidx == 0) { tb_fail(t); return; }
+                uint4 rec;
+                if (t.nq) {
+                    rec = t.nrec[0];
+#pragma unroll
+                    for (int k = 0; k + 1 < DEPTH; k++) t.nrec[k] = t.nrec[k + 1];
+                    t.nq--;
+                } else rec = *(const uint4*)(t.blocks + t.bidx - 1);
+                t.bidx--;
+                t.bi = rec.x; t.bj = rec.y;
+                const uint32_t h = rec.z & 0xffffu, w = rec.z >> 16;
+                t.in_rect = t.i >= t.bi && t.j >= t.bj;
+                t.zoff = h * w / 8;
+                t.right = rec.w >> 31;
+                t.tbase = rec.w & 0x3fffffffu;
+                const uint32_t Hv = t.right ? h : w;
+                t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
+                untraced = rec.w & 0x40000000u;
+                found = t.in_rect;
+            }
+        }
+        if (t.nq == 0 && t.bidx > 0) {   // the next records, in flight while this call waits for its trace words
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) if (t.bidx > (uint32_t)k) t.nrec[k] = *(const uint4*)(t.blocks + t.bidx - 1 - k);
+            t.nq = min((uint32_t)DEPTH, t.bidx);
+        }
         t.tw_ok = false;
         if (!t.in_rect) return;
-        if (rec.w & 0x40000000u) { tb_fail(t); return; }   // a speculative grow that was never materialised: must not be on a path
+        if (untraced) { tb_fail(t); return; }   // a speculative grow that was never materialised: must not be on a path
     }
     {
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
@@ -511,7 +531,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
         }
         if (!__any(walking)) break;
         if (walking) {
-            if (t.i > 0 || t.j > 0) tb_step<BA_WALK_CELLS>(t, eq, bp.cig_ops, lrec, lut);   // (no fill wave shares the SIMD here: a call walks on while its window lasts)
+            if (t.i > 0 || t.j > 0) tb_step<BA_WALK_CELLS, 4>(t, eq, bp.cig_ops, lrec, lut);   // (no fill wave shares the SIMD here: a call walks on while its window lasts)
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
                 bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);

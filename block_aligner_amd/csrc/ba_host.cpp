@@ -667,13 +667,13 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // ---- launch geometry: one wave per workgroup, as many resident waves as LDS / registers allow
     uint64_t sum_len2 = 0;
     for (size_t p = 0; p < n; p++) sum_len2 += (uint64_t)ql[p] + rl[p];
-    // Small blocks: a 32-cell block keeps 16 of a wave's 64 lanes busy, so batches that start at 32 cells run their plain shift
-    // steps four pairs to a wave (k_quad) between two passes of the per-pair kernel (see batch_launch).
-    // (Measured, score only: 1 kbp DNA at ~90 % identity, 200k pairs: 606 -> 1353 GCUPS. Protein pairs at 30..100 % identity leave
-    // k_quad at their first grow and the two extra passes each bring a launch tail: 100k pairs 540 -> 485, 200k 589 -> 725,
-    // 800k 597 -> 983. Hence amino-acid batches take the pipeline from 131072 pairs on; BA_FORCE_QUAD / BA_NO_QUAD override.)
-    b->quad = !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") &&
-              (getenv("BA_FORCE_QUAD") || n >= (kind == BA_KIND_AA ? 131072u : 2048u));
+    // Small blocks: a 32-cell block keeps 16 of a wave's 64 lanes busy, so batches that start at 32 cells begin in k_quad, four
+    // pairs to a wave, and only the pairs that need more than plain shift steps go on to the per-pair kernel (see batch_launch).
+    // Small batches are bound by their longest pair's chain of steps, which the hand-over only lengthens: the pipeline is taken
+    // from the sizes where it wins (measured, GCUPS with / without: protein pairs 32k 371 / 405, 64k 745 / 527, 400k 1375 / 597;
+    // PSSM 8k 108 / 105, 20k 211 / 162, 80k 458 / 172; 1 kbp DNA 200k 1347 / 606). BA_FORCE_QUAD / BA_NO_QUAD override.
+    const size_t quad_from = kind == BA_KIND_AA ? 65536u : (profile ? 8192u : 2048u);
+    b->quad = !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") && (getenv("BA_FORCE_QUAD") || n >= quad_from);
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
     // blocks take it in place of the hand-off ring (50..500 positions, 20k pairs: 143 -> 158 GCUPS, 80k: 172 -> 225). Short
