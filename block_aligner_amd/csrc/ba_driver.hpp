@@ -1336,8 +1336,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                         if (ticket >= (uint32_t)uni((int)tail)) break;
                     }
                     if (done >= bp.cq_producers) { closing = true; continue; }
-                    if (++spins > (1u << 21)) {   // several seconds without the producers finishing: report, do not hang
-                        if (is_lane(0)) __hip_atomic_store(bp.cq_ctrl + 48, 1u, BA_RLX_AGENT);
+                    if (++spins > (1u << 21)) {   // several seconds without the producers finishing: never hang. The launch beside k_quad
+                        // just ends (the launch after k_quad drains the queue); for that one the producers are done: report
+                        if (!bp.cq_side && is_lane(0)) __hip_atomic_store(bp.cq_ctrl + 48, 1u, BA_RLX_AGENT);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(32);

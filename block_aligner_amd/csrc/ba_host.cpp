@@ -770,7 +770,9 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
 static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves x 64 walking lanes each)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) return 1;
-    return std::min((b->n + 255u) / 256u, (uint32_t)prop.multiProcessorCount * 8u);
+    uint32_t per_cu = 8;
+    if (const char* env = getenv("BA_WALK_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = (uint32_t)v; }
+    return std::min((b->n + 255u) / 256u, (uint32_t)prop.multiProcessorCount * per_cu);
 }
 static int batch_launch(BaBatch* b) {
     if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");
@@ -814,7 +816,7 @@ static int batch_launch(BaBatch* b) {
         // (launched after k_quad: a kernel that only waits must never be the one that holds the device)
         const bool beside = (!xd || getenv("BA_CQ_BESIDE")) && !getenv("BA_CQ_AFTER");
         if (beside) {
-            BatchParams pa = pc; pa.ckpt_wave0 = b->grid * ba::WAVES_PER_WG;
+            BatchParams pa = pc; pa.ckpt_wave0 = b->grid * ba::WAVES_PER_WG; pa.cq_side = 1;
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
             HIP_TRY(launch(tr, xd, b->cq_grid, b->lds, b->stream2, &pa));
             HIP_TRY(hipEventRecord(b->ev_join, b->stream2));

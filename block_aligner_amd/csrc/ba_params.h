@@ -96,6 +96,7 @@ struct BatchParams {
     uint32_t* cq_queue;          // n entries: 1 + 2 * pair + (1: run from scratch), 0 = not yet written
     uint32_t* cq_ctrl;           // [0] tail (entries appended), [16] head (tickets handed out), [32] producer waves done, [48] consumer gave up
     uint32_t cq_producers;       // k_quad waves of the launch
+    uint32_t cq_side;            // 1: this per-pair launch runs beside k_quad (it may stop waiting; the launch after k_quad drains the queue)
     uint32_t inline_len2;        // pair-slot batches, per-pair kernel: pairs with |q| + |r| >= this walk their paths at once (lane 0), shorter ones leave them to k_walk
     uint32_t ckpt_wave0;         // this launch's first wave in the checkpoint arena (two per-pair kernels of one batch run side by side)
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)

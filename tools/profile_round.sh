@@ -22,5 +22,13 @@ run kernel_trace_stats --kernel-trace --stats -d /tmp/prof_kernel_trace_stats -o
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_pmc_fetch -o f -- python3 $B --steps 1 --warmup 0
 run pmc_write --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_pmc_write -o w -- python3 $B --steps 1 --warmup 0
 run pmc_sq --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d /tmp/prof_pmc_sq -o s -- python3 $B --steps 1 --warmup 0
+# 3. the side configurations (32..256 blocks: k_quad / k_align / k_walk), kernel trace only            -> gpurun_out/<tag>_sec_<config>.md
+for cfg in "c2 200000" "c2t 200000" "c4 400000" "c4t 400000" "c5 80000"; do
+  set -- $cfg
+  rm -rf /tmp/prof_sec_$1
+  BA_GEN_WORKERS=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_sec_$1 -o kt -- python3 tools/dev/sec.py $1 $2 > $out/${tag}_sec_$1.log 2>&1
+  db=$(find /tmp/prof_sec_$1 -name '*.db' | head -1)
+  [ -n "$db" ] && python3 tools/prof_summary.py "$db" $out/${tag}_sec_$1.md "round ${tag#r}: rocprofv3 --kernel-trace --stats -- python3 tools/dev/sec.py $1 $2 ($(grep GCUPS $out/${tag}_sec_$1.log | tail -1))" > /dev/null
+done
 python3 tools/traffic_from_pmc.py $out/${tag}_pmc_fetch.md $out/${tag}_pmc_write.md $pairs > $out/${tag}_traffic.json
 ls -la $out
