@@ -201,6 +201,9 @@ constexpr int TB_CELLS_PER_STEP = 4;
 #ifndef BA_WALK_CELLS
 #define BA_WALK_CELLS 8
 #endif
+#ifndef BA_WALK_DEPTH
+#define BA_WALK_DEPTH 4
+#endif
 // DEPTH: rectangle records fetched ahead. A path skips rectangles (a right strip's left neighbour on the path is an earlier right
 // strip, the down strips in between are not on it): with DEPTH > 1 a call walks down the stack past them instead of spending one
 // call -- one memory round trip of its wave -- on each.
@@ -531,7 +534,12 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
         }
         if (!__any(walking)) break;
         if (walking) {
-            if (t.i > 0 || t.j > 0) tb_step<BA_WALK_CELLS, 4>(t, eq, bp.cig_ops, lrec, lut);   // (no fill wave shares the SIMD here: a call walks on while its window lasts)
+            // (no fill wave shares the SIMD here: a call walks on while its window lasts; the mode bits as constants: a walk is a
+            // serial chain of ~200 instructions per cell whose length, for the batch's longest pair, ends the launch)
+            if (t.i > 0 || t.j > 0) {
+                if (eq) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH>(t, (uint32_t)F_CIGAR_EQ, bp.cig_ops, lrec, lut);
+                else tb_step<BA_WALK_CELLS, BA_WALK_DEPTH>(t, 0u, bp.cig_ops, lrec, lut);
+            }
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
                 bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
