@@ -201,6 +201,9 @@ constexpr int TB_CELLS_PER_STEP = 4;
 #ifndef BA_WALK_CELLS
 #define BA_WALK_CELLS 8
 #endif
+#ifndef BA_RING_DEPTH
+#define BA_RING_DEPTH 2   // (config 3, same box: 1503 -> 1507 GCUPS)
+#endif
 #ifndef BA_WALK_DEPTH
 #define BA_WALK_DEPTH 4
 #endif
@@ -453,7 +456,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
             if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut, c_sec);
             c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
 #else
-            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut);
+            if (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH>(t, eq, bp.cig_ops, lrec, lut);
 #endif
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
