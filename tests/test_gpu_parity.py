@@ -657,6 +657,35 @@ def test_pair_slot_batches_without_small_blocks(hip, oracle, monkeypatch, mode):
     compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 256), 40, mode, cigar_eq=False)
 
 
+@pytest.mark.parametrize("mode", [(), ("trace",)])
+def test_small_block_batches_in_flight_together(hip, oracle, monkeypatch, mode):
+    """Three small-block batches of global alignments launched back to back, each with its k_quad, the per-pair kernel beside it
+    (which waits on k_quad's queue) and the one after it, on their own streams; then collected. Whatever order the device runs
+    the kernels in, every batch's results are the oracle's -- a side launch that cannot get its k_quad going gives way."""
+    monkeypatch.setenv("BA_FORCE_QUAD", "1")
+    m = hip.TRACE if mode else 0
+    sets = [synth.make_pairs(3000, (22, 700), (0, 200), 0, synth.AMINO, seed=900 + k) for k in range(3)]
+    batches = [hip.BatchAligner(S.BLOSUM62, (-11, -1), (32, 256), 0, m, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len) for ps in sets]
+    for rnd in range(2):
+        for b in batches:
+            b.launch()
+        for b in batches:
+            b.wait()
+        for b, ps in zip(batches, sets):
+            res = b.results()
+            assert not res["status"].any()
+            ref = oracle.batch_align(S.BLOSUM62, ps.pool, ps.q_off, ps.q_len, ps.r_off, ps.r_len, (-11, -1), (32, 256), 0, mode, cigar_eq=False, threads=8)
+            assert np.array_equal(res["score"], ref["scores"]) and int(res["cells"].sum()) == ref["cells"]
+            if mode:
+                assert np.array_equal(res["cigar_len"], ref["cig_len"])
+                runs, off = b.cigars(res["cigar_len"])
+                for p in range(0, len(ps), 7):
+                    want = ref["cig_ops"][int(ref["cig_off"][p]): int(ref["cig_off"][p]) + int(ref["cig_len"][p])]
+                    assert np.array_equal(runs[int(off[p]): int(off[p + 1])], want), (rnd, p)
+    for b in batches:
+        b.close()
+
+
 @pytest.mark.parametrize("margin", ["3", "60"])
 def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, monkeypatch, margin):
     """The TRACE form of the small-block pipeline cuts the trace arena into one region per pair, sized for the pair's expected
