@@ -566,10 +566,10 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         b->slots_per_wave = spw;
         // The last hand-offs of the batch go to fill waves that have run out of pairs (one walking lane per wave, on
         // SIMDs with nothing else left to do): a walk alone is much shorter than one among 40 in lockstep, and the
-        // batch ends one walk after its last fill. Three quarters of the fill waves (measured at config 3: flat between
-        // 3000 and 3500 of 3968, 1 % slower at 2000 or 6000); fewer than all of them, so the fill waves can never all be
+        // batch ends one walk after its last fill. Half of the fill waves (measured at config 3 with 3968 of them: flat between
+        // 1000 and 2500, 0.6 % slower at 3000, more below 500); fewer than all of them, so the fill waves can never all be
         // waiting for trace slots whose walks are reserved for helpers that do not exist yet.
-        b->tb_reserve = b->n_fill_waves / 4 * 3;
+        b->tb_reserve = b->n_fill_waves / 2;
         // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
         // less of the batch to walkers that only exist once the first wave has run out of pairs
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
