@@ -1043,7 +1043,7 @@ int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
     HIP_TRY(hipMemcpy(runs, d_out.p, total * 4, hipMemcpyDeviceToHost));
     return 0;
 }
-int ba_batch_prof(BaBatch* b, uint64_t out[128]) {   // development: phase timers of a -DBA_TIMING build (second half: pass 3 of a small-block batch)
+int ba_batch_prof(BaBatch* b, uint64_t out[128]) {   // development: phase timers of a -DBA_TIMING build (all per-pair launches of a batch add up)
     if (!b) return fail("null batch");
     HIP_TRY(hipMemcpy(out, b->prof.p, 1024, hipMemcpyDeviceToHost));
     return 0;

@@ -1,5 +1,5 @@
 """Per-pair phase times of a secondary configuration from a -DBA_TIMING build (libblock_aligner_hip_timing.so):
-python tools/dev/sec_timing.py [c2|c2t|c4|c4t|c5] [pairs]. Small-block batches: pass 1 and pass 3 separately."""
+python tools/dev/sec_timing.py [c2|c2t|c4|c4t|c5] [pairs]. (The per-pair launches of a small-block batch add into one set of timers.)"""
 import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,7 +14,7 @@ H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
 H.lib().ba_batch_prof(b._h, prof.ctypes.data)
 names = {44: "pair taken -> run()", 45: "run()", 47: "run(): before the step loop", 15: "run(): step loop", 12: "  rect setup", 13: "  place", 14: "  post-step", 17: "slot wait"}
 print(f"{which} n={n} kernel {ms:.3f} ms (timing build); s_memtime ticks = 10 ns")
-for ps, base in (("pass 1 / only pass", 0), ("pass 3", 64)):
+for ps, base in (("per-pair kernel", 0),):
     pairs = float(prof[base + 46])
     if not pairs:
         continue
