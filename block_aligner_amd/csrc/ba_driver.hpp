@@ -257,14 +257,17 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         const uint32_t chunk = v >> 7, lc = (v & 127) >> 1, g = w >> 2;
         if (!local && !(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u)) {
             // the two column groups ending at the cell's and the five lanes ending at the cell's
-            t.tw_chunk = chunk; t.tw_g = g; t.tw_lane0 = lc >= 4 ? lc - 4 : 0; t.tw_ok = true;
-            const uint32_t* hi = t.trace + t.tbase + (g * t.nch + chunk) * t.nl;
+            // (five consecutive words per group: one 16-byte and one 4-byte load each -- the walks of a wave are in 64 different
+            // places, so every load instruction is 64 transactions; the window is pushed down where it would pass the last lane)
+            t.tw_chunk = chunk; t.tw_g = g; t.tw_lane0 = min(lc >= 4 ? lc - 4 : 0u, t.nl - 5u); t.tw_ok = true;   // (nl >= 8)
+            const uint32_t* hi = t.trace + t.tbase + (g * t.nch + chunk) * t.nl + t.tw_lane0;
             const uint32_t* lo = g ? hi - t.nch * t.nl : hi;
             uint32_t wv[10];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const uint32_t l = min(t.tw_lane0 + k, t.nl - 1);
-                wv[k] = hi[l]; wv[5 + k] = lo[l];
+            {
+                uint4 h4, l4;
+                __builtin_memcpy(&h4, hi, 16); __builtin_memcpy(&l4, lo, 16);
+                wv[0] = h4.x; wv[1] = h4.y; wv[2] = h4.z; wv[3] = h4.w; wv[4] = hi[4];
+                wv[5] = l4.x; wv[6] = l4.y; wv[7] = l4.z; wv[8] = l4.w; wv[9] = lo[4];
             }
 #pragma unroll
             for (int k = 0; k < 10; k++) ((uint32_t*)lrec)[k] = wv[k];
