@@ -637,9 +637,9 @@ def test_small_block_pipeline(hip, oracle, monkeypatch, mode):
         compare(hip, oracle, dna, NUC, (-5, -1), size, 60, mode)
     prot = synth.make_pairs(500, (22, 900), (0, 250), 0, synth.AMINO, seed=62)
     compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), (32, 256), 40, mode)
-    if not mode:
+    if "x_drop" not in mode:   # (the byte matrix is documented as inaccurate with X-drop, scores.rs:235-239)
         byt = synth.make_pairs(200, (0, 400), (0, 50), 5, np.frombuffer(b"abcdefghij\x01\xff", np.uint8), seed=63)
-        compare(hip, oracle, byt, S.BYTES1, (-2, -1), (32, 128), 0, ())
+        compare(hip, oracle, byt, S.BYTES1, (-2, -1), (32, 128), 0, mode, cigar_eq=False)
     edge = synth.PairSet.from_lists([(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A" * 40, b"A" * 40), (b"ACGT" * 30, b"ACGT" * 30 + b"TTTT" * 20),
                                      (b"A" * 33, b"T" * 300), (b"ACGTNNNNACGT" * 5, b"ACGTACGT" * 6)] * 8)
     compare(hip, oracle, edge, S.NW1, (-2, -1), (32, 128), 20, mode)
