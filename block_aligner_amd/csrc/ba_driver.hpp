@@ -556,6 +556,29 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     }
 }
 
+// ------------------------------------------------------------------ exchange with the multi-pair kernel (ba_multi.hpp)
+// A pair's driver state at the top of the driver loop (scan_block.rs:123-130's locals), wave-uniform: what travels between a
+// slot of k_multi -- where it lives in the slot's lanes -- and Aligner::run.
+struct PairState {
+    uint32_t si, sj; int dir, prev_dir, off, off_max, best_max; uint32_t y_drop_iter; int x_drop_iter, D_corner;
+    uint32_t best_i, best_j, ck_i, ck_j; int ck_off; uint32_t ck_tt, ck_nb;
+    unsigned long long cells; uint32_t step_budget, trace_top, nblocks, status;
+};
+constexpr uint32_t MQ_B = 128;   // block size of a slot of k_multi
+struct MultiIO {
+    int mode;            // 0: start the pair from scratch; 1: resume from `st` and the slot registers `reg`
+    bool allow_quad;     // the pair may go (back) to its slot once its next step is a plain shift step at MQ_B cells
+    bool forced;         // resume: the step at the top is taken here whatever it is (the slot rolled it back)
+    bool exited;         // out: true = the pair goes on in its slot (st / LDS hold its state), false = it is finished
+    int sel;             // which 16-lane slot of the wave holds the registers
+    PairState st;
+    // resume: the checkpoint registers hold the state BEFORE the last improving step (that step -- direction ck_dir at block
+    // position (st.ck_i, st.ck_j) -- is repeated once here, for the location of its maximum and the borders it leaves)
+    bool ck_pre; int ck_dir, ck_offadd, ck_corner;
+    // the slot's registers, 8 cells per lane in cell order: [0..3] D_col, [4..7] C_col, [8..11] D_row, [12..15] R_row, [16..31] the checkpoint likewise
+    int* reg;
+};
+
 // ------------------------------------------------------------------ driver
 // SPECIAL: the batch uses LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS. A separate instantiation, so the
 // common kernels carry none of that state (it costs registers: +30 % spills when folded into one kernel).
@@ -627,7 +650,7 @@ struct Aligner {
         uint32_t si, sj; int dir, prev_dir, off, prev_off, off_max, off_add, best_max; uint32_t y_drop_iter; int x_drop_iter, D_corner;
         uint32_t step_budget; int run_exit; Best cur; FastOut fo;
     };
-    __device__ __forceinline__ RunState fast_run(const RunState in, int corner, const uint32_t B, const uint32_t min_size, const uint32_t max_size) {
+    __device__ __forceinline__ RunState fast_run(const RunState in, int corner, const uint32_t B, const uint32_t min_size, const uint32_t max_size, const bool one_step = false) {
         uint32_t si = in.si, sj = in.sj; int dir = in.dir, prev_dir = in.prev_dir, off = in.off, prev_off = in.prev_off, off_max = in.off_max;
         int off_add = in.off_add, best_max = in.best_max; uint32_t y_drop_iter = in.y_drop_iter; int x_drop_iter = in.x_drop_iter, D_corner = in.D_corner;
         uint32_t step_budget = in.step_budget; int run_exit = RUN_EXIT_POST; FastOut fo{};
@@ -716,7 +739,8 @@ struct Aligner {
             dir = go_down ? DIR_DOWN : DIR_RIGHT;
 
             // ---- set up the next step (what the top of the driver loop does)
-            if (!fast_eligible(dir == DIR_RIGHT ? si : sj, B, dir == DIR_RIGHT ? qlen : rlen, (dir == DIR_RIGHT ? sj : si) + B - STEP, dir == DIR_RIGHT ? rlen : qlen)) { run_exit = RUN_EXIT_TOP; break; }
+            // (one_step: the multi-pair kernel takes the pair back into its slot for the plain steps that follow)
+            if (one_step || !fast_eligible(dir == DIR_RIGHT ? si : sj, B, dir == DIR_RIGHT ? qlen : rlen, (dir == DIR_RIGHT ? sj : si) + B - STEP, dir == DIR_RIGHT ? rlen : qlen)) { run_exit = RUN_EXIT_TOP; break; }
             if (--step_budget == 0) { status |= ST_WATCHDOG; run_exit = RUN_EXIT_FATAL; break; }
 #ifdef BA_TIMING
             prof[16]++;
@@ -858,7 +882,7 @@ struct Aligner {
     }
 
     // (always inlined: as a real call the Aligner object and everything it references would live in scratch memory)
-    __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr) {
+    __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr, MultiIO* mio = nullptr) {
         BA_TSTAMP(tq0);
         q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
         qlen = coldp()->q_len[pair_in]; rlen = coldp()->r_len[pair_in];
@@ -930,6 +954,56 @@ struct Aligner {
             ck_in_regs = true;
             lds_sync();
         }
+        if (mio && mio->mode == 1) {   // a pair that comes back from its slot of the multi-pair kernel (ba_multi.hpp)
+            const PairState& st = mio->st;
+            si = st.si; sj = st.sj; dir = st.dir; prev_dir = st.prev_dir; off = st.off; off_max = st.off_max; best_max = st.best_max;
+            y_drop_iter = st.y_drop_iter; x_drop_iter = st.x_drop_iter; D_corner = st.D_corner; cells = st.cells; step_budget = st.step_budget;
+            park<5>(parked, (int)st.best_i); park<6>(parked, (int)st.best_j);
+            park<0>(parked, (int)st.ck_i); park<1>(parked, (int)st.ck_j); park<2>(parked, st.ck_off);
+            if (TRACE) { trace_top = st.trace_top; nblocks = st.nblocks; status = st.status; park<3>(parked, (int)st.ck_tt); park<4>(parked, (int)st.ck_nb); }
+            const int lane = lane_id(), l8 = 8 * (lane & 15);
+            const bool mine = (lane >> 4) == mio->sel;
+            const int* rg = mio->reg;
+            auto slot_to_lds = [&](int base) {   // 16 lanes x 4 registers x 2 cells = 128 entries per array, in cell order
+                lds_sync();
+                if (mine) {
+                    *(int4*)(L.D_col + l8) = int4{rg[base + 0], rg[base + 1], rg[base + 2], rg[base + 3]};
+                    *(int4*)(L.C_col + l8) = int4{rg[base + 4], rg[base + 5], rg[base + 6], rg[base + 7]};
+                    *(int4*)(L.D_row + l8) = int4{rg[base + 8], rg[base + 9], rg[base + 10], rg[base + 11]};
+                    *(int4*)(L.R_row + l8) = int4{rg[base + 12], rg[base + 13], rg[base + 14], rg[base + 15]};
+                }
+                lds_sync();
+            };
+            const bool need_ck = MQ_B < max_size;
+            if (mio->ck_pre || need_ck) {
+                slot_to_lds(16);
+                int cDc = *(const int*)(L.D_col + 2 * lane), cCc = *(const int*)(L.C_col + 2 * lane);
+                int cDr = *(const int*)(L.D_row + 2 * lane), cRr = *(const int*)(L.R_row + 2 * lane);
+                lds_sync();
+                if (mio->ck_pre) {
+                    // the last improving step once more (it ran in the slot, which keeps neither the location of a step's maximum nor
+                    // the borders after it, only the state before it): scan_block.rs:370-427 for that step
+                    constexpr int PR_DIST = (int)(lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u) / 2);
+                    const bool cright = mio->ck_dir == DIR_RIGHT;
+                    const uint8_t* seqV = cright ? q : r; const uint8_t* seqC = cright ? r : q;
+                    const uint32_t cri = cright ? st.ck_i : st.ck_j, crj = (cright ? st.ck_j : st.ck_i) + MQ_B - STEP;
+                    const int vc = (int)*(const unsigned short*)(seqV + cri + 2 * lane);
+                    const unsigned long long cb = load_cols(seqC + crj);
+                    FastOut fo{};
+                    if constexpr (KIND != KIND_PROFILE) {
+                        if (cright) fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, 64, mio->ck_corner, mio->ck_offadd, -1, nullptr, fo);
+                        else fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, 64, mio->ck_corner, mio->ck_offadd, -1, nullptr, fo);
+                    }
+                    if (XDROP) {
+                        if (cright) { park<5>(parked, (int)(st.ck_i + (uint32_t)fo.row)); park<6>(parked, (int)(st.ck_j + (MQ_B - STEP) + (uint32_t)fo.col)); }
+                        else { park<5>(parked, (int)(st.ck_i + (MQ_B - STEP) + (uint32_t)fo.col)); park<6>(parked, (int)(st.ck_j + (uint32_t)fo.row)); }
+                    }
+                    lds_sync();
+                }
+                ck_reg[0] = cDc; ck_reg[1] = cCc; ck_reg[2] = cDr; ck_reg[3] = cRr; ck_in_regs = true;
+            }
+            slot_to_lds(0);
+        }
         // speculative grows (see the grow transition below): the checkpoint the chain started from
         uint32_t ub_size = 0, ub_tt = 0, ub_nb = 0, ub_budget = 0; int ub_xiter = 0; unsigned long long ub_cells = 0;
         bool no_spec = false;
@@ -983,6 +1057,33 @@ struct Aligner {
             BA_TSTAMP(tsa);
             const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
+            if (mio && mio->allow_quad && fast && !mio->forced && block_size == MQ_B && min_size == MQ_B && !chain && !no_spec) {
+                // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
+                // four pairs to a wave. The borders are in LDS (cell order); the checkpoint follows them at entries MQ_B .. 2 MQ_B.
+                step_budget++;   // (the step this iteration counted has not been taken)
+                PairState& st = mio->st;
+                st.si = si; st.sj = sj; st.dir = dir; st.prev_dir = prev_dir; st.off = prev_off; st.off_max = off_max; st.best_max = best_max;
+                st.y_drop_iter = y_drop_iter; st.x_drop_iter = x_drop_iter; st.D_corner = D_corner; st.cells = cells; st.step_budget = step_budget;
+                st.best_i = (uint32_t)unpark<5>(parked); st.best_j = (uint32_t)unpark<6>(parked);
+                st.ck_i = (uint32_t)unpark<0>(parked); st.ck_j = (uint32_t)unpark<1>(parked); st.ck_off = unpark<2>(parked);
+                st.ck_tt = (uint32_t)unpark<3>(parked); st.ck_nb = (uint32_t)unpark<4>(parked);
+                st.trace_top = trace_top; st.nblocks = nblocks; st.status = status;
+                if (MQ_B < max_size) {
+                    const uint32_t k = 2 * lane_id(), ms = h_max_size;
+                    lds_sync();
+                    if (ck_in_regs) {
+                        *(int*)(L.D_col + MQ_B + k) = ck_reg[0]; *(int*)(L.C_col + MQ_B + k) = ck_reg[1];
+                        *(int*)(L.D_row + MQ_B + k) = ck_reg[2]; *(int*)(L.R_row + MQ_B + k) = ck_reg[3];
+                    } else {
+                        *(int*)(L.D_col + MQ_B + k) = ckpt_load(ckpt + k); *(int*)(L.C_col + MQ_B + k) = ckpt_load(ckpt + ms + k);
+                        *(int*)(L.D_row + MQ_B + k) = ckpt_load(ckpt + 2 * ms + k); *(int*)(L.R_row + MQ_B + k) = ckpt_load(ckpt + 3 * ms + k);
+                    }
+                    lds_sync();
+                }
+                mio->exited = true;
+                return;
+            }
+            if (mio) mio->forced = false;
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
             const bool spec = TRACE && chain && dir == DIR_GROW;   // this grow step runs without trace flags and location bookkeeping
@@ -1045,7 +1146,7 @@ struct Aligner {
                     rs.si = si; rs.sj = sj; rs.dir = dir; rs.prev_dir = prev_dir; rs.off = off; rs.prev_off = prev_off; rs.off_max = off_max;
                     rs.off_add = off_add; rs.best_max = best_max; rs.y_drop_iter = y_drop_iter; rs.x_drop_iter = x_drop_iter; rs.D_corner = D_corner;
                     rs.step_budget = step_budget; rs.run_exit = RUN_EXIT_POST; rs.cur = cur; rs.fo = fo;
-                    rs = fast_run(rs, corner, block_size, min_size, max_size);
+                    rs = fast_run(rs, corner, block_size, min_size, max_size, mio && mio->allow_quad && block_size == MQ_B && min_size == MQ_B);
                     si = rs.si; sj = rs.sj; dir = rs.dir; prev_dir = rs.prev_dir; off = rs.off; prev_off = rs.prev_off; off_max = rs.off_max;
                     off_add = rs.off_add; best_max = rs.best_max; y_drop_iter = rs.y_drop_iter; x_drop_iter = rs.x_drop_iter; D_corner = rs.D_corner;
                     step_budget = rs.step_budget; run_exit = rs.run_exit; cur = rs.cur; fo = rs.fo;
@@ -1330,6 +1431,32 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                 // Small-block batches: the pairs k_quad could not finish arrive through a queue while it is still running (entry =
                 // 1 + 2 * pair + (1 if the pair is to be run from scratch, else resume from its record)). A ticket is a queue position;
                 // the wave waits for its entry, and leaves once every producer wave is done and the queue ends before the ticket.
+                if (bp.cq_side) {
+                    // The launch beside k_quad never owns a queue position it might abandon (it may stop waiting: a claimed but
+                    // unread position would be a lost pair): it looks at the head entry and takes it with a compare-and-swap on
+                    // the head counter only once the entry is there. The launch after k_quad takes tickets (below): by then every
+                    // producer is done, so a ticket either has its entry or lies beyond the tail.
+                    uint32_t e = 0, spins = 0;
+                    for (;;) {
+                        uint32_t h = 0, v = 0, done = 0, tail = 0, won = 0;
+                        if (is_lane(0)) {
+                            h = __hip_atomic_load(bp.cq_ctrl + 16, BA_RLX_AGENT);
+                            done = __hip_atomic_load(bp.cq_ctrl + 32, BA_RLX_AGENT);
+                            tail = __hip_atomic_load(bp.cq_ctrl, BA_RLX_AGENT);
+                            if (h < bp.n) v = __hip_atomic_load(bp.cq_queue + h, BA_RLX_AGENT);
+                            if (v) { uint32_t expect = h; won = __hip_atomic_compare_exchange_strong(bp.cq_ctrl + 16, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
+                        }
+                        h = (uint32_t)uni((int)h); v = (uint32_t)uni((int)v); done = (uint32_t)uni((int)done); tail = (uint32_t)uni((int)tail); won = (uint32_t)uni((int)won);
+                        if (h >= bp.n) break;
+                        if (v) { if (won) { e = v; break; } continue; }               // (lost the race for this entry: look again)
+                        if (done >= bp.cq_producers && h >= tail) break;              // every producer done (read before the tail) and nothing is waiting
+                        if (++spins > (1u << 21)) break;                              // nothing claimed: the launch after k_quad drains the queue
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                    if (!e) break;
+                    pair = (e - 1u) >> 1;
+                    if (!((e - 1u) & 1u)) rec = bp.cont_in + pair;
+                } else {
                 if (w_next >= w_end) {   // one ticket while the producers run -- an entry is work waiting --, eight once they are done
                     const uint32_t chunk = closing ? 8u : 1u;
                     uint32_t t0 = 0;
@@ -1350,9 +1477,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                         if (ticket >= (uint32_t)uni((int)tail)) break;
                     }
                     if (done >= bp.cq_producers) { closing = true; continue; }
-                    if (++spins > (1u << 21)) {   // several seconds without the producers finishing: never hang. The launch beside k_quad
-                        // just ends (the launch after k_quad drains the queue); for that one the producers are done: report
-                        if (!bp.cq_side && is_lane(0)) __hip_atomic_store(bp.cq_ctrl + 48, 1u, BA_RLX_AGENT);
+                    if (++spins > (1u << 21)) {   // several seconds without the producers finishing (they were done before this launch
+                        // started): never hang, report (the host fails the run)
+                        if (is_lane(0)) __hip_atomic_store(bp.cq_ctrl + 48, 1u, BA_RLX_AGENT);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(32);
@@ -1360,6 +1487,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                 if (!e) break;
                 pair = (e - 1u) >> 1;   // (the record, released before its entry, is read past this CU's L1: see run())
                 if (!((e - 1u) & 1u)) rec = bp.cont_in + pair;
+                }
             }
             uint32_t slot = fill_wave * bp.slots_per_wave + turn;
             if (++turn == bp.slots_per_wave) turn = 0;

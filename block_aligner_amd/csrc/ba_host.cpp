@@ -51,6 +51,16 @@ typedef hipError_t (*OccFn)(int, int, unsigned, int*);
 // [special modes?][kind][block class]
 static const LaunchFn g_launch[2][4][5] = {{BA_ROW(0), BA_ROW(1), BA_ROW(2), BA_ROW(3)}, {BA_SROW(0), BA_SROW(1), BA_SROW(2), BA_SROW(3)}};
 static const OccFn g_occ[2][4][5] = {{BA_OROW(0), BA_OROW(1), BA_OROW(2), BA_OROW(3)}, {BA_SOROW(0), BA_SOROW(1), BA_SOROW(2), BA_SOROW(3)}};
+// k_multi (ba_multi.hpp): four pairs per wave at 128 cells; sequence kinds only
+#define BA_DECL_M(K, P)                                                                                               \
+    extern "C" hipError_t ba_launch_m_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);     \
+    extern "C" hipError_t ba_occupancy_m_k##K##_p##P(int, int, unsigned, int*);
+#define BA_DECL_M_KIND(K) BA_DECL_M(K, 1) BA_DECL_M(K, 2) BA_DECL_M(K, 4) BA_DECL_M(K, 8) BA_DECL_M(K, 16)
+BA_DECL_M_KIND(0) BA_DECL_M_KIND(1) BA_DECL_M_KIND(2)
+#define BA_MROW(K) {ba_launch_m_k##K##_p1, ba_launch_m_k##K##_p2, ba_launch_m_k##K##_p4, ba_launch_m_k##K##_p8, ba_launch_m_k##K##_p16}
+#define BA_MOROW(K) {ba_occupancy_m_k##K##_p1, ba_occupancy_m_k##K##_p2, ba_occupancy_m_k##K##_p4, ba_occupancy_m_k##K##_p8, ba_occupancy_m_k##K##_p16}
+static const LaunchFn g_launch_m[3][5] = {BA_MROW(0), BA_MROW(1), BA_MROW(2)};
+static const OccFn g_occ_m[3][5] = {BA_MOROW(0), BA_MOROW(1), BA_MOROW(2)};
 typedef hipError_t (*QuadFn)(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k0(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k1(int, int, unsigned, hipStream_t, const BatchParams*);
@@ -190,7 +200,7 @@ struct DevBuf {
 struct BaBatch {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: pair-slot small-block batches (see batch_launch)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_l0 = nullptr, ev_m1 = nullptr;   // ev_l0 / ev_m1: batch_retry
     int kind = 0; uint32_t mode = 0;
     uint32_t n = 0, min_size = 0, max_size = 0, pclass = 0;
     int gap_open = 0, gap_extend = 0, x_drop = 0;
@@ -207,6 +217,7 @@ struct BaBatch {
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false, in_flight = false;
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
+    bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
     DevBuf cq_queue, cq_ctrl;   // the queue those pairs travel through (ba_params.h)
@@ -248,6 +259,8 @@ struct BaBatch {
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_l0) (void)hipEventDestroy(ev_l0);
+        if (ev_m1) (void)hipEventDestroy(ev_m1);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -487,7 +500,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[kind] : g_occ[special_of(mode)][kind][pc];
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[kind] : (b->multi ? g_occ_m[kind][pc] : g_occ[special_of(mode)][kind][pc]);
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
@@ -561,8 +574,10 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
+        if (b->multi) spw = 10;   // four pairs being filled + pending walks
         if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
+        if (b->multi && spw < 6) return fail("device memory: the multi-pair kernel needs six trace slots per wave");   // (batch_build falls back to the per-pair kernel)
         b->slots_per_wave = spw;
         // The last hand-offs of the batch go to fill waves that have run out of pairs (one walking lane per wave, on
         // SIMDs with nothing else left to do): a walk alone is much shorter than one among 40 in lockstep, and the
@@ -575,6 +590,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
         if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
     }
+    if (b->multi && b->slots_per_wave < 4) b->slots_per_wave = 4;   // (without the hand-off ring: one trace slot per slot of the wave)
     b->slots = b->n_fill_waves * b->slots_per_wave;
     if (b->pipe) b->slots = (uint32_t)n;   // (slot = pair: slot_info holds one entry per pair for k_walk)
     {
@@ -592,7 +608,8 @@ static int batch_alloc_scratch(BaBatch* b) {
     BA_ALLOC(trace, b->pipe ? b->pipe_words * 4 : b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->pipe ? b->pipe_recs * sizeof(BlockRec) : b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)(b->grid + b->cq_grid) * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
-    BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short) : 0);
+    BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short)
+                                              : (b->multi ? (size_t)b->grid * ba::WAVES_PER_WG * ba::MQ_WAVE_BYTES : 0));
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
 #undef BA_ALLOC
@@ -673,7 +690,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // from the sizes where it wins (measured, GCUPS with / without: protein pairs 32k 371 / 405, 64k 745 / 527, 400k 1375 / 597;
     // PSSM 8k 108 / 105, 20k 211 / 162, 80k 458 / 172; 1 kbp DNA 200k 1347 / 606). BA_FORCE_QUAD / BA_NO_QUAD override.
     const size_t quad_from = kind == BA_KIND_AA ? 65536u : (profile ? 8192u : 2048u);
-    b->quad = !special_of(mode) && min_size == 32 && !getenv("BA_NO_QUAD") && (getenv("BA_FORCE_QUAD") || n >= quad_from);
+    b->quad = !special_of(mode) && pc != BA_PCLASS_BIG && min_size == 32 && !getenv("BA_NO_QUAD") && (getenv("BA_FORCE_QUAD") || n >= quad_from);
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
     // blocks take it in place of the hand-off ring (50..500 positions, 20k pairs: 143 -> 158 GCUPS, 80k: 172 -> 225). Short
@@ -687,6 +704,11 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         }
     }
     if (trace && !b->pipe) b->quad = false;   // with TRACE the pipeline needs every pair's trace stack resident until the end
+    // Batches that start at 128 cells (the reference's nanopore set-up, examples/nanopore_bench.rs: 1 % .. 10 % of 10 kbp): four pairs
+    // per wave while a pair's block is 128 cells (ba_multi.hpp), from the sizes at which every wave still finds four pairs.
+    b->multi = !profile && !special_of(mode) && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !getenv("BA_NO_MULTI") && (getenv("BA_FORCE_MULTI") || n >= 16384);
+    if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
+    if (!b->multi)
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
     if (b->pipe) b->adaptive = true;
     b->cig_total = trace ? cig_total : 0;
@@ -787,7 +809,8 @@ static int batch_launch(BaBatch* b) {
     }
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : g_launch[special_of(b->mode)][b->kind][b->pclass];
+    if (b->ev_l0) HIP_TRY(hipEventRecord(b->ev_l0, b->stream));   // (a re-run sub-batch: batch_retry re-uses ev0 for the merge)
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : (b->multi ? g_launch_m[b->kind][b->pclass] : g_launch[special_of(b->mode)][b->kind][b->pclass]);
     if (b->quad && b->n <= b->cap_n) {
         // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
         // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a
@@ -852,7 +875,7 @@ static int d2h(const DevBuf& buf, T* dst, size_t count) {
 }
 // Re-run the pairs `idx` (device order) of a TRACE batch with trace slots of the reference's full bound and put their results
 // where the first pass left BA_ST_TRACE_OVERFLOW. The sub-batch reads the parent's resident images and matrix.
-static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx) {
+static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx, float* retry_ms) {
     const size_t k = idx.size(), n = b->n;
     std::vector<uint32_t> ql(n), rl(n);
     if (d2h(b->q_len, ql.data(), n) || d2h(b->r_len, rl.data(), n)) return 1;
@@ -870,7 +893,8 @@ static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx) {
     }
     co[k] = cig_total;
     if (hipStreamCreateWithFlags(&sub.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    if (hipEventCreate(&sub.ev0) != hipSuccess || hipEventCreate(&sub.ev1) != hipSuccess) return fail("hipEventCreate failed");
+    if (hipEventCreate(&sub.ev0) != hipSuccess || hipEventCreate(&sub.ev1) != hipSuccess || hipEventCreate(&sub.ev_l0) != hipSuccess ||
+        hipEventCreate(&sub.ev_m1) != hipSuccess) return fail("hipEventCreate failed");
     if (batch_plan(&sub, k, cig_total * 4 + (uint64_t)k * 64, maxlen2, true)) return 1;
     sub.cig_total = cig_total;
     sub.pool.view(b->pool.p, b->pool.bytes); sub.matrix.view(b->matrix.p, b->matrix.bytes);
@@ -887,8 +911,17 @@ static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx) {
     HIP_TRY(hipStreamSynchronize(sub.stream));
     sub.in_flight = false;
     const BatchParams sp = sub.params(), dp = b->params();
+    HIP_TRY(hipEventRecord(sub.ev0, sub.stream));
     HIP_TRY(ba_launch_merge_retry(sub.stream, d_idx.as<uint32_t>(), (uint32_t)k, &sp, &dp, sub.trace_words.as<uint32_t>(), b->trace_words.as<uint32_t>()));
+    HIP_TRY(hipEventRecord(sub.ev_m1, sub.stream));
     HIP_TRY(hipStreamSynchronize(sub.stream));
+    // the re-run belongs to the batch's device time: its kernels (ev0 .. ev1 of the sub-batch's launch) and the merge
+    if (retry_ms) {
+        float a = 0, c = 0;
+        HIP_TRY(hipEventElapsedTime(&a, sub.ev_l0, sub.ev1));
+        HIP_TRY(hipEventElapsedTime(&c, sub.ev0, sub.ev_m1));
+        *retry_ms = a + c;
+    }
     return 0;
 }
 static int batch_wait(BaBatch* b, float* kernel_ms) {
@@ -899,16 +932,20 @@ static int batch_wait(BaBatch* b, float* kernel_ms) {
     b->in_flight = false;
     b->retried = 0;
     if (b->quad) {
-        uint32_t gave_up = 0;
-        HIP_TRY(hipMemcpy(&gave_up, b->cq_ctrl.as<uint32_t>() + 48, 4, hipMemcpyDeviceToHost));
-        if (gave_up) return fail("a per-pair kernel gave up waiting for the small-block kernel's queue");
+        uint32_t ctl[64] = {0};
+        HIP_TRY(hipMemcpy(ctl, b->cq_ctrl.p, sizeof ctl, hipMemcpyDeviceToHost));
+        if (ctl[48]) return fail("a per-pair kernel gave up waiting for the small-block kernel's queue");
+        // every queued pair was taken by a per-pair wave: positions handed out (head) cover the entries appended (tail)
+        if (ctl[16] < ctl[0]) return fail("small-block pipeline: %u queued pairs were never taken by the per-pair kernel", ctl[0] - ctl[16]);
     }
     if (b->adaptive) {   // pairs whose trace stack outgrew the expected size: once more, with the reference's full bound
         std::vector<uint32_t> st(b->n), again;
         if (d2h(b->status, st.data(), b->n)) return 1;
         for (uint32_t p = 0; p < b->n; p++) if (st[p] & BA_ST_TRACE_OVERFLOW) again.push_back(p);
         if (!again.empty()) {
-            if (batch_retry(b, again)) return 1;
+            float retry_ms = 0;
+            if (batch_retry(b, again, &retry_ms)) return 1;
+            if (kernel_ms) *kernel_ms += retry_ms;   // the merged results include the re-run pairs' cells: so does the time
             b->retried = (uint32_t)again.size();
         }
     }
@@ -1333,13 +1370,21 @@ BaMultiBatch* ba_multibatch_create(int kind, const void* matrix, Gaps gaps, Size
 }
 int ba_multibatch_run(BaMultiBatch* m, float* kernel_ms) {
     if (!m) return fail("null batch");
-    for (auto& b : m->part) if (b && batch_launch(b.get())) return 1;        // all devices first ...
+    // all devices first, then collect. A failure does not leave the other parts in flight: every part that was launched is
+    // waited for before the first error is reported.
+    std::string first_err;
+    for (auto& b : m->part) {
+        if (!b || !first_err.empty()) continue;
+        if (batch_launch(b.get())) first_err = g_err;
+    }
     float worst = 0;
-    for (auto& b : m->part) {                                                // ... then collect
+    for (auto& b : m->part) {
+        if (!b || !b->in_flight) continue;
         float ms = 0;
-        if (b && batch_wait(b.get(), &ms)) return 1;
+        if (batch_wait(b.get(), &ms)) { if (first_err.empty()) first_err = g_err; b->in_flight = false; continue; }
         worst = std::max(worst, ms);
     }
+    if (!first_err.empty()) return fail("%s", first_err.c_str());
     if (kernel_ms) *kernel_ms = worst;
     return 0;
 }
@@ -1400,6 +1445,8 @@ struct BlockImpl {
     AlignResult res{0, 0, 0};
     std::unique_ptr<BaBatch> dev;                // persistent device state (created with the handle when a device is usable)
     std::vector<uint8_t> staging;                // host image of hblk
+    int8_t matrix_image[1024] = {0};             // host image of the matrix last uploaded
+    bool matrix_valid = false;
     uint32_t last_ql = 0, last_rl = 0, last_nblocks = 0, last_slot = 0;
     bool aligned = false;
 };
@@ -1490,10 +1537,16 @@ static void handle_align(BlockImpl* h, int kind, const PaddedBytes* q, const Pad
     hipError_t e = hipMemcpyAsync(b->hblk.p, st, used, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess && b->matrix.p) {
         const size_t mat_bytes = kind == BA_KIND_AA ? 27 * 32 : (kind == BA_KIND_NUC ? 8 * 16 : (kind == BA_KIND_BYTES ? 2 : 0));
+        // (the image lives in the handle: the source of an asynchronous copy has to outlive the stream synchronisation;
+        // unchanged matrices are not uploaded again)
         int8_t tmp[1024] = {0};
         if (kind == BA_KIND_BYTES) { const ByteMatrix* bm = (const ByteMatrix*)matrix; tmp[0] = bm->match_score; tmp[1] = bm->mismatch_score; }
         else if (mat_bytes) memcpy(tmp, matrix, mat_bytes);
-        if (mat_bytes) e = hipMemcpyAsync(b->matrix.p, tmp, 1024, hipMemcpyHostToDevice, b->stream);   // (pageable source: staged before the call returns)
+        if (mat_bytes && (!h->matrix_valid || memcmp(tmp, h->matrix_image, 1024) != 0)) {
+            memcpy(h->matrix_image, tmp, 1024);
+            e = hipMemcpyAsync(b->matrix.p, h->matrix_image, 1024, hipMemcpyHostToDevice, b->stream);
+            h->matrix_valid = e == hipSuccess;
+        }
     }
     if (e != hipSuccess) die("hipMemcpy H2D failed: %s", hipGetErrorString(e));
     b->in_flight = false; b->ran = false;

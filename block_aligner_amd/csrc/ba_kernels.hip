@@ -54,6 +54,37 @@ extern "C" hipError_t BA_OCC(int trace, int xdrop, unsigned lds, int* blocks_per
     return xdrop ? occ1<false, true>(blocks_per_cu, lds) : occ1<false, false>(blocks_per_cu, lds);
 }
 
+#if BA_KIND != 3 && !BA_SPECIAL && !BA_BIG
+// four pairs per wave while the block is 128 cells, everything else by the same wave on all its lanes (ba_multi.hpp): one kernel per
+// kind and block class
+#include "ba_multi.hpp"
+template <bool TRACE, bool XDROP>
+static hipError_t launch_multi(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP>
+static hipError_t occ_multi(int* blocks_per_cu, unsigned lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP>, ba::WAVES_PER_WG * 64, lds);
+}
+extern "C" hipError_t BA_CAT(ba_launch_m_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch_multi<true, true>(grid, lds, s, *bp) : launch_multi<true, false>(grid, lds, s, *bp);
+    return xdrop ? launch_multi<false, true>(grid, lds, s, *bp) : launch_multi<false, false>(grid, lds, s, *bp);
+}
+extern "C" hipError_t BA_CAT(ba_occupancy_m_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    if (trace) return xdrop ? occ_multi<true, true>(blocks_per_cu, lds) : occ_multi<true, false>(blocks_per_cu, lds);
+    return xdrop ? occ_multi<false, true>(blocks_per_cu, lds) : occ_multi<false, false>(blocks_per_cu, lds);
+}
+#endif
+
 #if BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
 // four pairs per wave while the block is 32 cells (ba_quad.hpp): one kernel per kind
 #include "ba_quad.hpp"

@@ -1,0 +1,502 @@
+// block_aligner_amd — four pairs per wavefront while the block is 128 cells, inside ONE persistent kernel.
+//
+// The per-pair kernel (ba_driver.hpp) spends ~37 vector instructions on a 128-cell column of which 9 are the 64-lane prefix
+// scan and pays ~55 instructions of driver shell per 8-column step, all for one pair. k_multi hosts FOUR pairs per wave, one
+// per 16-lane DPP row ("slot"), with EIGHT cells per lane: lane l of a slot owns cells 8l .. 8l+7 of the block's vector axis as
+// four packed 2 x i16 registers. The gap scan along the column (avx2.rs:297-338 + scan_block.rs:1144-1150) then is an in-lane
+// chain over the lane's four registers followed by ONE 16-lane DPP scan (4 steps) that serves all four pairs at once; the
+// orthogonal border shifts by exactly one lane per step (8 entries), i.e. by a DPP row shift instead of an LDS round trip; and
+// the driver decisions of scan_block.rs:332-558 are evaluated for the four slots together with vector compares and selects
+// (what is wave-uniform in the per-pair kernel is row-uniform here, replicated over the slot's lanes in VGPRs).
+//
+// A slot takes only PLAIN shift steps at 128 cells. Whatever else a pair needs -- its first block, a grow, the steps at larger
+// block sizes, a shrink, X-drop termination, the end of the matrix, the early column break -- is done by the same wave in
+// "solo" mode: the pair's state moves to LDS / scalars and Aligner::run (ba_driver.hpp: all 64 lanes on that one pair, the code
+// of the per-pair kernel) takes it until the pair is finished or its next step is again a plain shift step at 128 cells, while
+// the other three slots wait in their registers. No lane is idle in either mode. A step whose outcome calls for more than a
+// shift is rolled back in the slot and repeated solo.
+//
+// The location of a step's maximum (X-drop: scan_block.rs:370-404) is not computed in a slot: only the LAST improving step's
+// location reaches the result, and that step is also the checkpoint (scan_block.rs:406-427). A slot keeps the state BEFORE its
+// last improving step; whenever the pair goes solo that step is repeated once (Aligner::run, MultiIO::ck_pre), which yields the
+// location and the borders the reference's checkpoint holds.
+//
+// Trace words and rectangle records are those of the per-pair kernel (word (col >> 2) * 64 + (row >> 1) of a 128-row
+// rectangle holds cells (row, row + 1) x 4 columns; with 8 cells per lane these are a lane's four registers, one 16-byte store).
+#pragma once
+#include "ba_quad.hpp"
+
+namespace ba {
+
+template <int N>
+__device__ __forceinline__ int row_bcast(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xf, 0xf, false); }   // row_newbcast:N
+// lane l <- src[l + 1] inside the row; lane 15 keeps `last`
+__device__ __forceinline__ int row_shl1_keep(int last, int src) { return __builtin_amdgcn_update_dpp(last, src, 0x101, 0xf, 0xf, false); }
+__device__ __forceinline__ int splat_hi(int x) { const s16x2 t = as_s(x); return as_i(s16x2{t.y, t.y}); }
+__device__ __forceinline__ int splat_lo(int x) { const s16x2 t = as_s(x); return as_i(s16x2{t.x, t.x}); }
+
+struct MultiConsts {
+    int G[4];             // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
+    int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g, except row lane 0 which holds -32768 (no lane above: a candidate that never wins)
+    int vtop[4];          // per cell: max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column)
+};
+
+struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
+
+// One 8-column shift step for the four slots of a wave, 8 cells per lane (scan_block.rs:147-246 with place_block 1083-1228 and
+// the border moves 1003-1061 folded in). (Ad, Ac): the border pair along the step's vector axis, (Pd, Pr) the orthogonal pair.
+// tout: this lane's four words of the step's first column group.
+template <int KIND, bool TRACE>
+__device__ __forceinline__ void multi_rect(const char* table, const FillConsts& fc, const MultiConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
+                                           int (&Pd)[4], int (&Pr)[4], uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add,
+                                           uint32_t* __restrict__ tout, bool store, MultiOut& o) {
+    const int offa = splat(off_add);
+    int d[4], c[4], pd[4], pr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // just_offset (scan_block.rs:1003-1012)
+        d[k] = adds(Ad[k], offa); c[k] = adds(Ac[k], offa); pd[k] = adds(Pd[k], offa); pr[k] = adds(Pr[k], offa);
+    }
+    o.corner_new = row_bcast<0>(pd[3]) >> 16;   // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based
+    ScoreKey<KIND> key[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t w = k < 2 ? vb.x : vb.y;
+        key[k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
+    }
+    int dmax[4] = {0, 0, 0, 0}, tacc[4] = {0, 0, 0, 0};
+    int nvD[4] = {0, 0, 0, 0}, nvR[4] = {0, 0, 0, 0};   // the last cells of the 8 new columns: the orthogonal border's new entries (row lane 15)
+    int holdD = 0, holdR = 0;
+#pragma unroll
+    for (int j = 0; j < STEP; j++) {
+        const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
+        int sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sc[k] = fetch_score<KIND>(table, key[k], cb);
+        // D00: the previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
+        int prev = row_shr1_z(d[3]);
+        if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
+        int d00[4];
+        d00[0] = __builtin_amdgcn_alignbit(d[0], prev, 16);
+#pragma unroll
+        for (int k = 1; k < 4; k++) d00[k] = __builtin_amdgcn_alignbit(d[k], d[k - 1], 16);
+        int d11[4], copen[4], cn[4], x[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            d11[k] = adds(d00[k], sc[k]);
+            copen[k] = adds(d[k], fc.go2);
+            cn[k] = vmax(adds(c[k], fc.ge2), copen[k]);
+            d11[k] = vmax(d11[k], cn[k]);
+            x[k] = adds(d11[k], fc.ome2);                                  // D11_open
+            r[k] = vmax(x[k], splat_lo(adds(x[k], fc.ge2)));               // inside the register
+        }
+        // R11: the chain over the lane's registers, then one 16-lane scan on values re-based by l * 8g
+#pragma unroll
+        for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(splat_hi(r[k - 1]), mc.G[0]));
+        const int pm = wave_prefix_max16((int)as_s(r[3]).y - mc.laneKG);
+        const int cs = splat_lo(add_row_shr1(pm, mc.lanem1KG));             // R of the lane above's last cell (no clamp: see fast_rect)
+        int dn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), mc.vtop[k]);
+            dn[k] = vmax(d11[k], r[k]);
+            if (TRACE) {   // the cell's four flags as sign bits of saturating differences, one nibble per column (see fast_rect)
+                const uint32_t sC = (uint32_t)subs(cn[k], dn[k]), sR = (uint32_t)subs(r[k], dn[k]), sCo = (uint32_t)subs(copen[k], cn[k]), sRo = (uint32_t)subs(x[k], r[k]);
+                const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);
+                const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);
+                tacc[k] = (int)(((uint32_t)tacc[k] >> 4) | (nib & 0xF000F000u));
+            }
+            dmax[k] = vmax(dmax[k], dn[k]);
+            d[k] = dn[k]; c[k] = cn[k];
+        }
+        if (TRACE && (j & 3) == 3) {
+            if (store) *(int4*)(tout + (j >> 2) * 64) = int4{tacc[0], tacc[1], tacc[2], tacc[3]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) tacc[k] = 0;
+        }
+        // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
+        if (j & 1) { nvD[j >> 1] = __builtin_amdgcn_perm(dn[3], holdD, 0x07060302); nvR[j >> 1] = __builtin_amdgcn_perm(r[3], holdR, 0x07060302); }
+        else { holdD = dn[3]; holdR = r[3]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // shift_and_offset (scan_block.rs:1040-1061): 8 entries = one lane
+        Pd[k] = row_shl1_keep(nvD[k], pd[k]); Pr[k] = row_shl1_keep(nvR[k], pr[k]);
+        Ad[k] = d[k]; Ac[k] = c[k];
+    }
+    {   // max of the first 8 entries of both borders (row lane 0), to every lane of the slot (scan_block.rs:1020-1022)
+        const int ma = vmax(vmax(d[0], d[1]), vmax(d[2], d[3])), mb = vmax(vmax(Pd[0], Pd[1]), vmax(Pd[2], Pd[3]));
+        const s16x2 sa = as_s(ma), sb = as_s(mb);
+        const int xa = vmax(ma, as_i(s16x2{sa.y, sa.x})), xb = vmax(mb, as_i(s16x2{sb.y, sb.x}));
+        const s16x2 rr = as_s(row_bcast<0>(__builtin_amdgcn_perm(xb, xa, 0x05040100)));
+        o.act_max8 = rr.x; o.pas_max8 = rr.y;
+    }
+    const int mm = vmax(vmax(dmax[0], dmax[1]), vmax(dmax[2], dmax[3]));
+    const int m32 = max(mm & 0xffff, (int)((uint32_t)mm >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
+    o.mx = row_bcast<15>(wave_prefix_max16(m32));
+}
+
+// Per wave and slot, in an L2-resident arena (BatchParams::big):
+//   two buffers that alternate between "the state before the step in flight" (written before every step: a step that is rolled
+//   back, or that a slot may not take, leaves the slot's registers behind as garbage and the pair's state here) and "the
+//   checkpoint" (the state before the last improving step: on an improving step the two simply change roles):
+//           A_d, A_c, P_d, P_r (16 lanes x 16 bytes each, relative to the direction in the scalars) + 16 scalars:
+//           [0] 1 = state before a step / 0 = checkpoint as the reference keeps it (after the step), [1] i, [2] j, [3] offset,
+//           [4] trace words, [5] rectangles (flag 1: before the step), [6] direction, [7] off_add, [8] corner
+//   and a record of 32 scalars: the slot's whole driver state while the wave is in solo mode (the slots' registers are live only
+//   inside the loop of shift steps: around a solo episode every slot is stored / loaded, so that the solo code -- the whole
+//   per-pair driver, which needs every register -- and the step loop are allocated independently of each other)
+// (sizes: MQ_BUF_BYTES / MQ_SLOT_BYTES / MQ_WAVE_BYTES in ba_params.h)
+enum { MR_PAIR = 0, MR_BEST_I, MR_BEST_J, MR_CELLS_LO, MR_CELLS_HI, MR_BUDGET, MR_STATUS, MR_TSLOT, MR_SI, MR_SJ, MR_DIR, MR_PREV_DIR, MR_OFF, MR_OFF_MAX,
+       MR_BEST_MAX, MR_Y_DROP, MR_X_ITER, MR_D_CORNER, MR_NSTEPS, MR_TRACE_TOP, MR_NBLOCKS, MR_SEL, MR_WORDS };
+__device__ __forceinline__ int mq_load(const char* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }   // past the L1: the wave reads back its own stores
+
+template <int PMAX, int KIND, bool TRACE, bool XDROP>
+__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_multi(const BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), l = lane & 15, g = lane >> 4;
+    const int wave = uni((int)threadIdx.x >> 6);
+    {   // workgroup-shared scoring table, as in k_align
+        char* tab = smem;
+        if (KIND == KIND_NUC) {
+            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
+                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
+                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
+            }
+        } else {
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
+        }
+    }
+    __syncthreads();
+    constexpr uint32_t LCLS = (uint32_t)PMAX * 128u;
+    constexpr uint32_t ab = lds_array_bytes_h(LCLS);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(LCLS);
+    WaveLds L;
+    L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
+    L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
+    L.misc = (short*)(base + 4 * ab);
+    L.table = smem;
+    const int gx = bp.gap_extend;
+    const uint32_t stride = bp.tb_stride;
+    const bool batch_traceback = TRACE && stride > 0;
+    if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
+        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(LCLS), 64u, true);
+        return;
+    }
+    const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
+    const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
+    const uint32_t max_size = bp.max_size;
+    const bool keep_pre = XDROP || MQ_B < max_size;   // a slot keeps the state before its last improving step
+    char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * MQ_WAVE_BYTES;
+
+    uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
+    uint32_t w_next = 0, w_end = 0;
+    bool more = true;
+
+    for (;;) {
+        // ================= solo mode: one pair at a time on all 64 lanes, the slots' state in memory. Whose turn? a slot whose step
+        // was rolled back, else a new pair for an idle slot, else -- the batch is running out and fewer than four slots are live: a
+        // step would idle lanes -- a live slot, to its end.
+        for (;;) {
+            int solo = -1; bool fresh = false, to_end = false;
+            uint32_t new_pair = 0;
+            if (pend_m) solo = __builtin_ctz(pend_m);
+            else if (live_m != 15u && more) {
+                if (w_next == w_end) {
+                    uint32_t v = 0;
+                    if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
+                    w_next = (uint32_t)uni((int)v);
+                    if (w_next >= bp.n) { more = false; w_next = w_end = 0; continue; }
+                    w_end = min(w_next + bp.work_chunk, bp.n);
+                }
+                new_pair = w_next++; solo = __builtin_ctz(~live_m & 15u); fresh = true;
+            } else if (live_m && live_m != 15u) { solo = __builtin_ctz(live_m); to_end = true; }
+            else break;
+
+            FillConsts fc;   // two cells per lane (as k_align)
+            {
+                fc.gap_extend = gx;
+                fc.go2 = splat(bp.gap_open); fc.ge2 = splat(gx); fc.ome2 = splat(clamp16(bp.gap_open - gx));
+                fc.g12 = pk(gx, 2 * gx);
+                fc.ones = 0x00010001;
+                fc.laneKG = lane * 2 * gx; fc.lanem1KG = lane ? (lane - 1) * 2 * gx : -32768;
+                int v[2];
+                for (int h = 0; h < 2; h++) {
+                    const int k = (2 * lane + h) & 15;
+                    const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
+                    v[h] = mult ? max(-32768, mult * gx) : -32768;
+                }
+                fc.vconst = pk(v[0], v[1]);
+                fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
+            }
+            Aligner<PMAX, KIND, TRACE, XDROP, false> al(bp, L, fc);
+            MultiIO io;
+            io.mode = fresh ? 0 : 1; io.allow_quad = !to_end; io.forced = !fresh && !to_end; io.exited = false; io.sel = 0;
+            io.ck_pre = false; io.ck_dir = 0; io.ck_offadd = 0; io.ck_corner = 0;
+            int reg[32];
+            io.reg = reg;
+            uint32_t s_pair, s_slot;
+            char* const smem_s = wave_mem + (uint32_t)solo * MQ_SLOT_BYTES;
+            char* const rec = smem_s + 2 * MQ_BUF_BYTES;
+            if (fresh) {
+                s_pair = new_pair;
+                // a free trace slot of this wave (a slot is busy from the pair's start until its traceback is done)
+                s_slot = fill_wave * bp.slots_per_wave;
+                if (batch_traceback) {
+                    uint32_t seen = 0, idle_n = 0; bool got = false;
+                    const uint32_t limit = (1u << 20) * (1u + (uint32_t)(bp.blocks_stride >> 15));
+                    for (;;) {
+                        uint32_t f = 0, head = 0;
+                        if ((uint32_t)lane < bp.slots_per_wave) f = __hip_atomic_load(bp.slot_free + s_slot + lane, BA_RLX_AGENT);
+                        if (is_lane(0)) head = __hip_atomic_load(bp.tb_ctrl + 32, BA_RLX_AGENT);
+                        const unsigned long long fm = __ballot(f != 0);
+                        if (fm) {
+                            s_slot += (uint32_t)__builtin_ctzll(fm);
+                            if (is_lane(0)) __hip_atomic_store(bp.slot_free + s_slot, 0u, BA_RLX_AGENT);
+                            got = true; break;
+                        }
+                        head = (uint32_t)uni((int)head);
+                        if (head != seen) { seen = head; idle_n = 0; }
+                        else if (++idle_n > limit) break;
+                        __builtin_amdgcn_s_sleep(64);
+                    }
+                    if (!got) {   // the traceback side has stopped making progress: report instead of hanging
+                        al.status = ST_SLOT_TIMEOUT;
+                        if (is_lane(0)) { bp.score[s_pair] = 0; bp.query_idx[s_pair] = 0; bp.reference_idx[s_pair] = 0; }
+                        al.hand_off(s_slot, s_pair, 0, 0, true);
+                        continue;
+                    }
+                } else if (TRACE) {
+                    // (no hand-off: the pair's traceback is walked by this wave before the slot is reused; the four slots of the wave
+                    // still need a trace slot each while their pairs are live)
+                    s_slot += (uint32_t)solo;
+                }
+            } else {
+                const int rv = lane < MR_WORDS ? mq_load(rec + 4 * lane) : 0;   // the slot's record: lane k holds word k
+#define BA_W(v, k) __builtin_amdgcn_readlane(v, k)
+                const uint32_t s_sel = (uint32_t)BA_W(rv, MR_SEL);
+                const char* live_b = smem_s + (s_sel ^ 1u) * MQ_BUF_BYTES; const char* ck_b = smem_s + s_sel * MQ_BUF_BYTES;
+                const int cv = lane < 16 ? mq_load(ck_b + 1024 + 4 * lane) : 0;   // the checkpoint's scalars
+                s_pair = (uint32_t)BA_W(rv, MR_PAIR); s_slot = (uint32_t)BA_W(rv, MR_TSLOT);
+                PairState& st = io.st;
+                st.si = (uint32_t)BA_W(rv, MR_SI); st.sj = (uint32_t)BA_W(rv, MR_SJ); st.dir = BA_W(rv, MR_DIR); st.prev_dir = BA_W(rv, MR_PREV_DIR);
+                st.off = BA_W(rv, MR_OFF); st.off_max = BA_W(rv, MR_OFF_MAX); st.best_max = BA_W(rv, MR_BEST_MAX);
+                st.y_drop_iter = (uint32_t)BA_W(rv, MR_Y_DROP); st.x_drop_iter = BA_W(rv, MR_X_ITER); st.D_corner = BA_W(rv, MR_D_CORNER);
+                st.trace_top = (uint32_t)BA_W(rv, MR_TRACE_TOP); st.nblocks = (uint32_t)BA_W(rv, MR_NBLOCKS);
+                const uint32_t ns = (uint32_t)BA_W(rv, MR_NSTEPS);
+                st.best_i = (uint32_t)BA_W(rv, MR_BEST_I); st.best_j = (uint32_t)BA_W(rv, MR_BEST_J);
+                st.cells = ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_LO) | ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_HI) << 32)) + (unsigned long long)ns * (STEP * MQ_B);
+                const uint32_t bud = (uint32_t)BA_W(rv, MR_BUDGET);
+                st.step_budget = bud > ns ? bud - ns : 1u;
+                st.status = (uint32_t)BA_W(rv, MR_STATUS);
+                const int flag = BA_W(cv, 0);
+                io.ck_pre = flag != 0;
+                st.ck_i = (uint32_t)BA_W(cv, 1); st.ck_j = (uint32_t)BA_W(cv, 2); st.ck_off = BA_W(cv, 3);
+                st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * MQ_B / 8 : 0u); st.ck_nb = (uint32_t)BA_W(cv, 5) + (flag ? 1u : 0u);
+                io.ck_dir = BA_W(cv, 6); io.ck_offadd = BA_W(cv, 7); io.ck_corner = BA_W(cv, 8);
+#undef BA_W
+                {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 15), into the canonical order D_col, C_col, D_row, R_row
+                    const bool lr = st.dir == DIR_RIGHT, cr = io.ck_dir == DIR_RIGHT;
+                    const uint32_t oAd = (lr ? 0u : 512u) + l * 16, oAc = (lr ? 256u : 768u) + l * 16, oPd = (lr ? 512u : 0u) + l * 16, oPr = (lr ? 768u : 256u) + l * 16;
+                    const uint32_t cAd = (cr ? 0u : 512u) + l * 16, cAc = (cr ? 256u : 768u) + l * 16, cPd = (cr ? 512u : 0u) + l * 16, cPr = (cr ? 768u : 256u) + l * 16;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        reg[k] = mq_load(live_b + oAd + 4 * k); reg[4 + k] = mq_load(live_b + oAc + 4 * k); reg[8 + k] = mq_load(live_b + oPd + 4 * k); reg[12 + k] = mq_load(live_b + oPr + 4 * k);
+                        reg[16 + k] = mq_load(ck_b + cAd + 4 * k); reg[20 + k] = mq_load(ck_b + cAc + 4 * k); reg[24 + k] = mq_load(ck_b + cPd + 4 * k); reg[28 + k] = mq_load(ck_b + cPr + 4 * k);
+                    }
+                }
+            }
+            al.trace = bp.trace_arena + (uint64_t)s_slot * bp.trace_stride;
+            al.blocks = bp.blocks + (uint64_t)s_slot * bp.blocks_stride;
+            al.ckpt = bp.ckpt + (uint64_t)(fill_wave + bp.ckpt_wave0) * 8 * bp.max_size;
+            al.run(s_pair, s_slot, batch_traceback, nullptr, &io);
+            pend_m &= ~(1u << solo);
+            if (io.exited) {   // the pair's next step is a plain shift step at MQ_B cells: into the slot (its memory)
+                const PairState& st = io.st;
+                const bool rgt = st.dir == DIR_RIGHT;
+                if (lane < 16) {
+                    const int l8 = 8 * l;
+                    const int4 a_d = *(const int4*)((rgt ? L.D_col : L.D_row) + l8), a_c = *(const int4*)((rgt ? L.C_col : L.R_row) + l8);
+                    const int4 p_d = *(const int4*)((rgt ? L.D_row : L.D_col) + l8), p_r = *(const int4*)((rgt ? L.R_row : L.C_col) + l8);
+                    char* b1 = smem_s + MQ_BUF_BYTES;   // the state at the top of the loop: buffer 1 (sel = 0)
+                    *(int4*)(b1 + l * 16) = a_d; *(int4*)(b1 + 256 + l * 16) = a_c; *(int4*)(b1 + 512 + l * 16) = p_d; *(int4*)(b1 + 768 + l * 16) = p_r;
+                    if (MQ_B < max_size) {   // the checkpoint as the reference keeps it (after its step): buffer 0
+                        char* b0 = smem_s;
+                        *(int4*)(b0 + l * 16) = *(const int4*)(L.D_col + MQ_B + l8); *(int4*)(b0 + 256 + l * 16) = *(const int4*)(L.C_col + MQ_B + l8);
+                        *(int4*)(b0 + 512 + l * 16) = *(const int4*)(L.D_row + MQ_B + l8); *(int4*)(b0 + 768 + l * 16) = *(const int4*)(L.R_row + MQ_B + l8);
+                    }
+                }
+                if (is_lane(0)) {
+                    char* b0 = smem_s;
+                    *(int4*)(b0 + 1024) = int4{0, (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + 1040) = int4{(int)st.ck_tt, (int)st.ck_nb, DIR_RIGHT, 0};
+                    *(int*)(b0 + 1056) = 0;
+                    int* rc = (int*)rec;
+                    rc[MR_PAIR] = (int)s_pair; rc[MR_BEST_I] = (int)st.best_i; rc[MR_BEST_J] = (int)st.best_j; rc[MR_CELLS_LO] = (int)(uint32_t)st.cells; rc[MR_CELLS_HI] = (int)(uint32_t)(st.cells >> 32);
+                    rc[MR_BUDGET] = (int)st.step_budget; rc[MR_STATUS] = (int)st.status; rc[MR_TSLOT] = (int)s_slot; rc[MR_SI] = (int)st.si; rc[MR_SJ] = (int)st.sj; rc[MR_DIR] = st.dir;
+                    rc[MR_PREV_DIR] = st.prev_dir; rc[MR_OFF] = st.off; rc[MR_OFF_MAX] = st.off_max; rc[MR_BEST_MAX] = st.best_max; rc[MR_Y_DROP] = (int)st.y_drop_iter;
+                    rc[MR_X_ITER] = st.x_drop_iter; rc[MR_D_CORNER] = st.D_corner; rc[MR_NSTEPS] = 0; rc[MR_TRACE_TOP] = (int)st.trace_top; rc[MR_NBLOCKS] = (int)st.nblocks; rc[MR_SEL] = 0;
+                }
+                lds_sync();
+                live_m |= 1u << solo;
+            } else live_m &= ~(1u << solo);
+        }
+        if (!live_m) break;
+
+        // ================= the slots: registers from memory, shift steps until a slot needs solo mode, registers to memory
+        {
+            char* const slot_mem = wave_mem + (uint32_t)g * MQ_SLOT_BYTES;   // this lane's slot
+            const int x_drop = bp.x_drop;
+            FillConsts fq;   // only the three gap constants (wave-uniform)
+            fq.go2 = splat(bp.gap_open); fq.ge2 = splat(gx); fq.ome2 = splat(clamp16(bp.gap_open - gx));
+            MultiConsts mc;  // eight cells per lane
+            mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : -32768;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+                int t[2];
+                for (int h = 0; h < 2; h++) {
+                    const int cell = 8 * l + 2 * k + h, k16 = cell & 15;
+                    const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
+                    const int art = mult ? max(-32768, mult * gx) : -32768;
+                    t[h] = max(art, max(-32768, (cell + 1) * gx));
+                }
+                mc.vtop[k] = pk(t[0], t[1]);
+            }
+            const uint64_t tcap64 = bp.trace_stride, bcap64 = bp.blocks_stride;
+            const uint32_t tcap = (uint32_t)(tcap64 < 0x7fffffffull ? tcap64 : 0x7fffffffull), bcap = (uint32_t)(bcap64 < 0x7fffffffull ? bcap64 : 0x7fffffffull);
+            // ---- slot state (row-uniform, replicated over the slot's lanes)
+            const bool live = (live_m >> g) & 1u;   // (all four, except when the batch holds fewer pairs than the wave has slots)
+            const char* rec = slot_mem + 2 * MQ_BUF_BYTES;
+#define BA_R(k) (live ? mq_load(rec + 4 * (k)) : 0)
+            const uint32_t pair = (uint32_t)BA_R(MR_PAIR), tslot = (uint32_t)BA_R(MR_TSLOT);
+            uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ), y_drop = (uint32_t)BA_R(MR_Y_DROP), nsteps = (uint32_t)BA_R(MR_NSTEPS);
+            uint32_t trace_top = (uint32_t)BA_R(MR_TRACE_TOP), nblocks = (uint32_t)BA_R(MR_NBLOCKS), sel = (uint32_t)BA_R(MR_SEL);
+            int dir = BA_R(MR_DIR), prev_dir = BA_R(MR_PREV_DIR), off = BA_R(MR_OFF), off_max = BA_R(MR_OFF_MAX), best_max = BA_R(MR_BEST_MAX);
+            int x_iter = BA_R(MR_X_ITER), D_corner = BA_R(MR_D_CORNER);
+#undef BA_R
+            const uint32_t qlen = live ? bp.q_len[pair] : 0u, rlen = live ? bp.r_len[pair] : 0u;
+            const uint8_t* qp = bp.pool + (live ? bp.q_off[pair] : 0ull); const uint8_t* rp = bp.pool + (live ? bp.r_off[pair] : 0ull);
+            int A_d[4], A_c[4], P_d[4], P_r[4];   // borders: (A) along the vector axis of the step at `dir`, (P) orthogonal
+            {
+                const char* b = slot_mem + (sel ^ 1u) * MQ_BUF_BYTES + l * 16;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    A_d[k] = live ? mq_load(b + 4 * k) : 0; A_c[k] = live ? mq_load(b + 256 + 4 * k) : 0;
+                    P_d[k] = live ? mq_load(b + 512 + 4 * k) : 0; P_r[k] = live ? mq_load(b + 768 + 4 * k) : 0;
+                }
+            }
+            // sequence bytes of the next step, fetched one step ahead for both possible directions
+            uint2 pf_qv = {0, 0}, pf_rv = {0, 0}, pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
+            bool leave = false;
+            // the slot's registers and the scalars of the step at the top into the buffer `which` (see above)
+            auto stage = [&](uint32_t which, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
+                char* b = slot_mem + which * MQ_BUF_BYTES;
+                *(int4*)(b + l * 16) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + 256 + l * 16) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
+                *(int4*)(b + 512 + l * 16) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 768 + l * 16) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
+                if (l == 0) {
+                    *(int4*)(b + 1024) = int4{1, (int)s_i, (int)s_j, s_off}; *(int4*)(b + 1040) = int4{(int)s_tt, (int)s_nb, s_dir, s_offadd};
+                    *(int*)(b + 1056) = s_corner;
+                }
+            };
+            do {
+                // ---- the step every live slot is about to take (scan_block.rs:147-246)
+                const bool right = dir == DIR_RIGHT;
+                const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (MQ_B - STEP);
+                const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
+                const bool q_out = si + MQ_B > qlen, r_out = sj + MQ_B > rlen;
+                // a step that could break early at the matrix edge (never with X-drop) or that the trace slot has no room for is not a slot's
+                bool elig = XDROP || ri + MQ_B <= lenV || rj + STEP <= lenC;
+                if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * MQ_B / 8) + 64 <= tcap;
+                leave = live && !elig;
+                const bool run = live && !leave;
+                const int off_n = off_max;
+                const int off_add = sat16(off - off_n);
+                const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
+                // the state before the step: for a slot that leaves (its registers do not survive the step) and for the checkpoint
+                if (live) stage(sel ^ 1u, si, sj, off_n, trace_top, nblocks, dir, off_add, corner);
+                uint2 vb, cbv;
+                {
+                    const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
+                    vb = right ? pf_qv : pf_rv; cbv = right ? pf_rc : pf_qc;
+                    if (__any(run && !pf_ok)) {   // a slot that has just taken its pair (back)
+                        if (run && !pf_ok) {
+                            const uint32_t* vp = (const uint32_t*)(Vp + ri + 8 * l);   // (images are 4-byte aligned, positions multiples of 8)
+                            vb.x = vp[0]; vb.y = vp[1];
+                            const uint32_t* cp = (const uint32_t*)(Cp + rj);
+                            cbv.x = cp[0]; cbv.y = cp[1];
+                        }
+                    }
+                    asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
+                    if (run) {                                    // for the step after this one, whichever way it goes
+                        const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + sj + 8 * l);
+                        const uint32_t* cq = (const uint32_t*)(qp + si + MQ_B); const uint32_t* cr = (const uint32_t*)(rp + sj + MQ_B);
+                        pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
+                        pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
+                        pf_ok = true;
+                    }
+                }
+                uint32_t* tw = nullptr;
+                if (TRACE) {
+                    tw = bp.trace_arena + (uint64_t)tslot * bp.trace_stride + trace_top + 4 * l;
+                    if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
+                        BlockRec br;
+                        br.i = right ? ri : rj; br.j = right ? rj : ri; br.h = (uint16_t)(right ? MQ_B : STEP); br.w = (uint16_t)(right ? STEP : MQ_B);
+                        br.trace_base = trace_top | (right ? 0x80000000u : 0u);
+                        bp.blocks[(uint64_t)tslot * bp.blocks_stride + nblocks] = br;
+                    }
+                }
+                MultiOut o;
+                multi_rect<KIND, TRACE>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, tw, run, o);
+
+                // ---- what does the step call for? (scan_block.rs:332-558; nothing is committed yet)
+                const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
+                const int new_off_max = off_n + o.mx - ZERO;
+                const bool improve = new_off_max > best_max;
+                const uint32_t new_y = improve ? 0u : y_drop + 1;
+                bool stop = q_out && r_out;                                                                   // end of the matrix
+                if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
+                stop = stop || (!q_out && !r_out && 2 * MQ_B <= max_size && new_y > MQ_B / STEP - 1);        // grow
+                const bool commit = run && !stop;
+                leave = leave || (run && stop);   // rolled back: the pair's state is what was staged before this step
+                if (commit) {
+                    if (improve) {
+                        if (keep_pre) sel ^= 1u;   // the state staged before this step is the checkpoint now (and yields the location of the maximum)
+                        best_max = new_off_max;
+                    }
+                    off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = dir; D_corner = o.corner_new;
+                    nsteps++;
+                    if (TRACE) { trace_top += STEP * MQ_B / 8; nblocks++; }
+                    if (XDROP) x_iter = (off_max < best_max - x_drop) ? x_iter + 1 : 0;
+                    const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
+                    si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
+                    const int ndir = go_down ? DIR_DOWN : DIR_RIGHT;
+                    if (ndir != dir) {   // the borders change roles with the direction
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int td = A_d[k], tc = A_c[k];
+                            A_d[k] = P_d[k]; A_c[k] = P_r[k]; P_d[k] = td; P_r[k] = tc;
+                        }
+                    }
+                    dir = ndir;
+                }
+            } while (!__any(leave));
+            // ---- every slot's state at the top of the loop to memory: the registers of the slots that took the step (the others'
+            // was staged before it)
+            if (live && !leave) stage(sel ^ 1u, si, sj, 0, trace_top, nblocks, dir, 0, 0);
+            if (live && l == 0) {
+                int* rc = (int*)(slot_mem + 2 * MQ_BUF_BYTES);
+                rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = prev_dir; rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
+                rc[MR_Y_DROP] = (int)y_drop; rc[MR_X_ITER] = x_iter; rc[MR_D_CORNER] = D_corner; rc[MR_NSTEPS] = (int)nsteps; rc[MR_TRACE_TOP] = (int)trace_top;
+                rc[MR_NBLOCKS] = (int)nblocks; rc[MR_SEL] = (int)sel;
+            }
+            const unsigned long long lm = __ballot(leave && l == 0);
+            pend_m = (uint32_t)((lm & 1ull) | ((lm >> 15) & 2ull) | ((lm >> 30) & 4ull) | ((lm >> 45) & 8ull));
+        }
+    }
+    // a fill wave joins the traceback side with one lane once the batch has no pairs left for it (see k_align)
+    if (batch_traceback) {
+        lds_sync();
+        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 1u, false);
+    }
+}
+
+}  // namespace ba

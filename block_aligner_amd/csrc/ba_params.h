@@ -110,6 +110,9 @@ constexpr uint32_t BIG_TILE = 2048;
 BA_HD constexpr uint64_t big_array_shorts(uint32_t max_size) { return (uint64_t)max_size + 64; }
 BA_HD constexpr uint64_t big_wave_shorts(uint32_t max_size) { return 6 * big_array_shorts(max_size); }
 
+constexpr uint32_t MQ_B_HOST = 128;   // k_multi: block size of a slot (ba_driver.hpp MQ_B)
+// k_multi: per wave and slot two state buffers and a record in the `big` arena (ba_multi.hpp)
+constexpr uint32_t MQ_BUF_BYTES = 4 * 256 + 64, MQ_SLOT_BYTES = 2 * MQ_BUF_BYTES + 128, MQ_WAVE_BYTES = 4 * MQ_SLOT_BYTES;
 constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...

@@ -16,7 +16,9 @@ path = sys.argv[1]
 kidx = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 min_v = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 lines = open(path).read().split("\n")
-starts = [i for i, l in enumerate(lines) if l.startswith("_ZN2ba7k_align") and "@" in l]
+import os
+KPAT = os.environ.get("KPAT", "_ZN2ba7k_align")
+starts = [i for i, l in enumerate(lines) if l.startswith(KPAT) and "@" in l]
 s = starts[kidx]
 e = next(i for i in range(s, len(lines)) if lines[i].startswith(".Lfunc_end"))
 print(lines[s].split(":")[0])
