@@ -563,27 +563,21 @@ struct PairState {
     uint32_t si, sj; int dir, prev_dir, off, off_max, best_max; uint32_t y_drop_iter; int x_drop_iter, D_corner;
     uint32_t best_i, best_j, ck_i, ck_j; int ck_off; uint32_t ck_tt, ck_nb;
     unsigned long long cells; uint32_t step_budget, trace_top, nblocks, status;
+    int exited;   // out of Aligner::run: 1 = the pair goes on in its slot (this state, borders in LDS), 0 = it is finished
 };
 constexpr uint32_t MQ_B = 128;   // block size of a slot of k_multi
-struct MultiIO {
-    int mode;            // 0: start the pair from scratch; 1: resume from `st` and the slot registers `reg`
-    bool allow_quad;     // the pair may go (back) to its slot once its next step is a plain shift step at MQ_B cells
-    bool forced;         // resume: the step at the top is taken here whatever it is (the slot rolled it back)
-    bool exited;         // out: true = the pair goes on in its slot (st / LDS hold its state), false = it is finished
-    int sel;             // which 16-lane slot of the wave holds the registers
-    PairState st;
-    // resume: the checkpoint registers hold the state BEFORE the last improving step (that step -- direction ck_dir at block
-    // position (st.ck_i, st.ck_j) -- is repeated once here, for the location of its maximum and the borders it leaves)
-    bool ck_pre; int ck_dir, ck_offadd, ck_corner;
-    // the slot's registers, 8 cells per lane in cell order: [0..3] D_col, [4..7] C_col, [8..11] D_row, [12..15] R_row, [16..31] the checkpoint likewise
-    int* reg;
-};
+// How a pair enters Aligner::run from k_multi (all passed and returned BY VALUE: through references or pointers the driver's
+// loop scalars are demoted to memory and its wave-uniform logic to vector code)
+enum { MM_NONE = -1, MM_FRESH = 0, MM_RESUME = 1 };
 
 // ------------------------------------------------------------------ driver
 // SPECIAL: the batch uses LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS. A separate instantiation, so the
 // common kernels carry none of that state (it costs registers: +30 % spills when folded into one kernel).
-template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL>
+struct NoState { int exited; };
+// MULTI: the instantiation k_multi (ba_multi.hpp) runs in its solo mode (entry / exit with a PairState; everything else is the per-pair driver)
+template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL, bool MULTI = false>
 struct Aligner {
+    typedef std::conditional_t<MULTI, PairState, NoState> RunOut;
     // The batch descriptor lives in device memory. Only the scalars the step loop needs are copied into registers;
     // everything else (a couple of dozen per-pair output pointers) is re-read where it is used, once per pair, so it
     // does not sit in SGPRs across the whole persistent loop and get spilled to VGPR lanes.
@@ -882,7 +876,13 @@ struct Aligner {
     }
 
     // (always inlined: as a real call the Aligner object and everything it references would live in scratch memory)
-    __device__ __forceinline__ void run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr, MultiIO* mio = nullptr) {
+    // mmode / min / allow_quad / forced_in: the multi-pair kernel's entry (MM_*): resume from `min` (borders already in LDS, checkpoint
+    // in ck_reg: see import_slot), leave again -- returning the state, exited = 1 -- once the next step is a plain shift step at MQ_B
+    // cells (allow_quad), after taking the step at the top here whatever it is (forced_in: the slot rolled it back)
+    __device__ __forceinline__ RunOut run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr, const int mmode_in = MM_NONE,
+                                          const RunOut min = RunOut{}, const bool allow_quad = false, const bool forced_in = false) {
+        RunOut mout{}; bool forced = MULTI && forced_in;
+        const int mmode = MULTI ? mmode_in : (int)MM_NONE;
         BA_TSTAMP(tq0);
         q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
         qlen = coldp()->q_len[pair_in]; rlen = coldp()->r_len[pair_in];
@@ -899,7 +899,7 @@ struct Aligner {
         FqeOut fq{0, 0};
         // scratch reset (scan_block.rs:1322-1339): borders to MIN = 0. The checkpoint copies need no reset: they are
         // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
-        lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size);
+        if (!MULTI || mmode != MM_RESUME) { lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size); }
         short* temp1 = L.misc + 16; short* temp2 = L.misc + 32;
         lds_fill0(temp1, 32);
 
@@ -954,55 +954,13 @@ struct Aligner {
             ck_in_regs = true;
             lds_sync();
         }
-        if (mio && mio->mode == 1) {   // a pair that comes back from its slot of the multi-pair kernel (ba_multi.hpp)
-            const PairState& st = mio->st;
+        if constexpr (MULTI) if (mmode == MM_RESUME) {   // a pair that comes back from its slot of the multi-pair kernel (ba_multi.hpp): borders in LDS, checkpoint in ck_reg
+            const PairState& st = min;
             si = st.si; sj = st.sj; dir = st.dir; prev_dir = st.prev_dir; off = st.off; off_max = st.off_max; best_max = st.best_max;
             y_drop_iter = st.y_drop_iter; x_drop_iter = st.x_drop_iter; D_corner = st.D_corner; cells = st.cells; step_budget = st.step_budget;
             park<5>(parked, (int)st.best_i); park<6>(parked, (int)st.best_j);
             park<0>(parked, (int)st.ck_i); park<1>(parked, (int)st.ck_j); park<2>(parked, st.ck_off);
             if (TRACE) { trace_top = st.trace_top; nblocks = st.nblocks; status = st.status; park<3>(parked, (int)st.ck_tt); park<4>(parked, (int)st.ck_nb); }
-            const int lane = lane_id(), l8 = 8 * (lane & 15);
-            const bool mine = (lane >> 4) == mio->sel;
-            const int* rg = mio->reg;
-            auto slot_to_lds = [&](int base) {   // 16 lanes x 4 registers x 2 cells = 128 entries per array, in cell order
-                lds_sync();
-                if (mine) {
-                    *(int4*)(L.D_col + l8) = int4{rg[base + 0], rg[base + 1], rg[base + 2], rg[base + 3]};
-                    *(int4*)(L.C_col + l8) = int4{rg[base + 4], rg[base + 5], rg[base + 6], rg[base + 7]};
-                    *(int4*)(L.D_row + l8) = int4{rg[base + 8], rg[base + 9], rg[base + 10], rg[base + 11]};
-                    *(int4*)(L.R_row + l8) = int4{rg[base + 12], rg[base + 13], rg[base + 14], rg[base + 15]};
-                }
-                lds_sync();
-            };
-            const bool need_ck = MQ_B < max_size;
-            if (mio->ck_pre || need_ck) {
-                slot_to_lds(16);
-                int cDc = *(const int*)(L.D_col + 2 * lane), cCc = *(const int*)(L.C_col + 2 * lane);
-                int cDr = *(const int*)(L.D_row + 2 * lane), cRr = *(const int*)(L.R_row + 2 * lane);
-                lds_sync();
-                if (mio->ck_pre) {
-                    // the last improving step once more (it ran in the slot, which keeps neither the location of a step's maximum nor
-                    // the borders after it, only the state before it): scan_block.rs:370-427 for that step
-                    constexpr int PR_DIST = (int)(lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u) / 2);
-                    const bool cright = mio->ck_dir == DIR_RIGHT;
-                    const uint8_t* seqV = cright ? q : r; const uint8_t* seqC = cright ? r : q;
-                    const uint32_t cri = cright ? st.ck_i : st.ck_j, crj = (cright ? st.ck_j : st.ck_i) + MQ_B - STEP;
-                    const int vc = (int)*(const unsigned short*)(seqV + cri + 2 * lane);
-                    const unsigned long long cb = load_cols(seqC + crj);
-                    FastOut fo{};
-                    if constexpr (KIND != KIND_PROFILE) {
-                        if (cright) fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, 64, mio->ck_corner, mio->ck_offadd, -1, nullptr, fo);
-                        else fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, 64, mio->ck_corner, mio->ck_offadd, -1, nullptr, fo);
-                    }
-                    if (XDROP) {
-                        if (cright) { park<5>(parked, (int)(st.ck_i + (uint32_t)fo.row)); park<6>(parked, (int)(st.ck_j + (MQ_B - STEP) + (uint32_t)fo.col)); }
-                        else { park<5>(parked, (int)(st.ck_i + (MQ_B - STEP) + (uint32_t)fo.col)); park<6>(parked, (int)(st.ck_j + (uint32_t)fo.row)); }
-                    }
-                    lds_sync();
-                }
-                ck_reg[0] = cDc; ck_reg[1] = cCc; ck_reg[2] = cDr; ck_reg[3] = cRr; ck_in_regs = true;
-            }
-            slot_to_lds(0);
         }
         // speculative grows (see the grow transition below): the checkpoint the chain started from
         uint32_t ub_size = 0, ub_tt = 0, ub_nb = 0, ub_budget = 0; int ub_xiter = 0; unsigned long long ub_cells = 0;
@@ -1057,11 +1015,11 @@ struct Aligner {
             BA_TSTAMP(tsa);
             const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
-            if (mio && mio->allow_quad && fast && !mio->forced && block_size == MQ_B && min_size == MQ_B && !chain && !no_spec) {
+            if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && fast && !forced && block_size == MQ_B && min_size == MQ_B && !chain && !no_spec) {
                 // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
                 // four pairs to a wave. The borders are in LDS (cell order); the checkpoint follows them at entries MQ_B .. 2 MQ_B.
                 step_budget++;   // (the step this iteration counted has not been taken)
-                PairState& st = mio->st;
+                PairState& st = mout;
                 st.si = si; st.sj = sj; st.dir = dir; st.prev_dir = prev_dir; st.off = prev_off; st.off_max = off_max; st.best_max = best_max;
                 st.y_drop_iter = y_drop_iter; st.x_drop_iter = x_drop_iter; st.D_corner = D_corner; st.cells = cells; st.step_budget = step_budget;
                 st.best_i = (uint32_t)unpark<5>(parked); st.best_j = (uint32_t)unpark<6>(parked);
@@ -1080,10 +1038,10 @@ struct Aligner {
                     }
                     lds_sync();
                 }
-                mio->exited = true;
-                return;
+                mout.exited = 1;
+                return mout;
             }
-            if (mio) mio->forced = false;
+            if (MULTI) forced = false;
             BA_TSTAMP(tsb);
             const uint32_t tb = trace_top;
             const bool spec = TRACE && chain && dir == DIR_GROW;   // this grow step runs without trace flags and location bookkeeping
@@ -1146,7 +1104,7 @@ struct Aligner {
                     rs.si = si; rs.sj = sj; rs.dir = dir; rs.prev_dir = prev_dir; rs.off = off; rs.prev_off = prev_off; rs.off_max = off_max;
                     rs.off_add = off_add; rs.best_max = best_max; rs.y_drop_iter = y_drop_iter; rs.x_drop_iter = x_drop_iter; rs.D_corner = D_corner;
                     rs.step_budget = step_budget; rs.run_exit = RUN_EXIT_POST; rs.cur = cur; rs.fo = fo;
-                    rs = fast_run(rs, corner, block_size, min_size, max_size, mio && mio->allow_quad && block_size == MQ_B && min_size == MQ_B);
+                    rs = fast_run(rs, corner, block_size, min_size, max_size, MULTI && mmode != MM_NONE && allow_quad && block_size == MQ_B && min_size == MQ_B);
                     si = rs.si; sj = rs.sj; dir = rs.dir; prev_dir = rs.prev_dir; off = rs.off; prev_off = rs.prev_off; off_max = rs.off_max;
                     off_add = rs.off_add; best_max = rs.best_max; y_drop_iter = rs.y_drop_iter; x_drop_iter = rs.x_drop_iter; D_corner = rs.D_corner;
                     step_budget = rs.step_budget; run_exit = rs.run_exit; cur = rs.cur; fo = rs.fo;
@@ -1312,7 +1270,7 @@ struct Aligner {
                 if (coldp()->trace_words_out) coldp()->trace_words_out[pair] = trace_top;
             }
             hand_off(slot, pair, ri, rj);
-            return;
+            return mout;
         }
         // pair-slot batches: pairs shorter than inline_len2 leave their paths to k_walk (one pair per lane) instead of this wave's lane 0
         const bool walk_later = TRACE && coldp()->trace_off && qlen + rlen < coldp()->inline_len2;
@@ -1337,6 +1295,55 @@ struct Aligner {
             if (coldp()->slot_out) coldp()->slot_out[pair] = slot;
             if (TRACE && coldp()->trace_off) coldp()->slot_info[pair] = SlotInfo{pair, walk_later ? nblocks : ~0u, ri, rj};   // pair-slot batches: k_walk's task (~0: nothing left to walk)
         }
+        return mout;
+    }
+
+    // k_multi, before run(MM_RESUME): a slot's registers (8 cells per lane, cell order; lanes 0 .. 15 hold them: reg[0..3] D_col, [4..7]
+    // C_col, [8..11] D_row, [12..15] R_row, ckr[] the checkpoint likewise) become this wave's LDS borders and ck_reg. ck_pre: the
+    // checkpoint registers hold the state BEFORE the last improving step (the slot keeps neither the location of a step's maximum
+    // nor the borders after it): that step -- direction ck_dir at block position (ck_i, ck_j) -- is taken once more here, for the
+    // location (returned in best_i / best_j; scan_block.rs:370-404) and the borders the reference's checkpoint holds (406-427).
+    __device__ __forceinline__ void import_slot(const int (&reg)[16], const int (&ckr)[16], uint32_t pair_in, bool have_ck, bool ck_pre, int ck_dir, int ck_offadd, int ck_corner,
+                                                uint32_t ck_i, uint32_t ck_j, uint32_t& best_i, uint32_t& best_j) {
+        const int lane = lane_id(), l8 = 8 * (lane & 15);
+        const bool mine = lane < 16;
+        q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
+        if (have_ck) {
+            lds_sync();
+            if (mine) {
+                *(int4*)(L.D_col + l8) = int4{ckr[0], ckr[1], ckr[2], ckr[3]}; *(int4*)(L.C_col + l8) = int4{ckr[4], ckr[5], ckr[6], ckr[7]};
+                *(int4*)(L.D_row + l8) = int4{ckr[8], ckr[9], ckr[10], ckr[11]}; *(int4*)(L.R_row + l8) = int4{ckr[12], ckr[13], ckr[14], ckr[15]};
+            }
+            lds_sync();
+            int cDc = *(const int*)(L.D_col + 2 * lane), cCc = *(const int*)(L.C_col + 2 * lane);
+            int cDr = *(const int*)(L.D_row + 2 * lane), cRr = *(const int*)(L.R_row + 2 * lane);
+            lds_sync();
+            if (ck_pre) {
+                constexpr int PR_DIST = (int)(lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u) / 2);
+                const bool cright = ck_dir == DIR_RIGHT;
+                const uint8_t* seqV = cright ? q : r; const uint8_t* seqC = cright ? r : q;
+                const uint32_t cri = cright ? ck_i : ck_j, crj = (cright ? ck_j : ck_i) + MQ_B - STEP;
+                const int vc = (int)*(const unsigned short*)(seqV + cri + 2 * lane);
+                const unsigned long long cb = load_cols(seqC + crj);
+                FastOut fo{};
+                if constexpr (KIND != KIND_PROFILE) {
+                    if (cright) fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, 64, ck_corner, ck_offadd, -1, nullptr, fo);
+                    else fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, 64, ck_corner, ck_offadd, -1, nullptr, fo);
+                }
+                if (XDROP) {
+                    if (cright) { best_i = ck_i + (uint32_t)fo.row; best_j = ck_j + (MQ_B - STEP) + (uint32_t)fo.col; }
+                    else { best_i = ck_i + (MQ_B - STEP) + (uint32_t)fo.col; best_j = ck_j + (uint32_t)fo.row; }
+                }
+                lds_sync();
+            }
+            ck_reg[0] = cDc; ck_reg[1] = cCc; ck_reg[2] = cDr; ck_reg[3] = cRr; ck_in_regs = true;
+        }
+        lds_sync();
+        if (mine) {
+            *(int4*)(L.D_col + l8) = int4{reg[0], reg[1], reg[2], reg[3]}; *(int4*)(L.C_col + l8) = int4{reg[4], reg[5], reg[6], reg[7]};
+            *(int4*)(L.D_row + l8) = int4{reg[8], reg[9], reg[10], reg[11]}; *(int4*)(L.R_row + l8) = int4{reg[12], reg[13], reg[14], reg[15]};
+        }
+        lds_sync();
     }
 };
 

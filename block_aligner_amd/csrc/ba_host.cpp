@@ -494,7 +494,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
     if (pc == BA_PCLASS_BIG && special_of(mode)) return fail("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
-    b->lds = ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
+    b->lds = (b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc))) + (trace ? ba::TB_LDS_BYTES : 0u);
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip

@@ -109,7 +109,11 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
             d[k] = dn[k]; c[k] = cn[k];
         }
         if (TRACE && (j & 3) == 3) {
+#ifndef MQ_X_NOTRSTORE
             if (store) *(int4*)(tout + (j >> 2) * 64) = int4{tacc[0], tacc[1], tacc[2], tacc[3]};
+#else
+            asm volatile("" :: "v"(tacc[0]), "v"(tacc[1]), "v"(tacc[2]), "v"(tacc[3]));
+#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) tacc[k] = 0;
         }
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     __syncthreads();
     constexpr uint32_t LCLS = (uint32_t)PMAX * 128u;
     constexpr uint32_t ab = lds_array_bytes_h(LCLS);
-    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * lds_wave_bytes_h(LCLS);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * mq_wave_bytes_h(LCLS);
     WaveLds L;
     L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
     L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
@@ -178,8 +182,15 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     const int gx = bp.gap_extend;
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
+#ifdef BA_TIMING
+    if (bp.prof && blockIdx.x == 0 && wave == 1 && is_lane(0)) atomicMax(bp.prof + 43, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    unsigned long long t_solo = 0, t_quad = 0, t_wait = 0, n_solo = 0, n_quad = 0;
+#endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
-        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(LCLS), 64u, true);
+        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * mq_wave_bytes_h(LCLS), 64u, true);
+#ifdef BA_TIMING
+        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
         return;
     }
     const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
@@ -188,6 +199,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     const bool keep_pre = XDROP || MQ_B < max_size;   // a slot keeps the state before its last improving step
     char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * MQ_WAVE_BYTES;
 
+    // (values derived again after the per-pair driver instead of being kept across it: laundered so that they are not hoisted)
+    auto coldp_big = [&]() { const __attribute__((address_space(4))) BatchParams* p = (const __attribute__((address_space(4))) BatchParams*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p->big; };
+    auto fill_wave_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); const uint32_t st = ((const __attribute__((address_space(4))) BatchParams*)__builtin_amdgcn_kernarg_segment_ptr())->tb_stride;
+                                const uint32_t cb = (TRACE && st > 0) ? (b + st - 1) / st + (b % st == 0 ? 1u : 0u) : 0u; return b * WAVES_PER_WG + w - cb; };
     uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
     uint32_t w_next = 0, w_end = 0;
     bool more = true;
@@ -212,6 +227,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             } else if (live_m && live_m != 15u) { solo = __builtin_ctz(live_m); to_end = true; }
             else break;
 
+            BA_TSTAMP(ts_a);
             FillConsts fc;   // two cells per lane (as k_align)
             {
                 fc.gap_extend = gx;
@@ -228,12 +244,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 fc.vconst = pk(v[0], v[1]);
                 fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
             }
-            Aligner<PMAX, KIND, TRACE, XDROP, false> al(bp, L, fc);
-            MultiIO io;
-            io.mode = fresh ? 0 : 1; io.allow_quad = !to_end; io.forced = !fresh && !to_end; io.exited = false; io.sel = 0;
-            io.ck_pre = false; io.ck_dir = 0; io.ck_offadd = 0; io.ck_corner = 0;
-            int reg[32];
-            io.reg = reg;
+            Aligner<PMAX, KIND, TRACE, XDROP, false, true> al(bp, L, fc);
+            PairState st{};
             uint32_t s_pair, s_slot;
             char* const smem_s = wave_mem + (uint32_t)solo * MQ_SLOT_BYTES;
             char* const rec = smem_s + 2 * MQ_BUF_BYTES;
@@ -242,6 +254,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 // a free trace slot of this wave (a slot is busy from the pair's start until its traceback is done)
                 s_slot = fill_wave * bp.slots_per_wave;
                 if (batch_traceback) {
+                    BA_TSTAMP(tw_a);
                     uint32_t seen = 0, idle_n = 0; bool got = false;
                     const uint32_t limit = (1u << 20) * (1u + (uint32_t)(bp.blocks_stride >> 15));
                     for (;;) {
@@ -259,6 +272,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                         else if (++idle_n > limit) break;
                         __builtin_amdgcn_s_sleep(64);
                     }
+#ifdef BA_TIMING
+                    t_wait += __builtin_amdgcn_s_memtime() - tw_a;
+#endif
                     if (!got) {   // the traceback side has stopped making progress: report instead of hanging
                         al.status = ST_SLOT_TIMEOUT;
                         if (is_lane(0)) { bp.score[s_pair] = 0; bp.query_idx[s_pair] = 0; bp.reference_idx[s_pair] = 0; }
@@ -277,7 +293,6 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 const char* live_b = smem_s + (s_sel ^ 1u) * MQ_BUF_BYTES; const char* ck_b = smem_s + s_sel * MQ_BUF_BYTES;
                 const int cv = lane < 16 ? mq_load(ck_b + 1024 + 4 * lane) : 0;   // the checkpoint's scalars
                 s_pair = (uint32_t)BA_W(rv, MR_PAIR); s_slot = (uint32_t)BA_W(rv, MR_TSLOT);
-                PairState& st = io.st;
                 st.si = (uint32_t)BA_W(rv, MR_SI); st.sj = (uint32_t)BA_W(rv, MR_SJ); st.dir = BA_W(rv, MR_DIR); st.prev_dir = BA_W(rv, MR_PREV_DIR);
                 st.off = BA_W(rv, MR_OFF); st.off_max = BA_W(rv, MR_OFF_MAX); st.best_max = BA_W(rv, MR_BEST_MAX);
                 st.y_drop_iter = (uint32_t)BA_W(rv, MR_Y_DROP); st.x_drop_iter = BA_W(rv, MR_X_ITER); st.D_corner = BA_W(rv, MR_D_CORNER);
@@ -289,47 +304,69 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 st.step_budget = bud > ns ? bud - ns : 1u;
                 st.status = (uint32_t)BA_W(rv, MR_STATUS);
                 const int flag = BA_W(cv, 0);
-                io.ck_pre = flag != 0;
+                const bool ck_pre = flag != 0;
                 st.ck_i = (uint32_t)BA_W(cv, 1); st.ck_j = (uint32_t)BA_W(cv, 2); st.ck_off = BA_W(cv, 3);
                 st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * MQ_B / 8 : 0u); st.ck_nb = (uint32_t)BA_W(cv, 5) + (flag ? 1u : 0u);
-                io.ck_dir = BA_W(cv, 6); io.ck_offadd = BA_W(cv, 7); io.ck_corner = BA_W(cv, 8);
+                const int ck_dir = BA_W(cv, 6), ck_offadd = BA_W(cv, 7), ck_corner = BA_W(cv, 8);
 #undef BA_W
                 {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 15), into the canonical order D_col, C_col, D_row, R_row
-                    const bool lr = st.dir == DIR_RIGHT, cr = io.ck_dir == DIR_RIGHT;
+                    int reg[16], ckr[16];
+                    const bool lr = st.dir == DIR_RIGHT, cr = ck_dir == DIR_RIGHT;
                     const uint32_t oAd = (lr ? 0u : 512u) + l * 16, oAc = (lr ? 256u : 768u) + l * 16, oPd = (lr ? 512u : 0u) + l * 16, oPr = (lr ? 768u : 256u) + l * 16;
                     const uint32_t cAd = (cr ? 0u : 512u) + l * 16, cAc = (cr ? 256u : 768u) + l * 16, cPd = (cr ? 512u : 0u) + l * 16, cPr = (cr ? 768u : 256u) + l * 16;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         reg[k] = mq_load(live_b + oAd + 4 * k); reg[4 + k] = mq_load(live_b + oAc + 4 * k); reg[8 + k] = mq_load(live_b + oPd + 4 * k); reg[12 + k] = mq_load(live_b + oPr + 4 * k);
-                        reg[16 + k] = mq_load(ck_b + cAd + 4 * k); reg[20 + k] = mq_load(ck_b + cAc + 4 * k); reg[24 + k] = mq_load(ck_b + cPd + 4 * k); reg[28 + k] = mq_load(ck_b + cPr + 4 * k);
+                        ckr[k] = mq_load(ck_b + cAd + 4 * k); ckr[4 + k] = mq_load(ck_b + cAc + 4 * k); ckr[8 + k] = mq_load(ck_b + cPd + 4 * k); ckr[12 + k] = mq_load(ck_b + cPr + 4 * k);
                     }
+                    al.import_slot(reg, ckr, s_pair, ck_pre || MQ_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j);
                 }
             }
             al.trace = bp.trace_arena + (uint64_t)s_slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)s_slot * bp.blocks_stride;
             al.ckpt = bp.ckpt + (uint64_t)(fill_wave + bp.ckpt_wave0) * 8 * bp.max_size;
-            al.run(s_pair, s_slot, batch_traceback, nullptr, &io);
+            // The per-pair driver needs every scalar register: what the wave keeps across it is parked in the lanes of one VGPR
+            // (the compiler would otherwise spill and reload these values inside the driver's inner loops).
+            int keepv = 0;
+            park<0>(keepv, (int)live_m); park<1>(keepv, (int)pend_m); park<2>(keepv, (int)w_next); park<3>(keepv, (int)w_end);
+            park<4>(keepv, (more ? 1 : 0) | (fresh ? 2 : 0) | (to_end ? 4 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair); park<7>(keepv, (int)s_slot);
+            BA_TSTAMP(tr_a);
+            st = al.run(s_pair, s_slot, batch_traceback, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh && !to_end);
+            live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
+            { const int fl = unpark<4>(keepv); more = fl & 1; fresh = fl & 2; to_end = fl & 4; }
+            solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv); s_slot = (uint32_t)unpark<7>(keepv);
+            char* const smem_s2 = (char*)coldp_big() + (uint64_t)fill_wave_of() * MQ_WAVE_BYTES + (uint32_t)solo * MQ_SLOT_BYTES;
+            char* const rec2 = smem_s2 + 2 * MQ_BUF_BYTES;
+#ifdef BA_TIMING
+            {   // development: the per-pair driver's phase timers (as k_align), + 45 = run(), 56 / 57 / 58 = run() of a new pair / a pair back from its slot / a pair taken to its end
+                const unsigned long long tr_b = __builtin_amdgcn_s_memtime();
+                al.prof[45] += tr_b - tr_a; al.prof[46] += fresh ? 1 : 0;
+                if (bp.prof && is_lane(0)) {
+                    for (int k = 0; k < 48; k++) if (k != 17 && !(k >= 20 && k < 32) && !(k >= 40 && k < 44)) atomicAdd(bp.prof + k, al.prof[k]);
+                    atomicAdd(bp.prof + (fresh ? 56 : (to_end ? 58 : 57)), tr_b - tr_a);
+                }
+            }
+#endif
             pend_m &= ~(1u << solo);
-            if (io.exited) {   // the pair's next step is a plain shift step at MQ_B cells: into the slot (its memory)
-                const PairState& st = io.st;
+            if (st.exited) {   // the pair's next step is a plain shift step at MQ_B cells: into the slot (its memory)
                 const bool rgt = st.dir == DIR_RIGHT;
                 if (lane < 16) {
                     const int l8 = 8 * l;
                     const int4 a_d = *(const int4*)((rgt ? L.D_col : L.D_row) + l8), a_c = *(const int4*)((rgt ? L.C_col : L.R_row) + l8);
                     const int4 p_d = *(const int4*)((rgt ? L.D_row : L.D_col) + l8), p_r = *(const int4*)((rgt ? L.R_row : L.C_col) + l8);
-                    char* b1 = smem_s + MQ_BUF_BYTES;   // the state at the top of the loop: buffer 1 (sel = 0)
+                    char* b1 = smem_s2 + MQ_BUF_BYTES;   // the state at the top of the loop: buffer 1 (sel = 0)
                     *(int4*)(b1 + l * 16) = a_d; *(int4*)(b1 + 256 + l * 16) = a_c; *(int4*)(b1 + 512 + l * 16) = p_d; *(int4*)(b1 + 768 + l * 16) = p_r;
                     if (MQ_B < max_size) {   // the checkpoint as the reference keeps it (after its step): buffer 0
-                        char* b0 = smem_s;
+                        char* b0 = smem_s2;
                         *(int4*)(b0 + l * 16) = *(const int4*)(L.D_col + MQ_B + l8); *(int4*)(b0 + 256 + l * 16) = *(const int4*)(L.C_col + MQ_B + l8);
                         *(int4*)(b0 + 512 + l * 16) = *(const int4*)(L.D_row + MQ_B + l8); *(int4*)(b0 + 768 + l * 16) = *(const int4*)(L.R_row + MQ_B + l8);
                     }
                 }
                 if (is_lane(0)) {
-                    char* b0 = smem_s;
+                    char* b0 = smem_s2;
                     *(int4*)(b0 + 1024) = int4{0, (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + 1040) = int4{(int)st.ck_tt, (int)st.ck_nb, DIR_RIGHT, 0};
                     *(int*)(b0 + 1056) = 0;
-                    int* rc = (int*)rec;
+                    int* rc = (int*)rec2;
                     rc[MR_PAIR] = (int)s_pair; rc[MR_BEST_I] = (int)st.best_i; rc[MR_BEST_J] = (int)st.best_j; rc[MR_CELLS_LO] = (int)(uint32_t)st.cells; rc[MR_CELLS_HI] = (int)(uint32_t)(st.cells >> 32);
                     rc[MR_BUDGET] = (int)st.step_budget; rc[MR_STATUS] = (int)st.status; rc[MR_TSLOT] = (int)s_slot; rc[MR_SI] = (int)st.si; rc[MR_SJ] = (int)st.sj; rc[MR_DIR] = st.dir;
                     rc[MR_PREV_DIR] = st.prev_dir; rc[MR_OFF] = st.off; rc[MR_OFF_MAX] = st.off_max; rc[MR_BEST_MAX] = st.best_max; rc[MR_Y_DROP] = (int)st.y_drop_iter;
@@ -338,11 +375,15 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 lds_sync();
                 live_m |= 1u << solo;
             } else live_m &= ~(1u << solo);
+#ifdef BA_TIMING
+            t_solo += __builtin_amdgcn_s_memtime() - ts_a; n_solo++;
+#endif
         }
         if (!live_m) break;
 
         // ================= the slots: registers from memory, shift steps until a slot needs solo mode, registers to memory
         {
+            BA_TSTAMP(tq_a);
             char* const slot_mem = wave_mem + (uint32_t)g * MQ_SLOT_BYTES;   // this lane's slot
             const int x_drop = bp.x_drop;
             FillConsts fq;   // only the three gap constants (wave-uniform)
@@ -384,17 +425,33 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     P_d[k] = live ? mq_load(b + 512 + 4 * k) : 0; P_r[k] = live ? mq_load(b + 768 + 4 * k) : 0;
                 }
             }
+            // While the slots run, the two buffers of every slot live in this wave's LDS region (the solo borders' space): the checkpoint
+            // (buffer `sel`) comes from the arena now and goes back after the loop; the other one is rewritten before every step.
+            char* const lbuf = base + (uint32_t)g * 2048u;                       // this slot's buffers: + which * 1024
+            int* const lsc = (int*)(base + MQ_LDS_SCALARS) + (uint32_t)g * 18u;   // their scalars: + which * 9
+            lds_sync();
+            if (live) {
+                const char* cb = slot_mem + sel * MQ_BUF_BYTES;
+                char* d = lbuf + sel * 1024u + l * 16;
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const char* sp = cb + a * 256 + l * 16;
+                    *(int4*)(d + a * 256) = int4{mq_load(sp), mq_load(sp + 4), mq_load(sp + 8), mq_load(sp + 12)};
+                }
+                if (l < 9) lsc[sel * 9u + l] = mq_load(cb + 1024 + 4 * l);
+            }
+            lds_sync();
             // sequence bytes of the next step, fetched one step ahead for both possible directions
             uint2 pf_qv = {0, 0}, pf_rv = {0, 0}, pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
             bool leave = false;
             // the slot's registers and the scalars of the step at the top into the buffer `which` (see above)
             auto stage = [&](uint32_t which, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
-                char* b = slot_mem + which * MQ_BUF_BYTES;
-                *(int4*)(b + l * 16) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + 256 + l * 16) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
-                *(int4*)(b + 512 + l * 16) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 768 + l * 16) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
+                char* b = lbuf + which * 1024u + l * 16;
+                *(int4*)(b) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + 256) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
+                *(int4*)(b + 512) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 768) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
                 if (l == 0) {
-                    *(int4*)(b + 1024) = int4{1, (int)s_i, (int)s_j, s_off}; *(int4*)(b + 1040) = int4{(int)s_tt, (int)s_nb, s_dir, s_offadd};
-                    *(int*)(b + 1056) = s_corner;
+                    int* sc = lsc + which * 9u;
+                    sc[0] = 1; sc[1] = (int)s_i; sc[2] = (int)s_j; sc[3] = s_off; sc[4] = (int)s_tt; sc[5] = (int)s_nb; sc[6] = s_dir; sc[7] = s_offadd; sc[8] = s_corner;
                 }
             };
             do {
@@ -412,7 +469,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 const int off_add = sat16(off - off_n);
                 const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
                 // the state before the step: for a slot that leaves (its registers do not survive the step) and for the checkpoint
+#ifndef MQ_X_NOSTAGE
                 if (live) stage(sel ^ 1u, si, sj, off_n, trace_top, nblocks, dir, off_add, corner);
+#endif
                 uint2 vb, cbv;
                 {
                     const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
@@ -478,10 +537,25 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     }
                     dir = ndir;
                 }
+#ifdef BA_TIMING
+                n_quad++;
+#endif
             } while (!__any(leave));
             // ---- every slot's state at the top of the loop to memory: the registers of the slots that took the step (the others'
             // was staged before it)
             if (live && !leave) stage(sel ^ 1u, si, sj, 0, trace_top, nblocks, dir, 0, 0);
+            lds_sync();
+            if (live) {   // both buffers back to the arena (solo mode needs the LDS region, and reads a pair's state from the arena)
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const char* sp = lbuf + w * 1024 + l * 16;
+                    char* d = slot_mem + w * MQ_BUF_BYTES + l * 16;
+#pragma unroll
+                    for (int a = 0; a < 4; a++) *(int4*)(d + a * 256) = *(const int4*)(sp + a * 256);
+                    if (l < 9) *(int*)(slot_mem + w * MQ_BUF_BYTES + 1024 + 4 * l) = lsc[w * 9 + l];
+                }
+            }
+            lds_sync();
             if (live && l == 0) {
                 int* rc = (int*)(slot_mem + 2 * MQ_BUF_BYTES);
                 rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = prev_dir; rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
@@ -490,12 +564,27 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             }
             const unsigned long long lm = __ballot(leave && l == 0);
             pend_m = (uint32_t)((lm & 1ull) | ((lm >> 15) & 2ull) | ((lm >> 30) & 4ull) | ((lm >> 45) & 8ull));
+#ifdef BA_TIMING
+            t_quad += __builtin_amdgcn_s_memtime() - tq_a;
+#endif
         }
     }
+#ifdef BA_TIMING
+    if (bp.prof && is_lane(0)) {
+        atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        atomicAdd(bp.prof + 50, t_solo); atomicAdd(bp.prof + 51, t_quad); atomicAdd(bp.prof + 52, t_wait); atomicAdd(bp.prof + 53, n_solo); atomicAdd(bp.prof + 54, n_quad); atomicAdd(bp.prof + 55, 1ull);
+    }
+#endif
     // a fill wave joins the traceback side with one lane once the batch has no pairs left for it (see k_align)
     if (batch_traceback) {
         lds_sync();
-        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 1u, false);
+#ifndef MQ_HELPER_LANES
+#define MQ_HELPER_LANES 1u
+#endif
+        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, MQ_HELPER_LANES, false);
+#ifdef BA_TIMING
+        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     }
 }
 

@@ -113,6 +113,9 @@ BA_HD constexpr uint64_t big_wave_shorts(uint32_t max_size) { return 6 * big_arr
 constexpr uint32_t MQ_B_HOST = 128;   // k_multi: block size of a slot (ba_driver.hpp MQ_B)
 // k_multi: per wave and slot two state buffers and a record in the `big` arena (ba_multi.hpp)
 constexpr uint32_t MQ_BUF_BYTES = 4 * 256 + 64, MQ_SLOT_BYTES = 2 * MQ_BUF_BYTES + 128, MQ_WAVE_BYTES = 4 * MQ_SLOT_BYTES;
+// k_multi: while the slots run, the same buffers live in the wave's LDS region (the solo borders' space, which the slots do not need):
+// 4 slots x 2 buffers x 1 KB of borders, then 8 x 9 scalars
+constexpr uint32_t MQ_LDS_SCALARS = 8192, MQ_LDS_BYTES = 8192 + 8 * 36 + 32;
 constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
@@ -120,9 +123,12 @@ BA_HD constexpr uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size 
 BA_HD constexpr uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_array_bytes_h(max_size) + 128; }
 BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }
 BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
+BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > 8512u ? lds_wave_bytes_h(max_size) : 8512u; }   // k_multi (MQ_LDS_BYTES)
+BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * mq_wave_bytes_h(max_size); }
 // TRACE batches: one more region behind the waves' for the workgroup's traceback wave (ba_driver.hpp tb_step): per lane
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
 constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;   // table first, then the records (a helper fill wave uses one)
+static_assert(MQ_LDS_BYTES <= 8512u, "k_multi LDS");
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES <= lds_wave_bytes_h(128), "traceback LDS regions");
 
 }  // namespace ba

@@ -2,10 +2,12 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from block_aligner_amd import hip as H, workloads as W
+if os.environ.get("BA_LIB"):   # another build of the library (same-box A/B)
+    H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), os.environ["BA_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 trace = os.environ.get("C3_TRACE", "1") == "1"
 w = W.config3(n, workers=int(os.environ.get("BA_GEN_WORKERS", "8")), size=(128, 1024), trace=trace)
 b = W.make_batch(H, w)
 ms = min(b.run() for _ in range(3))
 r = b.results(); cells = int(r["cells"].sum())
-print(f"c3 n={n} trace={trace} kernel {ms:.2f} ms {cells/ms/1e6:.1f} GCUPS bad {int((r['status']!=0).sum())}")
+print(f"{os.environ.get('BA_LIB', '')} c3 n={n} trace={trace} kernel {ms:.2f} ms {cells/ms/1e6:.1f} GCUPS bad {int((r['status']!=0).sum())}")

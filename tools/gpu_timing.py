@@ -17,7 +17,7 @@ H.lib().ba_batch_prof.argtypes = [C.c_void_p, C.c_void_p]
 H.lib().ba_batch_prof(b._h, prof.ctypes.data)
 names = {0: "fast prologue", 1: "fast columns", 2: "fast epilogue", 4: "generic<=128 prologue", 5: "generic<=128 columns", 6: "generic<=128 epilogue",
          8: "tall prologue", 9: "tall columns", 10: "tall epilogue", 12: "driver: rect setup", 13: "driver: place (all)", 14: "driver: post-step", 15: "pair total", 17: "waiting for a free trace slot", 18: "fast step: wait for outstanding memory ops", 32: "setup: direction / pointers", 33: "setup: prefetch consumption", 34: "setup: add_block, rz", 35: "post: border maxima (+ generic border moves)", 36: "post: offset, best cell, checkpoint", 37: "post: x-drop test"}
-tot = float(prof[15]); steps = float(prof[16])
+tot = max(float(prof[15]), 1.0); steps = float(prof[16])
 print(f"pairs={n} trace={trace} kernel_ms={ms:.2f} steps/pair={steps/n:.0f} cycles/pair={tot/n:.0f} (s_memtime ticks)")
 print(f"  prefetch hits per step: {float(prof[19])/max(steps,1):.3f}")
 for k, v in names.items():
@@ -32,3 +32,7 @@ if prof[26]:
 if prof[43]:
     t0, tf, tw = float(prof[43]), float(prof[40]), float(prof[41])
     print(f"wall clock (100 MHz counter): last fill wave done at {(tf-t0)/1e5:.2f} ms, last traceback wave done at {(tw-t0)/1e5:.2f} ms after launch start")
+if prof[55]:
+    w = float(prof[55])
+    print(f"k_multi fill waves={w:.0f}: solo ticks/wave={prof[50]/w:.0f} (episodes {prof[53]/w:.1f}, of which waiting for a trace slot {prof[52]/w:.0f}) step-loop ticks/wave={prof[51]/w:.0f} (steps {prof[54]/w:.0f}, {float(prof[51])/max(float(prof[54]),1):.1f} ticks/step)")
+    print(f"  run() ticks/wave: new pairs {prof[56]/w:.0f}, pairs back from their slots {prof[57]/w:.0f}, pairs taken to their end {prof[58]/w:.0f}")
