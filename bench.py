@@ -114,7 +114,8 @@ def self_check(np, w, res, runs, off, idx):
 
 
 def secondary_line(np, H, W, o, w, cores):
-    """One BASELINE.json side configuration on the same kernels: best of 3 launches, oracle-checked sample."""
+    """One BASELINE.json side configuration on the same kernels: best of 3 launches, EVERY pair compared with the oracle (score, end
+    positions, computed cells, CIGAR runs)."""
     b = W.make_batch(H, w)
     ms = min(b.run() for _ in range(3))
     res = b.results()
@@ -124,26 +125,33 @@ def secondary_line(np, H, W, o, w, cores):
     n = len(w.pairs)
     trace = "trace" in w.mode
     runs, off = b.cigars(res["cigar_len"]) if trace else (None, None)
+    retried = b.retried()
     checked = 0
     if o is not None:
         if w.profiles:
-            checked = min(n, 300)
-            for k in range(checked):
-                ref = o.align_profile(w.pairs.query(k), w.profiles[k], w.size, w.x_drop, w.mode)
-                got = (int(res["score"][k]), int(res["query_idx"][k]), int(res["reference_idx"][k]), int(res["cells"][k]))
-                if got != (ref["score"], ref["query_idx"], ref["reference_idx"], ref["cells"]) or \
-                        (trace and H.runs_to_string(runs[int(off[k]): int(off[k + 1])]) != ref["cigar"]):
-                    raise RuntimeError(f"bench.py: GPU results differ from the oracle on {w.name}; number is invalid")
+            ref = o.batch_align_profile(w.pairs.pool, w.pairs.q_off, w.pairs.q_len, w.profiles, w.size, w.x_drop, w.mode, threads=cores)
+            ok = (np.array_equal(ref["scores"], res["score"]) and np.array_equal(ref["query_idx"], res["query_idx"])
+                  and np.array_equal(ref["reference_idx"], res["reference_idx"]) and np.array_equal(ref["cells"], res["cells"].astype(np.uint64)))
+            if ok and trace:
+                ok = np.array_equal(ref["cig_len"], res["cigar_len"])
+                if ok:
+                    ln = ref["cig_len"].astype(np.int64)
+                    start = np.repeat(ref["cig_off"].astype(np.int64), ln)
+                    within = np.arange(int(ln.sum()), dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+                    ok = np.array_equal(ref["cig_ops"][start + within], runs[: int(off[n])])
+            if not ok:
+                raise RuntimeError(f"bench.py: GPU results differ from the oracle on {w.name}; number is invalid")
+            checked = n
         else:
-            checked = min(n, 4000)
+            checked = n
             oracle_compare(np, o, w, res, runs, off, checked, cores)
             if trace:
-                self_check(np, w, res, runs, off, range(0, checked, 16))
+                self_check(np, w, res, runs, off, range(0, checked, max(1, checked // 256)))
     b.close()
     gc = cells / (ms * 1e-3) / 1e9
     return {"config": w.name, "gcups": round(gc, 1), "valu_frac": round(gc * 1e9 * w.ops_per_cell / 1e12 / VALU_PEAK_INT16_TOPS, 4),
             "ops_per_cell": w.ops_per_cell, "kernel_ms": round(ms, 3), "pairs": n, "m_pairs_per_s": round(n / (ms * 1e-3) / 1e6, 3),
-            "full_matrix_equiv_gcups": round(w.full_matrix_cells() / (ms * 1e-3) / 1e9, 1), "parity_checked_pairs": checked}
+            "full_matrix_equiv_gcups": round(w.full_matrix_cells() / (ms * 1e-3) / 1e9, 1), "parity_checked_pairs": checked, "retried": retried}
 
 
 def main():
@@ -202,6 +210,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     res = batch.results()
+    retried_main = batch.retried()
     if res["status"].any():
         raise RuntimeError(f"rank {rank}: {int((res['status'] != 0).sum())} pairs failed on the device")
     cells_rank = int(res["cells"].sum())
@@ -271,7 +280,7 @@ def main():
                    "sanity_block32_us_per_pair": round(ref32["seconds"] / n32 * 1e6, 1),
                    "sanity_reference_notebook_us_per_pair": 239.7}
             if not a.no_secondary:
-                # (counts large enough that every resident wave sees a few dozen pairs: these launches last 5 - 30 ms)
+                # (counts large enough that every resident wave sees a few dozen pairs: these launches last 5 - 30 ms) ...
                 c2, c4 = W.config2(200000, workers=1), W.config4(400000)
                 secondary = [secondary_line(np, H, W, o, c2, cores)]
                 c2.mode = ("trace", "x_drop"); c2.name += ", traceback"
@@ -280,6 +289,17 @@ def main():
                 c4.mode = ("trace",); c4.name += ", traceback"
                 secondary.append(secondary_line(np, H, W, o, c4, cores))
                 secondary.append(secondary_line(np, H, W, o, W.config5(80000), cores))
+                # ... and the same configurations at the batch sizes of the reference's own harnesses (BASELINE.json: 10 k pairs,
+                # examples/nanopore_bench.rs:73-95; 7 k protein pairs, examples/uc_bench.rs:79-104; 11 k PSSMs, examples/pssm_bench.rs:94-100):
+                # a few pairs per wave, bound by the longest pair's chain of steps rather than by the machine
+                c2s, c4s = W.config2(10000, workers=1), W.config4(7000)
+                secondary.append(secondary_line(np, H, W, o, c2s, cores))
+                c2s.mode = ("trace", "x_drop"); c2s.name += ", traceback"
+                secondary.append(secondary_line(np, H, W, o, c2s, cores))
+                secondary.append(secondary_line(np, H, W, o, c4s, cores))
+                c4s.mode = ("trace",); c4s.name += ", traceback"
+                secondary.append(secondary_line(np, H, W, o, c4s, cores))
+                secondary.append(secondary_line(np, H, W, o, W.config5(11000), cores))
         out = {
             "metric": "GCUPS (DP cells/s) on 10 kbp DNA X-drop batch; bit-exact score+CIGAR vs AVX2",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -294,7 +314,7 @@ def main():
                        "cells_per_step": cells_total},
             "pairs_per_s": round(a.pairs * world * a.steps / elapsed, 1),
             "full_matrix_equiv_gcups": round(full_equiv * world * a.steps / elapsed / 1e9, 1),
-            "computed_cells": cells_rank, "surviving_cells": surviving,
+            "computed_cells": cells_rank, "surviving_cells": surviving, "retried": retried_main,
             "cigar_runs_checked": runs_checked, "cigars_rescored": rescored,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }

@@ -120,9 +120,11 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             if (bidx == 0) { *status |= ST_TRACEBACK_LOST; return 0; }
             bidx--;
             br = blocks[bidx];
-            if (i >= br.i && j >= br.j) break;
+            if (i >= (br.i & 0x7fffffffu) && j >= br.j) break;
         }
         const bool right_blk = br.trace_base >> 31;
+        const bool l2 = br.i >> 31;   // a slot's rectangle (ba_multi.hpp): words of 4 cells x 2 columns (BR_L2)
+        br.i &= 0x7fffffffu;
         if (br.trace_base & 0x40000000u) { *status |= ST_TRACEBACK_LOST; return 0; }   // a speculative grow that was never materialised: must not be on a path
         const uint32_t tbase = br.trace_base & 0x3fffffffu;
         const uint32_t Hv = right_blk ? br.h : br.w;          // cells along the vector axis
@@ -132,8 +134,14 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             const uint32_t v = right_blk ? ci : cj, w = right_blk ? cj : ci;
             const uint32_t chunk = v >> 7, lane = (v & 127) >> 1;
             if (right_blk && fqs && i == 0) { stop = true; break; }                     // scan_block.rs:1597-1599
-            const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
-            const uint32_t nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;   // all four bits are stored as "differs"
+            uint32_t nib;
+            if (l2) {
+                const uint32_t word = trace[tbase + (v >> 3) * 8 + (w >> 1) * 2 + ((v >> 2) & 1)];
+                nib = ((word >> ((v & 3) * 8 + (w & 1) * 4)) ^ 15u) & 15u;
+            } else {
+                const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
+                nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;   // all four bits are stored as "differs"
+            }
             table = tb_resolve(right_blk, table, nib);
             if (local && table == 0) {                                                   // scan_block.rs:1604-1611
                 const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
@@ -172,7 +180,7 @@ struct TbLane {
     uint32_t slot, pair, i, j, table, bidx, run_op, run_len, status;
     uint64_t wp, lo;
     const BlockRec* blocks; const uint32_t* trace; const uint8_t* q; const uint8_t* r;
-    uint32_t bi, bj, tbase, zoff, nch, nl; bool right, in_rect;
+    uint32_t bi, bj, tbase, zoff, nch, nl; bool right, in_rect, l2;
     // look-ahead state: the next rectangle records; what the LDS record of this lane currently holds: a 5-lane x
     // 2-column-group window of trace words (chunk tw_chunk, column groups tw_g and tw_g - 1, lanes from tw_lane0) and
     // 16-byte windows of both sequences ([qw0, qw0 + 16), [rw0, rw0 + 16); 0xffffffff = empty)
@@ -210,9 +218,13 @@ constexpr int TB_CELLS_PER_STEP = 4;
 // DEPTH: rectangle records fetched ahead. A path skips rectangles (a right strip's left neighbour on the path is an earlier right
 // strip, the down strips in between are not on it): with DEPTH > 1 a call walks down the stack past them instead of spending one
 // call -- one memory round trip of its wave -- on each.
-template <int CELLS = TB_CELLS_PER_STEP, int DEPTH = 1>
+// LB: bytes of a lane's LDS record. TB_LANE_BYTES: 10 trace words + the two sequence windows. TB_LANE_BYTES_L2 (k_multi): 16 trace words, so
+// that a window also holds the words of a slot's rectangles (4 cells x 2 columns each: two 8-cell lanes x two column groups = 64 bytes).
+template <int CELLS = TB_CELLS_PER_STEP, int DEPTH = 1, int LB = (int)TB_LANE_BYTES>
 __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned char* lrec,
                                         const unsigned char* lut, unsigned long long* tacc = nullptr) {
+    constexpr bool L2OK = LB == (int)TB_LANE_BYTES_L2;
+    constexpr int SEQ_Q = L2OK ? 64 : 40, SEQ_R = SEQ_Q + 16;   // byte offsets of the sequence windows in the record
     const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
     BA_TSTAMP(ts0);
     bool fresh = true;   // LOCAL_START only: may this call still issue a direct load?
@@ -230,7 +242,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
                     t.nq--;
                 } else rec = *(const uint4*)(t.blocks + t.bidx - 1);
                 t.bidx--;
-                t.bi = rec.x; t.bj = rec.y;
+                t.l2 = L2OK && (rec.x >> 31); t.bi = rec.x & 0x7fffffffu; t.bj = rec.y;
                 const uint32_t h = rec.z & 0xffffu, w = rec.z >> 16;
                 t.in_rect = t.i >= t.bi && t.j >= t.bj;
                 t.zoff = h * w / 8;
@@ -255,6 +267,21 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
         const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
         const uint32_t chunk = v >> 7, lc = (v & 127) >> 1, g = w >> 2;
+        if (L2OK && t.l2) {
+            // a slot's rectangle (128 x 8 cells, one chunk): a lane's 8 cells x 8 columns are 32 contiguous bytes (word lane8 * 8 +
+            // (column >> 1) * 2 + cell quad); the window is the two 8-cell lanes ending at the cell's: 64 contiguous bytes, four
+            // 16-byte loads into one cache line (mostly). tw_lane0: the first lane8.
+            const uint32_t L8 = v >> 3;
+            if (!local && !(t.tw_ok && t.tw_chunk == 0xffffu && L8 - t.tw_lane0 < 2u)) {
+                t.tw_chunk = 0xffffu; t.tw_g = 0; t.tw_lane0 = L8 ? L8 - 1 : 0u; t.tw_ok = true;
+                const uint32_t* wp = t.trace + t.tbase + t.tw_lane0 * 8;
+                uint4 a0, a1, a2, a3;
+                __builtin_memcpy(&a0, wp, 16); __builtin_memcpy(&a1, wp + 4, 16); __builtin_memcpy(&a2, wp + 8, 16); __builtin_memcpy(&a3, wp + 12, 16);
+                uint4* lw = (uint4*)lrec;
+                lw[0] = a0; lw[1] = a1; lw[2] = a2; lw[3] = a3;
+                fresh = false;
+            }
+        } else
         if (!local && !(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u)) {
             // the two column groups ending at the cell's and the five lanes ending at the cell's
             // (five consecutive words per group: one 16-byte and one 4-byte load each -- the walks of a wave are in 64 different
@@ -281,7 +308,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
 #pragma unroll
                 for (int k = 0; k < 4; k++) b4[k] = p[k];
 #pragma unroll
-                for (int k = 0; k < 4; k++) ((uint32_t*)lrec)[10 + k] = b4[k];
+                for (int k = 0; k < 4; k++) ((uint32_t*)lrec)[SEQ_Q / 4 + k] = b4[k];
             }
             if (t.rw0 == 0xffffffffu || t.j < t.rw0 + 8 || t.j >= t.rw0 + 16) {
                 t.rw0 = t.j >= 12 ? (t.j - 12) & ~3u : 0;
@@ -290,7 +317,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
 #pragma unroll
                 for (int k = 0; k < 4; k++) b4[k] = p[k];
 #pragma unroll
-                for (int k = 0; k < 4; k++) ((uint32_t*)lrec)[14 + k] = b4[k];
+                for (int k = 0; k < 4; k++) ((uint32_t*)lrec)[SEQ_R / 4 + k] = b4[k];
             }
         }
     }
@@ -316,11 +343,20 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
                 if (stop) t.i = t.j = 0;
                 alive = alive && !stop;
             }
-            const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
-            alive = alive && (v >> 7) == t.tw_chunk && gi <= 1u && k <= 4u;                 // else: left the window, the next call reloads it
+            const uint32_t gi = t.tw_g - (w >> 2);
+            uint32_t baddr;
+            if (L2OK && t.l2) {
+                const uint32_t k8 = (v >> 3) - t.tw_lane0;
+                alive = alive && t.tw_chunk == 0xffffu && k8 <= 1u;
+                baddr = k8 * 32 + (w >> 1) * 8 + ((v >> 2) & 1) * 4 + (v & 3);
+            } else {
+                const uint32_t k = lc - t.tw_lane0;
+                alive = alive && (v >> 7) == t.tw_chunk && gi <= 1u && k <= 4u;             // else: left the window, the next call reloads it
+                baddr = gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1);
+            }
             const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
-            const uint32_t byte = lrec[alive ? gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1) : 0u];
-            const uint32_t qb = lrec[40 + (qo & 15u)], rb = lrec[56 + (ro & 15u)];          // for a match at this cell (read alongside, used if needed)
+            const uint32_t byte = lrec[alive ? baddr : 0u];
+            const uint32_t qb = lrec[SEQ_Q + (qo & 15u)], rb = lrec[SEQ_R + (ro & 15u)];    // for a match at this cell (read alongside, used if needed)
             const uint32_t nib = ((byte >> ((w & 1) * 4)) ^ 15u) & 15u;                      // all four bits stored as "differs"
             const uint32_t table = tb_resolve(t.right, t.table, nib);
             const uint32_t m = lut[((uint32_t)t.right << 6) | (table << 4) | nib];          // op | di << 3 | dj << 4 | next << 5
@@ -371,7 +407,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         if (eq && op == 1) {
             const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
             if (qo > 15u || ro > 15u) break;                                            // next call refills the windows
-            op = lrec[40 + qo] == lrec[56 + ro] ? 2 : 3;
+            op = lrec[SEQ_Q + qo] == lrec[SEQ_R + ro] ? 2 : 3;
         }
         if (di > t.i || dj > t.j) { tb_fail(t); return; }   // would leave the matrix: corrupt trace
         t.i -= di; t.j -= dj; t.table = tb_next(t.right, m >> 5, v);
@@ -385,6 +421,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
 // dependent iterations whose length grows with the number of lanes walking in lockstep, so the last `tb_reserve`
 // hand-offs are left to these late helpers, one lane per wave on a SIMD that has nothing else left to do (the
 // dedicated waves stop claiming tickets once the ticket counter reaches that reserve).
+template <int LB = (int)TB_LANE_BYTES>
 __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds, uint32_t nlanes, bool dedicated) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
     int phase = (uint32_t)lane_id() < nlanes ? IDLE : RETIRED;
@@ -395,7 +432,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
     uint32_t* head = bp.tb_ctrl + 32;
     // this lane's LDS record and the move table (scan_block.rs:1532-1558), two entries built per lane
     unsigned char* lut = tb_lds;
-    unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * TB_LANE_BYTES;
+    unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * (uint32_t)LB;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const uint32_t idx = (uint32_t)lane_id() + 64u * e;
@@ -456,10 +493,10 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
         if (walking) {
 #ifdef BA_TIMING
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-            if (t.i > 0 || t.j > 0) tb_step(t, eq, bp.cig_ops, lrec, lut, c_sec);
+            if (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut, c_sec);
             c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
 #else
-            if (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH>(t, eq, bp.cig_ops, lrec, lut);
+            if (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
 #endif
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);

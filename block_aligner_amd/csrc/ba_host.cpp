@@ -79,6 +79,23 @@ constexpr int BA_PCLASS_BIG = 5;
 static inline int special_of(uint32_t mode) { return (mode & (BA_LOCAL_START | BA_FREE_QUERY_START_GAPS | BA_FREE_QUERY_END_GAPS)) ? 1 : 0; }
 constexpr int BA_KIND_PROFILE_ = ba::KIND_PROFILE;   // batches whose "reference" is an AAProfile (sequence bytes: AA alphabet)
 
+// ------------------------------------------------------------------ development switches
+// The release library reads NO environment variables: its results and its launch geometry depend on the call's arguments only.
+// Built with -DBA_DEV (lib/libblock_aligner_hip_dev.so: the tests that force a code path on small inputs, the measurement
+// scripts under tools/) the switches below exist; they are listed in README.md.
+#ifdef BA_DEV
+#define dev_env(name) getenv(name)
+#else
+#define dev_env(name) ((const char*)nullptr)
+#endif
+extern "C" int ba_dev_build(void) {
+#ifdef BA_DEV
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 static int fail(const char* fmt, ...) {
@@ -217,6 +234,7 @@ struct BaBatch {
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
     bool ran = false, in_flight = false;
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
+    uint32_t mq_drain = 0;      // k_multi: pairs at the end of the batch that are run one at a time (BatchParams::mq_drain)
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
@@ -235,10 +253,10 @@ struct BaBatch {
         bp.q_off = q_off.as<uint64_t>(); bp.q_len = q_len.as<uint32_t>();
         bp.r_off = r_off.as<uint64_t>(); bp.r_len = r_len.as<uint32_t>();
         bp.n = n; bp.gap_open = gap_open; bp.gap_extend = gap_extend;
-        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (getenv("BA_NO_FAST") ? 0x100u : 0u) | (getenv("BA_SKIP_WALK") ? 0x200u : 0u) | ((handle_mode || getenv("BA_NO_SPEC")) ? 0x400u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
+        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (dev_env("BA_NO_FAST") ? 0x100u : 0u) | (dev_env("BA_SKIP_WALK") ? 0x200u : 0u) | ((handle_mode || dev_env("BA_NO_SPEC")) ? 0x400u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
-        bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !getenv("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
+        bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !dev_env("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
         bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
         bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>(); bp.trace_words_out = trace_words.as<uint32_t>();
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
@@ -251,6 +269,7 @@ struct BaBatch {
         bp.slot_free = slot_free.as<uint32_t>(); bp.slot_info = slot_info.as<ba::SlotInfo>();
         bp.work_counter = counter.as<uint32_t>();
         bp.work_chunk = work_chunk;
+        bp.mq_drain = mq_drain;
         bp.prof = prof.as<unsigned long long>();
         return bp;
     }
@@ -381,7 +400,7 @@ static int pack_pairs_in_order(int kind, Gaps gaps, size_t min_size, size_t max_
     P.total = total; P.maxlen2 = maxlen2; P.cig_total = cig_total; P.pad = (uint32_t)pad;
     // One dense host buffer (the pooled batch calls): ship it as it is, pad and convert on the device. Scattered or
     // overlapping sources (PaddedBytes handles, a reference shared by many pairs) and profile batches are packed here.
-    if (!profile && !already_converted && n >= 256 && n < (1u << 30) && (uint64_t)(hi - lo) <= 2 * sum_len + 4096 && !getenv("BA_HOST_PACK")) {
+    if (!profile && !already_converted && n >= 256 && n < (1u << 30) && (uint64_t)(hi - lo) <= 2 * sum_len + 4096 && !dev_env("BA_HOST_PACK")) {
         P.on_device = true; P.raw = lo; P.raw_bytes = (uint64_t)(hi - lo);
         P.raw_qo.resize(n); P.raw_ro.resize(n);
         for (size_t p = 0; p < n; p++) {
@@ -442,7 +461,7 @@ static int pack_pairs(int kind, Gaps gaps, size_t min_size, size_t max_size, uin
     std::stable_sort(P.order.begin(), P.order.end(), [&](uint32_t a, uint32_t c) { return cost[a] > cost[c]; });
     bool identity = true;
     for (size_t p = 0; p < n && identity; p++) identity = P.order[p] == p;
-    if (identity || getenv("BA_CALLER_ORDER")) P.order.clear();
+    if (identity || dev_env("BA_CALLER_ORDER")) P.order.clear();
     lap("longest-first order");
     const std::vector<uint32_t>& order = P.order;
     if (order.empty()) return pack_pairs_in_order(kind, gaps, min_size, max_size, mode, n, already_converted, get, getp, P, lap);
@@ -475,7 +494,7 @@ static int pipe_cut(BaBatch* b, const uint32_t* ql, const uint32_t* rl, size_t n
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     uint64_t forced = 0;   // (development / test switch, as for the ring slots)
-    if (const char* env = getenv("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) forced = (uint64_t)v; }
+    if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) forced = (uint64_t)v; }
     for (uint64_t pct : {175ull, 140ull, 110ull}) {
         if (forced) pct = forced;
         pipe_regions(b, ql, rl, n, pct, toff, boff);
@@ -494,7 +513,8 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
     if (pc == BA_PCLASS_BIG && special_of(mode)) return fail("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
-    b->lds = (b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc))) + (trace ? ba::TB_LDS_BYTES : 0u);
+    // (k_multi's traceback waves keep their records in their own wave's region: no extra space)
+    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
@@ -505,7 +525,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
     if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
-    if (const char* env = getenv("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
+    if (const char* env = dev_env("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
     uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
     const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
     if (grid > need) grid = need;
@@ -519,10 +539,10 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // size, one full grow sequence to the maximum, a few steps there -- times a margin; the few pairs that outgrow
     // their slot report BA_ST_TRACE_OVERFLOW on the device and are re-run with full-size slots by batch_wait.
     b->adaptive = false;
-    if (trace && !full_trace && !getenv("BA_FULL_TRACE_SLOTS") && (n >= 4096 || getenv("BA_ADAPTIVE_TRACE"))) {
+    if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || dev_env("BA_ADAPTIVE_TRACE"))) {
         const uint64_t est = (maxlen2 * b->min_size / 8 + (uint64_t)max_size * max_size / 8 + 16ull * max_size) * zm;
         uint64_t pct = 175;   // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT)
-        if (const char* env = getenv("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
+        if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
         const uint64_t want = est * pct / 100 + 4096;
         if (want < b->trace_full) { b->trace_stride = want; b->adaptive = true; }
     }
@@ -544,7 +564,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     b->cq_grid = 0;
     if (b->quad) {   // the per-pair kernel beside k_quad: one workgroup per CU, so that k_quad always finds room next to it
         b->cq_grid = (uint32_t)std::min<uint64_t>(grid, (uint64_t)prop.multiProcessorCount);
-        if (const char* env = getenv("BA_CQ_GRID")) { int v = atoi(env); if (v > 0) b->cq_grid = (uint32_t)std::min<uint64_t>(grid, (uint64_t)v); }
+        if (const char* env = dev_env("BA_CQ_GRID")) { int v = atoi(env); if (v > 0) b->cq_grid = (uint32_t)std::min<uint64_t>(grid, (uint64_t)v); }
     }
     // TRACE batches big enough to keep them busy get dedicated traceback waves (ba_driver.hpp traceback_consumer)
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
@@ -552,13 +572,13 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
     // Short pairs: a walk is a few hundred dependent steps, cheaper done at once by the fill wave's lane 0 than handed to a
     // traceback lane (protein pairs of ~300 residues, block 32..256: 202 vs 99 GCUPS; 1 kbp DNA pairs already prefer the hand-off).
-    const bool short_pairs = kind != BA_KIND_PROFILE_ && avg_len2 <= 1024 && !getenv("BA_FORCE_TB");
+    const bool short_pairs = kind != BA_KIND_PROFILE_ && avg_len2 <= 1024 && !dev_env("BA_FORCE_TB");
     {   // several short pairs per work-counter atomic; long pairs one by one (a chunk of long pairs would lengthen the launch's ragged end)
         const uint64_t waves = grid * ba::WAVES_PER_WG;
         const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
         b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
     }
-    if (trace && (b->grid >= 32 || (getenv("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !b->pipe && !getenv("BA_INLINE_TRACEBACK")) {
+    if (trace && (b->grid >= 32 || (dev_env("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !b->pipe && !dev_env("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
         // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
@@ -566,7 +586,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // (the traceback work per filled cell grows as the block shrinks: with blocks below 128 cells one wave per 3
         // workgroups -- 1 kbp DNA, block 32..256: 360 GCUPS against 285 at one per 4)
         uint32_t stride = b->grid >= 32 ? (b->min_size >= 128 ? 4 : 3) : 2;
-        if (const char* env = getenv("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
+        if (const char* env = dev_env("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
         size_t free_b = 0, total_b = 0;
@@ -575,7 +595,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
         if (b->multi) spw = 10;   // four pairs being filled + pending walks
-        if (const char* env = getenv("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
+        if (const char* env = dev_env("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         if (b->multi && spw < 6) return fail("device memory: the multi-pair kernel needs six trace slots per wave");   // (batch_build falls back to the per-pair kernel)
         b->slots_per_wave = spw;
@@ -588,8 +608,10 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
         // less of the batch to walkers that only exist once the first wave has run out of pairs
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
-        if (const char* env = getenv("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
+        if (const char* env = dev_env("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
     }
+    b->mq_drain = b->multi ? b->n_fill_waves : 0;
+    if (const char* env = dev_env("BA_MQ_DRAIN")) b->mq_drain = (uint32_t)std::max(0, atoi(env));
     if (b->multi && b->slots_per_wave < 4) b->slots_per_wave = 4;   // (without the hand-off ring: one trace slot per slot of the wave)
     b->slots = b->n_fill_waves * b->slots_per_wave;
     if (b->pipe) b->slots = (uint32_t)n;   // (slot = pair: slot_info holds one entry per pair for k_walk)
@@ -642,7 +664,7 @@ template <class GetSeq, class GetProfile = NoProfiles>
 static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange size, int32_t x_drop, uint32_t mode, size_t n,
                             bool already_converted, GetSeq get, GetProfile getp = GetProfile()) {
     if (ensure_device()) return nullptr;
-    const bool verbose = getenv("BA_SETUP_TIMING") != nullptr;   // development: where the batch set-up time goes
+    const bool verbose = dev_env("BA_SETUP_TIMING") != nullptr;   // development: where the batch set-up time goes
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!verbose) return;
@@ -690,23 +712,23 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // from the sizes where it wins (measured, GCUPS with / without: protein pairs 32k 371 / 405, 64k 745 / 527, 400k 1375 / 597;
     // PSSM 8k 108 / 105, 20k 211 / 162, 80k 458 / 172; 1 kbp DNA 200k 1347 / 606). BA_FORCE_QUAD / BA_NO_QUAD override.
     const size_t quad_from = kind == BA_KIND_AA ? 65536u : (profile ? 8192u : 2048u);
-    b->quad = !special_of(mode) && pc != BA_PCLASS_BIG && min_size == 32 && !getenv("BA_NO_QUAD") && (getenv("BA_FORCE_QUAD") || n >= quad_from);
+    b->quad = !special_of(mode) && pc != BA_PCLASS_BIG && min_size == 32 && !dev_env("BA_NO_QUAD") && (dev_env("BA_FORCE_QUAD") || n >= quad_from);
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
     // blocks take it in place of the hand-off ring (50..500 positions, 20k pairs: 143 -> 158 GCUPS, 80k: 172 -> 225). Short
     // sequence pairs do not: their walks are few hundred steps, cheapest done at once by the fill wave's lane 0 (protein pairs,
     // 8k..65k pairs: 3 .. 20 % slower with k_walk, whose latest wave ends one longest-path walk after the fill).
     std::vector<uint64_t> toff, boff;
-    if (trace && !special_of(mode) && pc != BA_PCLASS_BIG && (b->quad || (profile && n >= 4096) || getenv("BA_FORCE_PIPE"))) {
+    if (trace && !special_of(mode) && pc != BA_PCLASS_BIG && (b->quad || (profile && n >= 4096) || dev_env("BA_FORCE_PIPE"))) {
         const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * (64 + sizeof(ba::PairCont) + 40);
-        if (!getenv("BA_NO_PIPE") && !pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) {
+        if (!dev_env("BA_NO_PIPE") && !pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) {
             b->pipe = true; b->pipe_words = toff[n] + toff[n] / 8; b->pipe_recs = boff[n] + boff[n] / 8;   // (headroom for ba_batch_reload)
         }
     }
     if (trace && !b->pipe) b->quad = false;   // with TRACE the pipeline needs every pair's trace stack resident until the end
     // Batches that start at 128 cells (the reference's nanopore set-up, examples/nanopore_bench.rs: 1 % .. 10 % of 10 kbp): four pairs
     // per wave while a pair's block is 128 cells (ba_multi.hpp), from the sizes at which every wave still finds four pairs.
-    b->multi = !profile && !special_of(mode) && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !getenv("BA_NO_MULTI") && (getenv("BA_FORCE_MULTI") || n >= 16384);
+    b->multi = !profile && !special_of(mode) && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || n >= 16384);
     if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
     if (!b->multi)
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
@@ -793,7 +815,7 @@ static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) return 1;
     uint32_t per_cu = 8;
-    if (const char* env = getenv("BA_WALK_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = (uint32_t)v; }
+    if (const char* env = dev_env("BA_WALK_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = (uint32_t)v; }
     return std::min((b->n + 255u) / 256u, (uint32_t)prop.multiProcessorCount * per_cu);
 }
 static int batch_launch(BaBatch* b) {
@@ -837,7 +859,7 @@ static int batch_launch(BaBatch* b) {
         // chain (protein pairs, 400k: 905 -> 1350 GCUPS; PSSM 80k: 349 -> 432); with X-drop every pair leaves and the per-pair
         // kernel has a full machine's worth of work after k_quad anyway (1 kbp DNA: 1320 -> 1226 with the side launch).
         // (launched after k_quad: a kernel that only waits must never be the one that holds the device)
-        const bool beside = (!xd || getenv("BA_CQ_BESIDE")) && !getenv("BA_CQ_AFTER");
+        const bool beside = (!xd || dev_env("BA_CQ_BESIDE")) && !dev_env("BA_CQ_AFTER");
         if (beside) {
             BatchParams pa = pc; pa.ckpt_wave0 = b->grid * ba::WAVES_PER_WG; pa.cq_side = 1;
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
@@ -1627,7 +1649,7 @@ static size_t block_trace_blocks_impl(BlockImpl* b, Rectangle* out, size_t capac
     std::vector<BlockRec> recs(nb);
     if (nb && hipMemcpy(recs.data(), d->blocks.as<BlockRec>() + (size_t)slot * d->blocks_stride, (size_t)nb * sizeof(BlockRec), hipMemcpyDeviceToHost) != hipSuccess)
         die("hipMemcpy of the rectangle list failed");
-    for (size_t k = 0; k < nb && k < capacity; k++) out[k] = Rectangle{recs[k].i, recs[k].j, recs[k].w, recs[k].h};
+    for (size_t k = 0; k < nb && k < capacity; k++) out[k] = Rectangle{recs[k].i & 0x7fffffffu, recs[k].j, recs[k].w, recs[k].h};   // (bit 31 of i: trace word layout)
     return nb;
 }
 

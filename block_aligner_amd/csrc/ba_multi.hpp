@@ -45,7 +45,7 @@ struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
 
 // One 8-column shift step for the four slots of a wave, 8 cells per lane (scan_block.rs:147-246 with place_block 1083-1228 and
 // the border moves 1003-1061 folded in). (Ad, Ac): the border pair along the step's vector axis, (Pd, Pr) the orthogonal pair.
-// tout: this lane's four words of the step's first column group.
+// tout: this lane's eight trace words of the step.
 template <int KIND, bool TRACE>
 __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& fc, const MultiConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
                                            int (&Pd)[4], int (&Pr)[4], uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add,
@@ -63,7 +63,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
         const uint32_t w = k < 2 ? vb.x : vb.y;
         key[k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
     }
-    int dmax[4] = {0, 0, 0, 0}, tacc[4] = {0, 0, 0, 0};
+    int dmax[4] = {0, 0, 0, 0}, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int nvD[4] = {0, 0, 0, 0}, nvR[4] = {0, 0, 0, 0};   // the last cells of the 8 new columns: the orthogonal border's new entries (row lane 15)
     int holdD = 0, holdR = 0;
 #pragma unroll
@@ -95,31 +95,43 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
         const int pm = wave_prefix_max16((int)as_s(r[3]).y - mc.laneKG);
         const int cs = splat_lo(add_row_shr1(pm, mc.lanem1KG));             // R of the lane above's last cell (no clamp: see fast_rect)
         int dn[4];
+        uint32_t sC[4], sR[4], sCo[4], sRo[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), mc.vtop[k]);
             dn[k] = vmax(d11[k], r[k]);
-            if (TRACE) {   // the cell's four flags as sign bits of saturating differences, one nibble per column (see fast_rect)
-                const uint32_t sC = (uint32_t)subs(cn[k], dn[k]), sR = (uint32_t)subs(r[k], dn[k]), sCo = (uint32_t)subs(copen[k], cn[k]), sRo = (uint32_t)subs(x[k], r[k]);
-                const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);
-                const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);
-                tacc[k] = (int)(((uint32_t)tacc[k] >> 4) | (nib & 0xF000F000u));
+            if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect); packed below, two registers at a time
+                sC[k] = (uint32_t)subs(cn[k], dn[k]); sR[k] = (uint32_t)subs(r[k], dn[k]); sCo[k] = (uint32_t)subs(copen[k], cn[k]); sRo[k] = (uint32_t)subs(x[k], r[k]);
             }
             dmax[k] = vmax(dmax[k], dn[k]);
             d[k] = dn[k]; c[k] = cn[k];
         }
-        if (TRACE && (j & 3) == 3) {
-#ifndef MQ_X_NOTRSTORE
-            if (store) *(int4*)(tout + (j >> 2) * 64) = int4{tacc[0], tacc[1], tacc[2], tacc[3]};
-#else
-            asm volatile("" :: "v"(tacc[0]), "v"(tacc[1]), "v"(tacc[2]), "v"(tacc[3]));
-#endif
+        if (TRACE) {
+            // Trace words of a slot's rectangle: 4 consecutive cells (the two registers of a pair) x 2 columns, a byte per cell, the even
+            // column in its low nibble; a lane's eight words -- its 8 cells x the step's 8 columns -- are contiguous in memory (word
+            // lane * 8 + (column >> 1) * 2 + register pair), so that the traceback finds everything around a path cell in one cache line.
+            // The sign bytes of two registers' differences are gathered by one v_perm each, so that the three bit-field inserts that build a
+            // nibble {nRo, nCo, nR, nC} (see fast_rect) serve four cells instead of two.
 #pragma unroll
-            for (int k = 0; k < 4; k++) tacc[k] = 0;
+            for (int p2 = 0; p2 < 2; p2++) {
+                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[2 * p2 + 1], (int)sC[2 * p2], 0x07050301), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[2 * p2 + 1], (int)sR[2 * p2], 0x07050301);
+                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[2 * p2 + 1], (int)sCo[2 * p2], 0x07050301), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[2 * p2 + 1], (int)sRo[2 * p2], 0x07050301);
+                const uint32_t hi2 = bfi(0x80808080u, pRo, pCo >> 1), lo2 = bfi(0x80808080u, pR, pC >> 1);
+                const uint32_t nib = bfi(0xC0C0C0C0u, hi2, lo2 >> 2);   // bits 7..4 of every byte
+                if (j & 1) tacc[2 * (j >> 1) + p2] = (int)bfi(0xF0F0F0F0u, nib, (uint32_t)tacc[2 * (j >> 1) + p2]);
+                else tacc[2 * (j >> 1) + p2] = (int)(nib >> 4);
+            }
         }
         // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
         if (j & 1) { nvD[j >> 1] = __builtin_amdgcn_perm(dn[3], holdD, 0x07060302); nvR[j >> 1] = __builtin_amdgcn_perm(r[3], holdR, 0x07060302); }
         else { holdD = dn[3]; holdR = r[3]; }
+    }
+    if (TRACE) {
+#ifndef MQ_X_NOTRSTORE
+        if (store) { *(int4*)tout = int4{tacc[0], tacc[1], tacc[2], tacc[3]}; *(int4*)(tout + 4) = int4{tacc[4], tacc[5], tacc[6], tacc[7]}; }
+#else
+        asm volatile("" :: "v"(tacc[0]), "v"(tacc[1]), "v"(tacc[2]), "v"(tacc[3]), "v"(tacc[4]), "v"(tacc[5]), "v"(tacc[6]), "v"(tacc[7]));
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // shift_and_offset (scan_block.rs:1040-1061): 8 entries = one lane
@@ -187,7 +199,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     unsigned long long t_solo = 0, t_quad = 0, t_wait = 0, n_solo = 0, n_quad = 0;
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
-        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * mq_wave_bytes_h(LCLS), 64u, true);
+        traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 64u, true);   // (records in this wave's own region)
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -205,7 +217,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                                 const uint32_t cb = (TRACE && st > 0) ? (b + st - 1) / st + (b % st == 0 ? 1u : 0u) : 0u; return b * WAVES_PER_WG + w - cb; };
     uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
     uint32_t w_next = 0, w_end = 0;
-    bool more = true;
+    bool more = true, drain = false;
 
     for (;;) {
         // ================= solo mode: one pair at a time on all 64 lanes, the slots' state in memory. Whose turn? a slot whose step
@@ -215,7 +227,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             int solo = -1; bool fresh = false, to_end = false;
             uint32_t new_pair = 0;
             if (pend_m) solo = __builtin_ctz(pend_m);
-            else if (live_m != 15u && more) {
+            else if (more && (drain ? live_m == 0u : live_m != 15u)) {
                 if (w_next == w_end) {
                     uint32_t v = 0;
                     if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
@@ -224,6 +236,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     w_end = min(w_next + bp.work_chunk, bp.n);
                 }
                 new_pair = w_next++; solo = __builtin_ctz(~live_m & 15u); fresh = true;
+                to_end = drain;                                      // (the batch is running out: this pair is not for a slot)
+                if (new_pair + bp.mq_drain >= bp.n) drain = true;    // from the next pair on
             } else if (live_m && live_m != 15u) { solo = __builtin_ctz(live_m); to_end = true; }
             else break;
 
@@ -329,11 +343,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             // (the compiler would otherwise spill and reload these values inside the driver's inner loops).
             int keepv = 0;
             park<0>(keepv, (int)live_m); park<1>(keepv, (int)pend_m); park<2>(keepv, (int)w_next); park<3>(keepv, (int)w_end);
-            park<4>(keepv, (more ? 1 : 0) | (fresh ? 2 : 0) | (to_end ? 4 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair); park<7>(keepv, (int)s_slot);
+            park<4>(keepv, (more ? 1 : 0) | (fresh ? 2 : 0) | (to_end ? 4 : 0) | (drain ? 8 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair); park<7>(keepv, (int)s_slot);
             BA_TSTAMP(tr_a);
             st = al.run(s_pair, s_slot, batch_traceback, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh && !to_end);
             live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
-            { const int fl = unpark<4>(keepv); more = fl & 1; fresh = fl & 2; to_end = fl & 4; }
+            { const int fl = unpark<4>(keepv); more = fl & 1; fresh = fl & 2; to_end = fl & 4; drain = fl & 8; }
             solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv); s_slot = (uint32_t)unpark<7>(keepv);
             char* const smem_s2 = (char*)coldp_big() + (uint64_t)fill_wave_of() * MQ_WAVE_BYTES + (uint32_t)solo * MQ_SLOT_BYTES;
             char* const rec2 = smem_s2 + 2 * MQ_BUF_BYTES;
@@ -495,10 +509,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 }
                 uint32_t* tw = nullptr;
                 if (TRACE) {
-                    tw = bp.trace_arena + (uint64_t)tslot * bp.trace_stride + trace_top + 4 * l;
+                    tw = bp.trace_arena + (uint64_t)tslot * bp.trace_stride + trace_top + 8 * l;
                     if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
                         BlockRec br;
-                        br.i = right ? ri : rj; br.j = right ? rj : ri; br.h = (uint16_t)(right ? MQ_B : STEP); br.w = (uint16_t)(right ? STEP : MQ_B);
+                        br.i = (right ? ri : rj) | 0x80000000u;   // (bit 31: words of 4 cells x 2 columns, see multi_rect)
+                        br.j = right ? rj : ri; br.h = (uint16_t)(right ? MQ_B : STEP); br.w = (uint16_t)(right ? STEP : MQ_B);
                         br.trace_base = trace_top | (right ? 0x80000000u : 0u);
                         bp.blocks[(uint64_t)tslot * bp.blocks_stride + nblocks] = br;
                     }
@@ -579,9 +594,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     if (batch_traceback) {
         lds_sync();
 #ifndef MQ_HELPER_LANES
-#define MQ_HELPER_LANES 1u
+#define MQ_HELPER_LANES 4u   // (the batch's last walks: 1 -> 4 lanes per emptied fill wave +1.5 % at config 3)
 #endif
-        traceback_consumer(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, MQ_HELPER_LANES, false);
+        traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, MQ_HELPER_LANES, false);
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

@@ -99,6 +99,8 @@ struct BatchParams {
     uint32_t cq_side;            // 1: this per-pair launch runs beside k_quad (it may stop waiting; the launch after k_quad drains the queue)
     uint32_t inline_len2;        // pair-slot batches, per-pair kernel: pairs with |q| + |r| >= this walk their paths at once (lane 0), shorter ones leave them to k_walk
     uint32_t ckpt_wave0;         // this launch's first wave in the checkpoint arena (two per-pair kernels of one batch run side by side)
+    uint32_t mq_drain;           // k_multi: the last mq_drain pairs of the batch are not taken into slots (four pairs per wave, each four times as long in
+                                 // flight) but one at a time by waves whose slots have emptied, and run on all lanes to their end: a finer ragged end
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;
@@ -127,8 +129,9 @@ BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_by
 BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * mq_wave_bytes_h(max_size); }
 // TRACE batches: one more region behind the waves' for the workgroup's traceback wave (ba_driver.hpp tb_step): per lane
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
-constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;   // table first, then the records (a helper fill wave uses one)
-static_assert(MQ_LDS_BYTES <= 8512u, "k_multi LDS");
+constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;
+constexpr uint32_t TB_LANE_BYTES_L2 = 100;   // k_multi's traceback waves (16 trace words per window): their records sit in the wave's own LDS region   // table first, then the records (a helper fill wave uses one)
+static_assert(MQ_LDS_BYTES <= 8512u && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= 8512u, "k_multi LDS");
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES <= lds_wave_bytes_h(128), "traceback LDS regions");
 
 }  // namespace ba

@@ -49,12 +49,25 @@ class AlignResult:
     reference_idx: int
 
 
+# The same kernels behind a host side that reads the BA_* development switches (environment variables): for the tests that force
+# a code path on small inputs and for the measurement scripts under tools/. The release library reads no environment variables.
+DEV_LIB_PATH = os.path.join(_HERE, "lib", "libblock_aligner_hip_dev.so")
 _lib = None
+_loaded = {}
+
+
+def use_library(path: str) -> None:
+    """Route every later call through another build of the library (objects must not outlive the switch)."""
+    global LIB_PATH, _lib
+    LIB_PATH = path
+    _lib = _loaded.get(path)
 
 
 def lib() -> C.CDLL:
     """Load the HIP library; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
+    if _lib is None and LIB_PATH in _loaded:
+        _lib = _loaded[LIB_PATH]
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
@@ -121,6 +134,7 @@ def lib() -> C.CDLL:
         L.ba_multibatch_destroy.argtypes = [vp]
         L.ba_shard_slices.argtypes = [vp, vp, sz, C.c_int, vp]
         _lib = L
+        _loaded[LIB_PATH] = L
     return _lib
 
 

@@ -272,4 +272,72 @@ int ba_oracle_batch_align(int kind, const int8_t* matrix, const uint8_t* pool,
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+
+// Batch of seq-profile alignments (Block::align_profile, scan_block.rs:942-968), threaded like ba_oracle_batch_align: bench.py's
+// check of every pair of the PSSM configuration. Profile p occupies rows [p_off[p], p_off[p] + p_len[p] + 1) of pos_aa_all
+// ((len + 1) x 32 i8 rows, row 0 = the padding column) and of the three gap arrays. cells_pp: computed cells per pair (optional).
+int ba_oracle_batch_align_profile(const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, size_t n,
+                                  const int8_t* pos_aa_all, const int8_t* goC_all, const int8_t* gcC_all, const int8_t* goR_all,
+                                  const uint64_t* p_off, const uint32_t* p_len, int8_t gap_extend,
+                                  size_t min_size, size_t max_size, int32_t x_drop, uint32_t flags, int n_threads,
+                                  int32_t* scores, uint32_t* qidx, uint32_t* ridx, uint32_t* cig_ops, const uint64_t* cig_off, uint32_t* cig_len,
+                                  uint64_t* cells_pp, double* seconds_out) {
+    try {
+        const size_t pad = max_size < (size_t)L ? (size_t)L : max_size;
+        size_t max_q = 0, max_r = 0;
+        for (size_t p = 0; p < n; p++) { if (q_len[p] > max_q) max_q = q_len[p]; if (p_len[p] > max_r) max_r = p_len[p]; }
+        if (n_threads < 1) n_threads = 1;
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        std::string err;
+        auto worker = [&](int) {
+            try {
+                Block blk(mode_of(flags), max_q, max_r, pad);
+                Cigar cg((flags & F_TRACE) ? max_q : 0, (flags & F_TRACE) ? max_r : 0);
+                for (;;) {
+                    const size_t base = next.fetch_add(16);
+                    if (base >= n) break;
+                    for (size_t p = base; p < n && p < base + 16; p++) {
+                        PaddedBytes pq = PaddedBytes::from_bytes<AAMatrix>(pool + q_off[p], q_len[p], pad);
+                        const size_t plen = p_len[p];
+                        AAProfile pr(plen, pad, gap_extend);
+                        for (size_t i = 0; i <= plen; i++) {
+                            const size_t row = p_off[p] + i;
+                            for (int b = 0; b < 32; b++) {
+                                pr.pos_aa[i * 32 + b] = pos_aa_all[row * 32 + b];
+                                pr.aa_pos[(size_t)b * pr.curr_len + i] = pos_aa_all[row * 32 + b];
+                            }
+                            pr.pos_gap_open_C[i] = goC_all[row]; pr.pos_gap_close_C[i] = gcC_all[row]; pr.pos_gap_open_R[i] = goR_all[row];
+                        }
+                        blk.align_profile(pq, pr, min_size, max_size, x_drop);
+                        if (scores) scores[p] = blk.res.score;
+                        if (qidx) qidx[p] = (uint32_t)blk.res.query_idx;
+                        if (ridx) ridx[p] = (uint32_t)blk.res.reference_idx;
+                        if (cells_pp) cells_pp[p] = blk.cells_computed;
+                        if ((flags & F_TRACE) && cig_len) {
+                            blk.trace().cigar(blk.res.query_idx, blk.res.reference_idx, cg);
+                            const size_t k = cg.len();
+                            cig_len[p] = (uint32_t)k;
+                            if (cig_ops) for (size_t e = 0; e < k; e++) { OpLen o = cg.get(e); cig_ops[cig_off[p] + e] = (uint32_t)((o.len << 4) | o.op); }
+                        }
+                    }
+                }
+            } catch (const std::exception& e) {
+                if (!failed.exchange(true)) err = e.what();
+            }
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        if (n_threads == 1) worker(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t);
+            for (auto& x : th) x.join();
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        if (failed) { g_err = err; return 1; }
+        if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 }  // extern "C"

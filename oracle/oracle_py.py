@@ -55,6 +55,9 @@ class Oracle:
                                               C.c_int8, C.c_int8, C.c_size_t, C.c_size_t, C.c_int32, C.c_uint32, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        lib.ba_oracle_batch_align_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_int8, C.c_size_t, C.c_size_t, C.c_int32, C.c_uint32, C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         self.backend = lib.ba_oracle_backend().decode()
 
     def _err(self):
@@ -156,6 +159,41 @@ class Oracle:
             raise self._err()
         return dict(scores=scores, query_idx=qi, reference_idx=ri, cig_ops=cig_ops, cig_off=cig_off, cig_len=cig_len,
                     cells=cells.value, seconds=secs.value)
+
+    def batch_align_profile(self, pool, q_off, q_len, profiles, size, x_drop=0, mode=(), threads=1):
+        """Threaded batch of sequence-to-profile alignments. -> dict(scores, query_idx, reference_idx, cells (per pair), cig_ops,
+        cig_off, cig_len, seconds)."""
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64); q_len = np.ascontiguousarray(q_len, dtype=np.uint32)
+        n = len(q_len)
+        p_len = np.array([p.str_len for p in profiles], np.uint32)
+        rows = p_len.astype(np.uint64) + 1
+        p_off = np.zeros(n, np.uint64)
+        np.cumsum(rows[:-1], out=p_off[1:])
+        pos_aa = np.concatenate([np.ascontiguousarray(p.pos_aa[: p.str_len + 1], dtype=np.int8) for p in profiles])
+        goc = np.concatenate([np.asarray(p.pos_gap_open_C[: p.str_len + 1], dtype=np.int8) for p in profiles])
+        gcc = np.concatenate([np.asarray(p.pos_gap_close_C[: p.str_len + 1], dtype=np.int8) for p in profiles])
+        gor = np.concatenate([np.asarray(p.pos_gap_open_R[: p.str_len + 1], dtype=np.int8) for p in profiles])
+        ge = profiles[0].gap_extend
+        scores = np.zeros(n, np.int32); qi = np.zeros(n, np.uint32); ri = np.zeros(n, np.uint32); cells = np.zeros(n, np.uint64)
+        trace = "trace" in mode
+        if trace:
+            cap = q_len.astype(np.uint64) + p_len.astype(np.uint64) + 1
+            cig_off = np.zeros(n, np.uint64)
+            np.cumsum(cap[:-1], out=cig_off[1:])
+            cig_ops = np.zeros(int(cap.sum()), np.uint32); cig_len = np.zeros(n, np.uint32)
+            cp, co, cl = cig_ops.ctypes.data, cig_off.ctypes.data, cig_len.ctypes.data
+        else:
+            cig_ops = cig_off = cig_len = None
+            cp = co = cl = None
+        secs = C.c_double()
+        rc = self.lib.ba_oracle_batch_align_profile(pool.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, n, pos_aa.ctypes.data, goc.ctypes.data,
+                                                    gcc.ctypes.data, gor.ctypes.data, p_off.ctypes.data, p_len.ctypes.data, ge, size[0], size[1], x_drop,
+                                                    flags_of(mode), threads, scores.ctypes.data, qi.ctypes.data, ri.ctypes.data, cp, co, cl,
+                                                    cells.ctypes.data, C.byref(secs))
+        if rc:
+            raise self._err()
+        return dict(scores=scores, query_idx=qi, reference_idx=ri, cells=cells, cig_ops=cig_ops, cig_off=cig_off, cig_len=cig_len, seconds=secs.value)
 
 
 OPS = " M=XID"

@@ -43,3 +43,19 @@ def hip():
         __graft_entry__.build()
     H.lib()
     return H
+
+
+@pytest.fixture
+def devlib(hip):
+    """Tests that force a code path with the BA_* development switches: those exist only in the development build of the library
+    (lib/libblock_aligner_hip_dev.so, ba_host.cpp with -DBA_DEV); the release library reads no environment variables."""
+    if not os.path.exists(hip.DEV_LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    release = hip.LIB_PATH
+    hip.use_library(hip.DEV_LIB_PATH)
+    assert hip.lib().ba_dev_build() == 1
+    yield hip
+    import gc
+    gc.collect()          # objects of the test are freed by the library that made them
+    hip.use_library(release)

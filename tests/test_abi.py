@@ -123,3 +123,17 @@ def test_reference_preconditions_abort_like_the_reference():
         p = subprocess.run([sys.executable, "-c", code % (root, gaps[0], gaps[1], lo)], capture_output=True, text=True, timeout=120)
         assert p.returncode == -signal.SIGABRT, (p.returncode, p.stderr[-300:])
         assert msg in p.stderr, p.stderr[-300:]
+
+
+def test_release_library_holds_no_development_switches():
+    """The release build of the host side compiles every getenv-driven switch out (-DBA_DEV builds lib/libblock_aligner_hip_dev.so,
+    which the tests that force a path load explicitly): no BA_* environment variable name is left in the shipped library."""
+    import re
+    from block_aligner_amd import hip as H
+    if not (os.path.exists(H.LIB_PATH) and os.path.exists(H.DEV_LIB_PATH)):
+        import __graft_entry__
+        __graft_entry__.build()
+    names = lambda path: set(m.decode() for m in re.findall(rb"BA_[A-Z][A-Z0-9_]{3,}(?=\x00)", open(path, "rb").read()))
+    env_like = {n for n in names(H.DEV_LIB_PATH) if not n.startswith(("BA_ST_", "BA_KIND", "BA_TRI_", "BA_AA_")) and n != "BA_TRACE"}   # (BA_TRACE: the mode bit, named in an error message)
+    assert {"BA_FORCE_QUAD", "BA_SKIP_WALK", "BA_NO_SPEC", "BA_FORCE_MULTI"} <= env_like      # the development build has them ...
+    assert not (env_like & names(H.LIB_PATH)), env_like & names(H.LIB_PATH)                     # ... the release build none

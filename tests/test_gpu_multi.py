@@ -14,7 +14,7 @@ MODES = [(), ("x_drop",), ("trace",), ("trace", "x_drop")]
 
 
 @pytest.fixture
-def force_multi(monkeypatch):
+def force_multi(devlib, monkeypatch):
     monkeypatch.setenv("BA_FORCE_MULTI", "1")
 
 

@@ -101,7 +101,7 @@ def test_config3_shape(hip, oracle):
     assert (res["query_idx"] > 9000).all()
 
 
-def test_traceback_consumer_path(hip, oracle, monkeypatch):
+def test_traceback_consumer_path(hip, oracle, devlib, monkeypatch):
     """Large TRACE batches hand finished trace stacks to dedicated traceback workgroups inside the launch
     (agent-scope release/acquire queue, slot reuse). Force that path on a batch small enough for the oracle and big
     enough that every fill wave recycles its trace slots several times."""
@@ -173,7 +173,7 @@ def _pssm_case(rng, length, block_max):
 @pytest.mark.parametrize("pipe", ["", "1", "quad"])
 @pytest.mark.parametrize("mode", [(), ("x_drop",), ("trace",), ("trace", "x_drop")])
 @pytest.mark.parametrize("size", [(16, 16), (32, 128), (32, 256), (128, 1024)])
-def test_profile_batch(hip, oracle, monkeypatch, mode, size, pipe):
+def test_profile_batch(hip, oracle, devlib, monkeypatch, mode, size, pipe):
     """Sequence-to-profile alignment (place_block_profile_*, scan_block.rs:612-783) as a batch: every pair has its own
     PSSM and per-position gap open / close costs; compared with the oracle pair by pair. pipe: the pair-slot form large TRACE
     batches take (a trace region per pair, all paths walked by k_walk after the fill), forced on this small batch."""
@@ -390,7 +390,7 @@ def test_special_modes_large_blocks(hip, oracle, mode, size):
         compare(hip, oracle, prot, S.BLOSUM62, (-11, -1), size, 60, mode, cigar_eq=False)
 
 
-def test_profile_traceback_lanes_and_exp(hip, oracle, monkeypatch):
+def test_profile_traceback_lanes_and_exp(hip, oracle, devlib, monkeypatch):
     """Profile batches through the in-launch traceback hand-off (forced on a small batch), and align_profile_exp as a batch."""
     monkeypatch.setenv("BA_FORCE_TB", "1")
     monkeypatch.setenv("BA_WGS_PER_CU", "1")
@@ -429,7 +429,7 @@ def test_profile_traceback_lanes_and_exp(hip, oracle, monkeypatch):
         assert (int(sc[k]), int(qi[k]), int(ri[k]), int(reached[k]) or None) == (r["score"], r["query_idx"], r["reference_idx"], got), k
 
 
-def test_longest_first_order_is_invisible(hip, oracle, monkeypatch):
+def test_longest_first_order_is_invisible(hip, oracle, devlib, monkeypatch):
     """The library hands the pairs to the waves longest first (ba_host.cpp Packed::order); scores, end positions, cells,
     CIGAR lengths and the CIGAR runs come back in the caller's order, identical to a batch kept in the caller's order."""
     pairs = synth.make_pairs(500, (0, 3000), (0, 150), 40, synth.DNA, seed=123)
@@ -453,7 +453,7 @@ def test_longest_first_order_is_invisible(hip, oracle, monkeypatch):
     assert np.array_equal(out[0][0]["score"], ref["scores"]) and np.array_equal(out[0][0]["cigar_len"], ref["cig_len"])
 
 
-def test_device_side_packing(hip, oracle, monkeypatch):
+def test_device_side_packing(hip, oracle, devlib, monkeypatch):
     """Pooled batches of 256+ pairs are padded and converted on the device (k_pack_sequences); the images must equal the
     host packer's (BA_HOST_PACK=1): same results on mixed-case input, same error for a byte outside the alphabet."""
     mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
@@ -541,7 +541,7 @@ def test_batch_api_errors_and_coexisting_batches(hip, oracle):
 
 
 @pytest.mark.parametrize("margin", ["3", "40", "175"])
-def test_adaptive_trace_slots_rerun_overflows(hip, oracle, monkeypatch, margin):
+def test_adaptive_trace_slots_rerun_overflows(hip, oracle, devlib, monkeypatch, margin):
     """Large TRACE batches size their trace slots for the expected stack (block at its minimum size, one grow sequence);
     pairs that outgrow a slot come back with BA_ST_TRACE_OVERFLOW and are re-run with the reference's full bound inside
     the same ba_batch_run. Forced here on a small batch with long indels and artificially small margins: whatever share
@@ -624,7 +624,7 @@ def test_percent_len_sizes_are_accepted(hip, oracle):
 
 
 @pytest.mark.parametrize("mode", [("x_drop",), (), ("trace", "x_drop"), ("trace",)])
-def test_small_block_pipeline(hip, oracle, monkeypatch, mode):
+def test_small_block_pipeline(hip, oracle, devlib, monkeypatch, mode):
     """Batches that start at 32 cells run in two fill passes: k_quad (four pairs per wave, one per 16-lane DPP row) starts every
     pair -- its first block as four 8-column sub-steps -- and runs its plain shift steps; the per-pair kernel then does whatever
     else a pair needs (grow, termination, matrix edge; pairs shorter than a block from scratch); pairs travel between the passes
@@ -646,7 +646,7 @@ def test_small_block_pipeline(hip, oracle, monkeypatch, mode):
 
 
 @pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
-def test_pair_slot_batches_without_small_blocks(hip, oracle, monkeypatch, mode):
+def test_pair_slot_batches_without_small_blocks(hip, oracle, devlib, monkeypatch, mode):
     """TRACE batches of many short pairs keep every pair's trace stack in its own region and walk all paths after the fill
     (k_walk, one pair per lane) whatever their block range; forced on small batches here."""
     monkeypatch.setenv("BA_FORCE_PIPE", "1")
@@ -658,7 +658,7 @@ def test_pair_slot_batches_without_small_blocks(hip, oracle, monkeypatch, mode):
 
 
 @pytest.mark.parametrize("mode", [(), ("trace",)])
-def test_small_block_batches_in_flight_together(hip, oracle, monkeypatch, mode):
+def test_small_block_batches_in_flight_together(hip, oracle, devlib, monkeypatch, mode):
     """Three small-block batches of global alignments launched back to back, each with its k_quad, the per-pair kernel beside it
     (which waits on k_quad's queue) and the one after it, on their own streams; then collected. Whatever order the device runs
     the kernels in, every batch's results are the oracle's -- a side launch that cannot get its k_quad going gives way."""
@@ -687,7 +687,7 @@ def test_small_block_batches_in_flight_together(hip, oracle, monkeypatch, mode):
 
 
 @pytest.mark.parametrize("margin", ["3", "60"])
-def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, monkeypatch, margin):
+def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, devlib, monkeypatch, margin):
     """The TRACE form of the small-block pipeline cuts the trace arena into one region per pair, sized for the pair's expected
     stack; a pair that outgrows its region leaves k_quad, reports BA_ST_TRACE_OVERFLOW from the per-pair kernel and is re-run
     with the reference's full bound inside the same ba_batch_run. Artificially small margins here; then the same batch object
@@ -716,7 +716,7 @@ def test_pair_slot_regions_rerun_overflows_and_reload(hip, oracle, monkeypatch, 
 
 
 @pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
-def test_speculative_grows_are_invisible(hip, oracle, monkeypatch, mode):
+def test_speculative_grows_are_invisible(hip, oracle, devlib, monkeypatch, mode):
     """TRACE batches run grow steps without trace flags while nothing says their rectangles can be on a path, and go back to the
     chain's checkpoint -- re-running the steps since, traced -- when a later step raises the best score or a global alignment
     ends on top of them (ba_driver.hpp, "speculative grows"). Pairs with long indels grow in mid-alignment, improve afterwards

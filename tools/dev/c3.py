@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from block_aligner_amd import hip as H, workloads as W
+H.use_library(H.DEV_LIB_PATH)   # the build that reads the BA_* development switches
 if os.environ.get("BA_LIB"):   # another build of the library (same-box A/B)
     H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), os.environ["BA_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
