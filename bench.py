@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--len", type=int, default=10000)
     ap.add_argument("--edits", type=int, default=1000)
     ap.add_argument("--tail", type=int, default=500)
+    ap.add_argument("--strong", action="store_true", help="strong scaling: ONE list of --pairs pairs, cut into cost-balanced slices, one per rank "
+                                                        "(default: weak scaling, --pairs pairs per rank)")
     ap.add_argument("--no-trace", action="store_true", help="score-only variant (not the headline workload)")
     ap.add_argument("--cpu-baseline-pairs", type=int, default=0, help="0 = size the sample for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,14 +169,24 @@ def main():
 
     import numpy as np
     from block_aligner_amd import workloads as W
-    from block_aligner_amd.shard import reduce_job, shard_seed
+    from block_aligner_amd.shard import job_slice, reduce_job, shard_seed
 
     # ---- synthetic workload (forked workers: must happen before any GPU initialisation)
     t0 = time.time()
     workers = a.gen_workers or min(32, max(1, usable_cpus() // max(1, world)))
     trace = not a.no_trace
-    w = W.config3(a.pairs, a.len, a.edits, a.tail, seed=shard_seed(1234, rank), trace=trace, workers=workers)
+    if a.strong:
+        # one global list (the same on every rank: same seed), of which this rank aligns its cost-balanced contiguous slice
+        # (block_aligner_amd/shard.py balanced_slices = the library's ba_shard_slices rule; no collective on the data path)
+        w = W.config3(a.pairs, a.len, a.edits, a.tail, seed=1234, trace=trace, workers=workers)
+        sub, lo, hi = job_slice(w.pairs, rank, world)
+        if sub is None:
+            raise RuntimeError(f"rank {rank}: empty slice ({a.pairs} pairs over {world} ranks)")
+        w.pairs = sub
+    else:
+        w = W.config3(a.pairs, a.len, a.edits, a.tail, seed=shard_seed(1234, rank), trace=trace, workers=workers)
     pairs = w.pairs
+    n_rank = len(pairs)
     t_gen = time.time() - t0
 
     import torch
@@ -221,20 +233,31 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         gcups_kernel = cells_rank / (k_ms * 1e-3) / 1e9          # this rank's kernel alone, from HIP events on its stream
         achieved_gbs = BYTES_PER_CELL[trace] * cells_rank / (k_ms * 1e-3) / 1e9
+        # measured HBM bytes per launch: only from a profile record taken on THESE kernel sources (tools/profile_round.sh writes
+        # profiles/rNN_roofline.json with the hash of the sources it ran; a record of another build is not quoted)
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                t = json.load(open(tf))
-                if t.get("pairs") == a.pairs and t.get("kind") == ("xdrop+trace" if trace else "xdrop"):
+        profile_ref = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_hash import kernel_hash
+            here = kernel_hash()
+            recs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_roofline.json"))
+            for f in reversed(recs):
+                t = json.load(open(os.path.join(ROOT, "profiles", f)))
+                if t.get("kernel_sources_sha16") == here and t.get("pairs") == a.pairs and t.get("kind") == ("xdrop+trace" if trace else "xdrop"):
                     traffic = t.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                    profile_ref = {"file": "profiles/" + f, "commit": t.get("commit"), "kernel_sources_sha16": here, "valu_busy_per_simd": t.get("valu_busy_per_simd"),
+                                   "sq_insts_valu": (t.get("sq") or {}).get("SQ_INSTS_VALU")}
+                    break
+            if profile_ref is None:
+                profile_ref = {"file": None, "kernel_sources_sha16": here, "note": "no profile record of these kernel sources under profiles/: traffic not quoted"}
+        except Exception as e:
+            profile_ref = {"file": None, "note": f"profile record unreadable: {e}"}
         ops = w.ops_per_cell
         tops = gcups_kernel * 1e9 * ops / 1e12
         roofline = {"bound": "valu-int16", "achieved": round(tops, 3), "peak": round(VALU_PEAK_INT16_TOPS, 1), "unit": "Tint16-op/s",
-                    "frac": round(tops / VALU_PEAK_INT16_TOPS, 5), "traffic": traffic,
-                    "kernel": "ba::k_align<8, NUC, trace=%d, xdrop=1>" % int(trace), "kernel_ms": round(k_ms, 3),
+                    "frac": round(tops / VALU_PEAK_INT16_TOPS, 5), "traffic": traffic, "profile": profile_ref,
+                    "kernel": "ba::k_multi<8, NUC, trace=%d, xdrop=1>" % int(trace), "kernel_ms": round(k_ms, 3),
                     "algorithmic_ops_per_cell": ops, "kernel_gcups": round(gcups_kernel, 1),
                     "hbm": {"achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
                             "algorithmic_bytes_per_cell": BYTES_PER_CELL[trace]},
@@ -247,7 +270,7 @@ def main():
         if trace:
             runs, off = batch.cigars(res["cigar_len"])
         # oracle-independent self-check of the HIP output: a spread of pairs' CIGARs re-walked and re-scored
-        rescored = self_check(np, w, res, runs, off, range(0, a.pairs, max(1, a.pairs // 256))) if trace else 0
+        rescored = self_check(np, w, res, runs, off, range(0, n_rank, max(1, n_rank // 256))) if trace else 0
 
         batch.close()      # the 10 kbp batch's trace arena is most of the device memory: free it before the side configurations
         # ---- parity check + CPU baseline (the oracle is the checker and the "port" baseline, never the product)
@@ -259,7 +282,7 @@ def main():
             build()
             o = Oracle("avx2")
             cores = usable_cpus()
-            n_s = a.cpu_baseline_pairs or min(a.pairs, max(64, 8000 * cores))   # ~1 ms per pair per core -> <= ~10 s on all usable cores
+            n_s = a.cpu_baseline_pairs or min(n_rank, max(64, 8000 * cores))   # ~1 ms per pair per core -> <= ~10 s on all usable cores
             ref, runs_checked = oracle_compare(np, o, w, res, runs, off, n_s, cores)
             n1 = min(n_s, 2000)                                                  # ~6 s on one core
             sub1 = pairs.subset(np.arange(n1))
@@ -303,17 +326,17 @@ def main():
         out = {
             "metric": "GCUPS (DP cells/s) on 10 kbp DNA X-drop batch; bit-exact score+CIGAR vs AVX2",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None, "dtype": "i16 (saturating lane scores) + i32 block offsets", "data": "synthetic",
-            "config": {"workload": f"config 3: {a.pairs} pairs/GPU x {a.len} bp random DNA, {a.edits} edits, +{a.tail} bp random tails, "
+            "config": {"workload": f"config 3: {a.pairs} pairs{' in total' if a.strong else '/GPU'} x {a.len} bp random DNA, {a.edits} edits, +{a.tail} bp random tails, "
                                    f"NucMatrix(2,-3), gaps(-5,-1), X-drop {w.x_drop}, block {size[0]}..{size[1]}, "
                                    + ("traceback to =/X CIGAR" if trace else "score only"),
-                       "pairs_per_gpu": a.pairs, "block": list(size), "trace": trace, "parallelism": f"{world} x independent shard",
+                       "pairs_per_gpu": n_rank, "pairs_total": a.pairs if a.strong else a.pairs * world, "block": list(size), "trace": trace, "parallelism": f"{world} x independent shard",
                        "grid_waves": info["grid"], "lds_bytes_per_wave": info["lds_bytes_per_wave"],
                        "trace_arena_gb": round(info["trace_arena_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "cells_per_step": cells_total},
-            "pairs_per_s": round(a.pairs * world * a.steps / elapsed, 1),
-            "full_matrix_equiv_gcups": round(full_equiv * world * a.steps / elapsed / 1e9, 1),
+            "pairs_per_s": round((a.pairs if a.strong else a.pairs * world) * a.steps / elapsed, 1),
+            "full_matrix_equiv_gcups": round(full_equiv * (1 if a.strong and world == 1 else world) * a.steps / elapsed / 1e9, 1),
             "computed_cells": cells_rank, "surviving_cells": surviving, "retried": retried_main,
             "cigar_runs_checked": runs_checked, "cigars_rescored": rescored,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,

@@ -442,7 +442,10 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
     lds_sync();
     // A walk is a long dependent chain of short instructions sharing its SIMD with VALU-saturating fill waves; without
     // priority it gets a quarter of the issue slots and every pending walk pins a whole trace slot meanwhile.
-    __builtin_amdgcn_s_setprio(3);
+#ifndef BA_TB_PRIO
+#define BA_TB_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(BA_TB_PRIO);
 #ifdef BA_TIMING
     unsigned long long c_sec[3] = {};
     unsigned long long c_iters = 0, c_walk_lanes = 0, c_walk_iters = 0, c_poll_iters = 0, c_walk_ticks = 0, c_t0 = __builtin_amdgcn_s_memtime();
@@ -1460,6 +1463,21 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
         uint32_t turn = 0;
         uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter: bp.work_chunk pairs per atomic
         bool closing = false;             // queue mode: every producer wave has been seen done
+        if (bp.cont_mode == 2 && bp.cq_side) {
+            // The launch beside k_quad: a queue ticket, once taken, is served (an abandoned one would be a lost pair), so no ticket
+            // is taken before k_quad is known to be on the device -- from then on its resident waves finish the batch's pairs whatever
+            // else waits, and every ticket resolves. Until then this wave holds nothing: if k_quad does not show up (several batches
+            // launched at once can fill the machine with waiting workgroups) it leaves, and the launch after k_quad drains the queue.
+            uint32_t spins = 0; bool up = false;
+            for (;;) {
+                uint32_t f = 0;
+                if (is_lane(0)) f = __hip_atomic_load(bp.cq_ctrl + 20, BA_RLX_AGENT);
+                if (uni((int)f)) { up = true; break; }
+                if (++spins > (1u << 20)) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (!up) return;
+        }
         for (;;) {
             BA_TSTAMP(tk0);
             if (bp.cont_mode != 2 && w_next == w_end) {
@@ -1475,32 +1493,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                 // Small-block batches: the pairs k_quad could not finish arrive through a queue while it is still running (entry =
                 // 1 + 2 * pair + (1 if the pair is to be run from scratch, else resume from its record)). A ticket is a queue position;
                 // the wave waits for its entry, and leaves once every producer wave is done and the queue ends before the ticket.
-                if (bp.cq_side) {
-                    // The launch beside k_quad never owns a queue position it might abandon (it may stop waiting: a claimed but
-                    // unread position would be a lost pair): it looks at the head entry and takes it with a compare-and-swap on
-                    // the head counter only once the entry is there. The launch after k_quad takes tickets (below): by then every
-                    // producer is done, so a ticket either has its entry or lies beyond the tail.
-                    uint32_t e = 0, spins = 0;
-                    for (;;) {
-                        uint32_t h = 0, v = 0, done = 0, tail = 0, won = 0;
-                        if (is_lane(0)) {
-                            h = __hip_atomic_load(bp.cq_ctrl + 16, BA_RLX_AGENT);
-                            done = __hip_atomic_load(bp.cq_ctrl + 32, BA_RLX_AGENT);
-                            tail = __hip_atomic_load(bp.cq_ctrl, BA_RLX_AGENT);
-                            if (h < bp.n) v = __hip_atomic_load(bp.cq_queue + h, BA_RLX_AGENT);
-                            if (v) { uint32_t expect = h; won = __hip_atomic_compare_exchange_strong(bp.cq_ctrl + 16, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
-                        }
-                        h = (uint32_t)uni((int)h); v = (uint32_t)uni((int)v); done = (uint32_t)uni((int)done); tail = (uint32_t)uni((int)tail); won = (uint32_t)uni((int)won);
-                        if (h >= bp.n) break;
-                        if (v) { if (won) { e = v; break; } continue; }               // (lost the race for this entry: look again)
-                        if (done >= bp.cq_producers && h >= tail) break;              // every producer done (read before the tail) and nothing is waiting
-                        if (++spins > (1u << 21)) break;                              // nothing claimed: the launch after k_quad drains the queue
-                        __builtin_amdgcn_s_sleep(32);
-                    }
-                    if (!e) break;
-                    pair = (e - 1u) >> 1;
-                    if (!((e - 1u) & 1u)) rec = bp.cont_in + pair;
-                } else {
+                {
                 if (w_next >= w_end) {   // one ticket while the producers run -- an entry is work waiting --, eight once they are done
                     const uint32_t chunk = closing ? 8u : 1u;
                     uint32_t t0 = 0;
@@ -1521,8 +1514,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
                         if (ticket >= (uint32_t)uni((int)tail)) break;
                     }
                     if (done >= bp.cq_producers) { closing = true; continue; }
-                    if (++spins > (1u << 21)) {   // several seconds without the producers finishing (they were done before this launch
-                        // started): never hang, report (the host fails the run)
+                    if (++spins > (1u << 24)) {   // tens of seconds without the producers finishing: never hang, and never lose the pair
+                        // silently -- report (the host fails the run). The launch beside k_quad takes tickets only once k_quad is
+                        // running (see below), so a ticket's producers are on the device and finish on their own.
                         if (is_lane(0)) __hip_atomic_store(bp.cq_ctrl + 48, 1u, BA_RLX_AGENT);
                         break;
                     }

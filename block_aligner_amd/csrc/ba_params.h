@@ -94,7 +94,7 @@ struct BatchParams {
     const PairCont* cont_in; const uint32_t* cont_in_flag;
     PairCont* cont_out; uint32_t* cont_out_flag;
     uint32_t* cq_queue;          // n entries: 1 + 2 * pair + (1: run from scratch), 0 = not yet written
-    uint32_t* cq_ctrl;           // [0] tail (entries appended), [16] head (tickets handed out), [32] producer waves done, [48] consumer gave up
+    uint32_t* cq_ctrl;           // [0] tail (entries appended), [16] head (tickets handed out), [20] k_quad is on the device, [32] producer waves done, [48] a ticket starved
     uint32_t cq_producers;       // k_quad waves of the launch
     uint32_t cq_side;            // 1: this per-pair launch runs beside k_quad (it may stop waiting; the launch after k_quad drains the queue)
     uint32_t inline_len2;        // pair-slot batches, per-pair kernel: pairs with |q| + |r| >= this walk their paths at once (lane 0), shorter ones leave them to k_walk

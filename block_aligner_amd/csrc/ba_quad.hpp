@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     const uint32_t total = bp.n;
     const uint32_t max_size = bp.max_size;
     const int x_drop = bp.x_drop;
+    if (lane == 0) __hip_atomic_store(bp.cq_ctrl + 20, 1u, BA_RLX_AGENT);   // on the device: the launch beside this one may take queue tickets (k_align)
 
     // ---- slot state (row-uniform, replicated over the slot's lanes)
     uint32_t pair = ~0u, si = 0, sj = 0, qlen = 0, rlen = 0, y_drop = 0, best_i = 0, best_j = 0, ck_i = 0, ck_j = 0, budget = 0, nsteps = 0;

@@ -31,6 +31,15 @@ def balanced_slices(q_len, r_len, parts: int):
     return bounds
 
 
+def job_slice(pairs, rank: int, world: int):
+    """Strong scaling: rank's cost-balanced contiguous slice of ONE global pair list -> (PairSet of the slice, lo, hi). An empty
+    slice (more ranks than pairs, or one pair that outweighs the rest) is returned as None."""
+    import numpy as np
+    b = balanced_slices(pairs.q_len, pairs.r_len, world)
+    lo, hi = b[rank], b[rank + 1]
+    return (pairs.subset(np.arange(lo, hi)) if hi > lo else None), lo, hi
+
+
 def reduce_job(elapsed_s: float, cells: float, device=None):
     """-> (max elapsed over ranks, total cells over ranks). Works on any initialised backend (nccl on GPU, gloo on CPU)."""
     import torch

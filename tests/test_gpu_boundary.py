@@ -1,0 +1,102 @@
+"""Boundary functions of the reference's C API that the other GPU tests only load: executed through the C ABI and compared with
+the oracle. block_set_all_aaprofile / _rev (ffi.rs:101-120, scores.rs:532-537,677-715: a whole PSSM in one call, optionally
+reversed, with the shift pair the reference applies to every score) and block_set_bytes_rev_padded_{aa,nuc} (ffi.rs:246-251,
+scan_block.rs:1824-1850: a sequence stored back to front)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from block_aligner_amd import scores as S
+from block_aligner_amd import synth
+from block_aligner_amd.hip import GapsC, SizeRangeC, AlignResultC
+
+pytestmark = pytest.mark.gpu
+
+ORDER = b"ARNDCQEGHILKMFPSTWYVBZX"
+
+
+def native_profile(L, str_len, block, ge, scores, lsh, rsh, rev, gaps):
+    L.block_new_aaprofile.restype = C.c_void_p
+    L.block_new_aaprofile.argtypes = [C.c_size_t, C.c_size_t, C.c_int8]
+    p = L.block_new_aaprofile(str_len, block, ge)
+    fn = L.block_set_all_rev_aaprofile if rev else L.block_set_all_aaprofile
+    fn.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+    fn(p, ORDER, len(ORDER), scores.ctypes.data, scores.size, lsh, rsh)
+    for name, g in zip(("open_C", "close_C", "open_R"), gaps):
+        f = getattr(L, f"block_set_all_gap_{name}_aaprofile")
+        f.argtypes = [C.c_void_p, C.c_int8]
+        f(p, g)
+    return p
+
+
+@pytest.mark.parametrize("rev", [False, True])
+@pytest.mark.parametrize("shifts", [(0, 0), (1, 0), (2, 3)])
+def test_set_all_aaprofile(hip, oracle, rev, shifts):
+    L = hip.lib()
+    rng = np.random.default_rng(42 + rev + 10 * shifts[0])
+    str_len, block = 137, 64
+    scores = rng.integers(-20, 21, size=str_len * len(ORDER)).astype(np.int8)
+    gaps = (-9, -1, -7)
+    p = native_profile(L, str_len, block, -1, scores, shifts[0], shifts[1], rev, gaps)
+    mirror = S.AAProfile(str_len, block, -1)
+    (mirror.set_all_rev if rev else mirror.set_all)(ORDER, scores, shifts[0], shifts[1])
+    mirror.set_all_gap_open_C(gaps[0]); mirror.set_all_gap_close_C(gaps[1]); mirror.set_all_gap_open_R(gaps[2])
+    # every cell the call wrote, read back through the ABI
+    L.block_get_aaprofile.restype = C.c_int8
+    L.block_get_aaprofile.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8]
+    for i in range(0, str_len + 1):
+        for b in ORDER:
+            assert L.block_get_aaprofile(p, i, b) == int(mirror.pos_aa[i, b - 65]), (i, chr(b))
+    # hand-checked corner: position 1 (or the last one, reversed) holds the first row of scores, shifted as i8
+    first = ((scores[: len(ORDER)].astype(np.int16) << shifts[0]).astype(np.int8) >> shifts[1]).astype(np.int8)
+    row = str_len if rev else 1
+    assert [L.block_get_aaprofile(p, row, b) for b in ORDER] == [int(x) for x in first]
+    # and an alignment against it, with traceback, equals the oracle's on the mirrored profile
+    q = synth.rand_str(rng, 120, synth.AMINO).tobytes()
+    pq = hip.PaddedBytes.from_bytes(q, block, S.AAMatrix)
+    L.block_new_aa_trace.restype = C.c_void_p
+    L.block_new_aa_trace.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
+    blk = L.block_new_aa_trace(len(q), str_len, block)
+    L.block_align_profile_aa_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, SizeRangeC, C.c_int32]
+    L.block_align_profile_aa_trace(blk, pq._h, p, SizeRangeC(32, block), 0)
+    L.block_res_aa_trace.restype = AlignResultC
+    L.block_res_aa_trace.argtypes = [C.c_void_p]
+    r = L.block_res_aa_trace(blk)
+    ref = oracle.align_profile(q, mirror, (32, block), 0, ("trace",))
+    assert (r.score, r.query_idx, r.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
+    cg = hip.Cigar(r.query_idx, r.reference_idx)
+    L.block_cigar_aa_trace.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.block_cigar_aa_trace(blk, r.query_idx, r.reference_idx, cg._h)
+    assert str(cg) == ref["cigar"]
+    L.block_free_aa_trace.argtypes = [C.c_void_p]
+    L.block_free_aa_trace(blk)
+    L.block_free_aaprofile.argtypes = [C.c_void_p]
+    L.block_free_aaprofile(p)
+
+
+@pytest.mark.parametrize("kind", ["aa", "nuc"])
+def test_set_bytes_rev_padded(hip, oracle, kind):
+    """A sequence stored back to front aligns like its reversal (scan_block.rs:1824-1831)."""
+    rng = np.random.default_rng(7)
+    alpha, cls, matrix, gaps = (synth.AMINO, S.AAMatrix, S.BLOSUM62, (-11, -1)) if kind == "aa" else (synth.DNA, S.NucMatrix, S.NucMatrix.new_simple(2, -3), (-5, -1))
+    r = synth.rand_str(rng, 400, alpha)
+    q = synth.mutate(rng, r, 40, alpha)
+    qb, rb = q.tobytes(), r.tobytes()
+    block = 128
+    pq = hip.PaddedBytes(len(qb), block, cls); pr = hip.PaddedBytes(len(rb), block, cls)
+    pq.set_bytes_rev(qb, block); pr.set_bytes_rev(rb, block)
+    assert pq.len() == len(qb)
+    a = hip.Block(len(qb), len(rb), block, trace=True)
+    a.align(pq, pr, matrix, S.Gaps(*gaps), (32, block), 0)
+    res = a.res()
+    ref = oracle.align(matrix, qb[::-1], rb[::-1], gaps, (32, block), 0, ("trace",), cigar_eq=True)
+    assert (res.score, res.query_idx, res.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
+    cg = hip.Cigar(res.query_idx, res.reference_idx)
+    a.trace().cigar_eq(pq, pr, res.query_idx, res.reference_idx, cg)
+    assert str(cg) == ref["cigar"]
+    # mixed case input is folded like the forward setter's
+    pq2 = hip.PaddedBytes(len(qb), block, cls)
+    pq2.set_bytes_rev(qb.lower(), block)
+    a.align(pq2, pr, matrix, S.Gaps(*gaps), (32, block), 0)
+    assert a.res().score == ref["score"]

@@ -114,3 +114,61 @@ def test_sharded_batch_merges_in_caller_order_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert tag == "merged" and ok and bounds[0] == 0 and bounds[-1] == 64 and 0 < bounds[1] < 64
+
+
+def _ragged_worker(rank, world, port, q):
+    """World 4, ragged slices of one global list (one pair outweighs many: a slice may be empty), traceback included: every rank
+    aligns its slice (the oracle stands in for the device on CPU), rank 0 gathers scores and CIGAR strings in caller order."""
+    import numpy as np
+    import torch.distributed as dist
+    from block_aligner_amd import scores as S
+    from oracle.oracle_py import Oracle, cigar_runs_to_string
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    lists = []
+    for n in [6000] + [int(x) for x in rng.integers(0, 120, 37)] + [0, 0, 2500]:
+        a = synth.rand_str(rng, n, synth.DNA)
+        lists.append((synth.mutate(rng, a, n // 10, synth.DNA).tobytes() if n else b"", a.tobytes()))
+    pairs = synth.PairSet.from_lists(lists)                                   # the same global list on every rank
+    sub, lo, hi = shard.job_slice(pairs, rank, world)
+    o = Oracle("avx2")
+    m = S.NucMatrix.new_simple(2, -3)
+    mine = []
+    if sub is not None:
+        ref = o.batch_align(m, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, (-5, -1), (32, 256), 60, ("trace", "x_drop"), cigar_eq=True)
+        for k in range(hi - lo):
+            runs = ref["cig_ops"][int(ref["cig_off"][k]): int(ref["cig_off"][k]) + int(ref["cig_len"][k])]
+            mine.append((lo + k, int(ref["scores"][k]), cigar_runs_to_string(runs)))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, mine))
+    if rank == 0:
+        full = o.batch_align(m, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 256), 60, ("trace", "x_drop"), cigar_eq=True)
+        merged = sorted(x for _, _, part in gathered for x in part)
+        ok = [i for i, _, _ in merged] == list(range(len(pairs)))
+        for i, sc, cg in merged:
+            runs = full["cig_ops"][int(full["cig_off"][i]): int(full["cig_off"][i]) + int(full["cig_len"][i])]
+            ok = ok and sc == int(full["scores"][i]) and cg == cigar_runs_to_string(runs)
+        spans = [(a, b) for a, b, _ in gathered]
+        q.put(("merged", ok, spans))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_slices_gloo_world4():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    tag, ok, spans = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert tag == "merged" and ok
+    assert spans[0][0] == 0 and spans[-1][1] == 41 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [b - a for a, b in spans]
+    assert min(sizes) < max(sizes)           # ragged: the 6000-base pair fills a slice almost alone

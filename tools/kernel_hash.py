@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""sha256 (first 16 hex digits) over the sources the device code and the launch geometry are built from: what a profile under
+profiles/ was taken on. bench.py quotes measured HBM traffic only from a profile whose hash equals the working tree's."""
+import hashlib
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = ["ba_params.h", "ba_device.hpp", "ba_driver.hpp", "ba_quad.hpp", "ba_multi.hpp", "ba_kernels.hip", "ba_host.cpp", "Makefile"]
+
+
+def kernel_hash() -> str:
+    h = hashlib.sha256()
+    for f in FILES:
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "block_aligner_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print(kernel_hash())

@@ -2,7 +2,7 @@
 # Collect the rocprofv3 evidence bench.py's roofline refers to (run on the GPU box):  tools/profile_round.sh r01
 #   1. kernel trace + stats of the default bench command (100k pairs)      -> gpurun_out/<tag>_kernel_trace_stats.md
 #   2. separate PMC passes (no tracing domains besides --kernel-trace): FETCH_SIZE, WRITE_SIZE, SQ instruction mix
-#                                                                            -> gpurun_out/<tag>_pmc_*.md, <tag>_traffic.json
+#                                                                            -> gpurun_out/<tag>_pmc_*.md, <tag>_roofline.json (tools/roofline_from_pmc.py)
 # The program after `--` is python3 itself (no env / shell hop), inputs are generated in-process (--gen-workers 1).
 tag=${1:-r01}
 pairs=${2:-100000}
@@ -30,5 +30,5 @@ for cfg in "c2 200000" "c2t 200000" "c4 400000" "c4t 400000" "c5 80000"; do
   db=$(find /tmp/prof_sec_$1 -name '*.db' | head -1)
   [ -n "$db" ] && python3 tools/prof_summary.py "$db" $out/${tag}_sec_$1.md "round ${tag#r}: rocprofv3 --kernel-trace --stats -- python3 tools/dev/sec.py $1 $2 ($(grep GCUPS $out/${tag}_sec_$1.log | tail -1))" > /dev/null
 done
-python3 tools/traffic_from_pmc.py $out/${tag}_pmc_fetch.md $out/${tag}_pmc_write.md $pairs > $out/${tag}_traffic.json
+python3 tools/roofline_from_pmc.py $tag $pairs $out/${tag}_roofline.json > /dev/null
 ls -la $out
