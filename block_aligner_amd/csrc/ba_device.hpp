@@ -684,4 +684,205 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     return res;
 }
 
+
+// ------------------------------------------------------------------ tall rectangles, eight cells per lane
+// Rectangles of 512 / 1024 / 2048 rows (the grow steps that end every X-drop alignment of the 10 kbp configuration: 29 % of its
+// cells) with EIGHT cells per lane: a column is cut into chunks of 512 cells, lane l of a chunk owning cells 8l .. 8l+7 as four
+// packed registers. The gap scan along the column (avx2.rs:297-338 + scan_block.rs:1144-1150) is an in-lane chain over the four
+// registers followed by ONE 64-lane DPP scan per 512 cells (place_rect: one per 128), with a scalar carry between chunks. Same
+// recurrences, same trace words (a lane's four registers are four consecutive words of place_rect's layout: word ((col >> 2) *
+// (rows / 128) + row / 128) * 64 + (row % 128) / 2), same results; sequence kinds only, no special modes (those stay with place_rect).
+template <int NC8, int KIND, bool TRACE, bool XDROP, bool LOC = XDROP>
+__device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& fc, const uint8_t* __restrict__ seqV, const uint8_t* __restrict__ seqC,
+                                            uint32_t lenV, uint32_t lenC, uint32_t start_i, uint32_t start_j, uint32_t width, short* Dc, short* Cc,
+                                            short* Dr, short* Rr, int corner, int rel_zero, int off_add, uint32_t* __restrict__ trace_out, unsigned long long& cells) {
+    static_assert(KIND != KIND_PROFILE, "sequence kinds only");
+    constexpr uint32_t height = NC8 * 512u;
+    constexpr int NCH = NC8 * 4;   // chunks of 128 cells in the trace layout
+    const int lane = lane_id();
+    Best res{0, 0, 0};
+    if (width == 0) return res;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int g = fc.gap_extend;
+    const int laneKG = lane * 8 * g, lanem1KG = lane ? (lane - 1) * 8 * g : -32768;
+    int G[4], vart[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        G[k] = pk(max(-32768, (2 * k + 1) * g), max(-32768, (2 * k + 2) * g));
+        int t[2];
+        for (int h = 0; h < 2; h++) {   // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338; see k_align)
+            const int k16 = (8 * lane + 2 * k + h) & 15;
+            const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
+            t[h] = mult ? max(-32768, mult * g) : -32768;
+        }
+        vart[k] = pk(t[0], t[1]);
+    }
+    const int offa = splat(off_add);
+    int d[NC8][4], c[NC8][4], dmax[NC8][4], jlast[NC8][4], tacc[NC8][4];
+    ScoreKey<KIND> key[NC8][4];
+    uint32_t vb[NC8][2];
+#pragma unroll
+    for (int c8 = 0; c8 < NC8; c8++) {   // all loads issued before any is used
+        const uint32_t* vp = (const uint32_t*)(seqV + start_i + c8 * 512 + 8 * lane);   // (positions are multiples of 8, images 4-byte aligned)
+        vb[c8][0] = vp[0]; vb[c8][1] = vp[1];
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < NC8; c8++) {
+        const int4 dv = *(const int4*)(Dc + c8 * 512 + 8 * lane), cv = *(const int4*)(Cc + c8 * 512 + 8 * lane);
+        d[c8][0] = adds(dv.x, offa); d[c8][1] = adds(dv.y, offa); d[c8][2] = adds(dv.z, offa); d[c8][3] = adds(dv.w, offa);   // just_offset (scan_block.rs:1003-1012)
+        c[c8][0] = adds(cv.x, offa); c[c8][1] = adds(cv.y, offa); c[c8][2] = adds(cv.z, offa); c[c8][3] = adds(cv.w, offa);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            dmax[c8][k] = 0; jlast[c8][k] = 0; tacc[c8][k] = 0;
+            const uint32_t w = vb[c8][k >> 1];
+            key[c8][k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
+        }
+    }
+    const bool break_armed = !XDROP && (start_i + height > lenV);
+    int cvec = (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
+    int sc_next[NC8][4];
+    {
+        const int cb0 = __builtin_amdgcn_readlane(cvec, 0);
+#pragma unroll
+        for (int c8 = 0; c8 < NC8; c8++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sc_next[c8][k] = fetch_score<KIND>(L.table, key[c8][k], cb0);
+    }
+    const bool last_lane = is_lane(63);
+    const uint32_t tw_lane = (uint32_t)((lane >> 4) * 64 + (lane & 15) * 4);   // this lane's four words inside a 512-cell chunk of one column group
+    int corner_cur = corner;
+    for (uint32_t j = 0; j < width; j++) {
+        int sc[NC8][4];
+#pragma unroll
+        for (int c8 = 0; c8 < NC8; c8++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sc[c8][k] = sc_next[c8][k];
+        // scores of the next column are fetched while this one is computed
+        if (((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
+        {
+            const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
+#pragma unroll
+            for (int c8 = 0; c8 < NC8; c8++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) sc_next[c8][k] = fetch_score<KIND>(L.table, key[c8][k], cbn);
+        }
+        int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
+        corner_cur = 0;
+        int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
+        const int jp1 = splat((int)j + 1);
+        int r_last = 0;
+#pragma unroll
+        for (int c8 = 0; c8 < NC8; c8++) {
+            // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
+            int prev = wave_shr1_z(d[c8][3]);
+            if (up_d != 0) prev = set_lane0(prev, up_d);
+            if (NC8 > 1) up_d = __builtin_amdgcn_readlane(d[c8][3], 63);
+            int d00[4];
+            d00[0] = __builtin_amdgcn_alignbit(d[c8][0], prev, 16);
+#pragma unroll
+            for (int k = 1; k < 4; k++) d00[k] = __builtin_amdgcn_alignbit(d[c8][k], d[c8][k - 1], 16);
+            int d11[4], copen[4], cn[4], x[4], r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                d11[k] = adds(d00[k], sc[c8][k]);
+                if (c8 == 0 && k == 0 && j == 0 && start_i == 0 && start_j == 0) {   // cell (0,0) starts from the relative zero (scan_block.rs:1130-1132): lane 0, low half
+                    const int v0 = __builtin_amdgcn_readlane(d11[0], 0);
+                    d11[0] = set_lane0(d11[0], (v0 & (int)0xffff0000) | (rel_zero & 0xffff));
+                }
+                copen[k] = adds(d[c8][k], fc.go2);
+                cn[k] = vmax(adds(c[c8][k], fc.ge2), copen[k]);
+                d11[k] = vmax(d11[k], cn[k]);
+                x[k] = adds(d11[k], fc.ome2);                                      // D11_open
+                const s16x2 t2 = as_s(adds(x[k], fc.ge2));
+                r[k] = vmax(x[k], as_i(s16x2{t2.x, t2.x}));                        // inside the register
+            }
+#pragma unroll
+            for (int k = 1; k < 4; k++) { const s16x2 pr = as_s(r[k - 1]); r[k] = vmax(r[k], adds(as_i(s16x2{pr.y, pr.y}), G[0])); }   // the chain over the lane's registers
+            const int pm = wave_prefix_max((int)as_s(r[3]).y - laneKG);           // one 64-lane scan on values re-based by lane * 8g
+            // what the cells above this lane contribute: lanes above in this chunk, or (lane * 8g + carry) from above the chunk,
+            // which is MIN = 0 at the top of the column
+            int cin = add_shr1(pm, lanem1KG);
+            cin = max(max(cin, NC8 > 1 ? laneKG + carry_r : laneKG), -32768);
+            const s16x2 cs = as_s(cin);
+            const int csp = as_i(s16x2{cs.x, cs.x});
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = vmax(vmax(r[k], adds(csp, G[k])), vart[k]);
+            if (NC8 > 1) carry_r = (int)(short)(__builtin_amdgcn_readlane(r[3], 63) >> 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int dn = vmax(d11[k], r[k]);
+                if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect)
+                    const uint32_t sC = (uint32_t)subs(cn[k], dn), sR = (uint32_t)subs(r[k], dn), sCo = (uint32_t)subs(copen[k], cn[k]), sRo = (uint32_t)subs(x[k], r[k]);
+                    const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);
+                    const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);
+                    tacc[c8][k] = (int)(((uint32_t)tacc[c8][k] >> 4) | (nib & 0xF000F000u));
+                }
+                dmax[c8][k] = vmax(dmax[c8][k], dn);
+                if (LOC) jlast[c8][k] = vmaxu(jlast[c8][k], pk_mul(eq01(dmax[c8][k], dn, fc.ones), jp1));   // 1 + last column whose cell ties or raises its row's running max
+                d[c8][k] = dn; c[c8][k] = cn[k];
+            }
+            if (c8 == NC8 - 1) r_last = r[3];
+        }
+        if (TRACE && (j & 3) == 3) {
+#pragma unroll
+            for (int c8 = 0; c8 < NC8; c8++) {
+                *(int4*)(trace_out + ((j >> 2) * NCH + c8 * 4) * 64 + tw_lane) = int4{tacc[c8][0], tacc[c8][1], tacc[c8][2], tacc[c8][3]};
+                tacc[c8][0] = tacc[c8][1] = tacc[c8][2] = tacc[c8][3] = 0;
+            }
+        }
+        // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
+        if (last_lane) { Dr[j] = (short)(d[NC8 - 1][3] >> 16); Rr[j] = (short)(r_last >> 16); }
+        cells += height;
+        if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
+            if (TRACE && (j & 3) != 3) {            // (the words of the unfinished column group: its columns so far sit in the high nibbles)
+#pragma unroll
+                for (int c8 = 0; c8 < NC8; c8++) {
+                    const int sh = 4 * (3 - (int)(j & 3));
+                    *(int4*)(trace_out + ((j >> 2) * NCH + c8 * 4) * 64 + tw_lane) =
+                        int4{(int)((uint32_t)tacc[c8][0] >> sh), (int)((uint32_t)tacc[c8][1] >> sh), (int)((uint32_t)tacc[c8][2] >> sh), (int)((uint32_t)tacc[c8][3] >> sh)};
+                }
+            }
+            break;
+        }
+    }
+    // ---- write the vector-axis border back
+#pragma unroll
+    for (int c8 = 0; c8 < NC8; c8++) {
+        *(int4*)(Dc + c8 * 512 + 8 * lane) = int4{d[c8][0], d[c8][1], d[c8][2], d[c8][3]};
+        *(int4*)(Cc + c8 * 512 + 8 * lane) = int4{c[c8][0], c[c8][1], c[c8][2], c[c8][3]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- rectangle max and (X-drop) its location: among cells equal to the max, smallest (row % 16), then largest column, then
+    // largest row (avx2.rs:271-274 + scan_block.rs:1198-1200 last-writer-wins per lane)
+    int lm = -32768;
+#pragma unroll
+    for (int c8 = 0; c8 < NC8; c8++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) lm = max(lm, max((int)as_s(dmax[c8][k]).x, (int)as_s(dmax[c8][k]).y));
+    const int M = wave_max(lm);
+    res.mx = M;
+    if (LOC) {
+        int kmin = 0x7fffffff;
+#pragma unroll
+        for (int c8 = 0; c8 < NC8; c8++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int v = h ? (int)as_s(dmax[c8][k]).y : (int)as_s(dmax[c8][k]).x;
+                    const int jl1 = h ? (jlast[c8][k] >> 16) & 0xffff : jlast[c8][k] & 0xffff;
+                    const int jl = jl1 ? jl1 - 1 : 0;
+                    const int row = c8 * 512 + 8 * lane + 2 * k + h;
+                    const int kk = ((row & 15) << 24) | ((4095 - jl) << 12) | (4095 - row);
+                    if (v == M) kmin = min(kmin, kk);
+                }
+        kmin = wave_min(kmin);
+        res.col = 4095 - ((kmin >> 12) & 4095);
+        res.row = 4095 - (kmin & 4095);
+    }
+    return res;
+}
+
 }  // namespace ba

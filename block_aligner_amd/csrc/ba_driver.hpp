@@ -1155,9 +1155,14 @@ struct Aligner {
             }
             else if (rh <= 128) BA_PLACE(1);
             else if (PMAX >= 2 && rh == 256) BA_PLACE(2);
-            else if (PMAX >= 4 && rh == 512) BA_PLACE(4);
-            else if (PMAX >= 8 && rh == 1024) BA_PLACE(8);
-            else if (PMAX >= 16 && rh == 2048) BA_PLACE(16);
+            // (512 rows and more: eight cells per lane, see place_rect8 -- sequence kinds without special modes)
+#define BA_PLACE8(N8) do { if constexpr (KIND != KIND_PROFILE && !SPECIAL && !kBig) { \
+                if (TRACE && spec) cur = place_rect8<N8, KIND, false, XDROP, false>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, Dc, Cc, Dr, Rr, corner, rz, off_add, nullptr, cells); \
+                else cur = place_rect8<N8, KIND, TRACE, XDROP>(L, fc, seqV, seqC, lenV, lenC, ri, rj, rw, Dc, Cc, Dr, Rr, corner, rz, off_add, tout, cells); } } while (0)
+            else if (PMAX >= 4 && rh == 512) { if constexpr (KIND != KIND_PROFILE && !SPECIAL && !kBig) BA_PLACE8(1); else BA_PLACE(4); }
+            else if (PMAX >= 8 && rh == 1024) { if constexpr (KIND != KIND_PROFILE && !SPECIAL && !kBig) BA_PLACE8(2); else BA_PLACE(8); }
+            else if (PMAX >= 16 && rh == 2048) { if constexpr (KIND != KIND_PROFILE && !SPECIAL && !kBig) BA_PLACE8(4); else BA_PLACE(16); }
+#undef BA_PLACE8
 #undef BA_PLACE
 #undef BA_PLACE_S
 #undef BA_PLACE_T
