@@ -215,6 +215,9 @@ constexpr int TB_CELLS_PER_STEP = 4;
 #ifndef BA_WALK_DEPTH
 #define BA_WALK_DEPTH 4
 #endif
+#ifndef BA_HELPER_CELLS
+#define BA_HELPER_CELLS 4   // cells per call of an emptied fill wave's walking lanes (TB_CELLS_PER_STEP: the same code as the dedicated waves)
+#endif
 // DEPTH: rectangle records fetched ahead. A path skips rectangles (a right strip's left neighbour on the path is an earlier right
 // strip, the down strips in between are not on it): with DEPTH > 1 a call walks down the stack past them instead of spending one
 // call -- one memory round trip of its wave -- on each.
@@ -499,7 +502,12 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
             if (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut, c_sec);
             c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
 #else
-            if (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
+            // (an emptied fill wave's few lanes -- the batch's last walks, each a chain of memory round trips that ends the launch --
+            // take more cells per call and look further ahead; dedicated waves share their SIMD with fill waves: see tb_step)
+            if (t.i > 0 || t.j > 0) {
+                if (BA_HELPER_CELLS != TB_CELLS_PER_STEP && !dedicated) tb_step<BA_HELPER_CELLS, BA_WALK_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
+                else tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
+            }
 #endif
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);

@@ -586,6 +586,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // (the traceback work per filled cell grows as the block shrinks: with blocks below 128 cells one wave per 3
         // workgroups -- 1 kbp DNA, block 32..256: 360 GCUPS against 285 at one per 4)
         uint32_t stride = b->grid >= 32 ? (b->min_size >= 128 ? 4 : 3) : 2;
+        // (k_multi fills faster -- four pairs per wave, eight cells per lane -- and its walks are what it waits for: one traceback wave
+        // per 2 workgroups. Config 3, same box: per 4: 217 ms, per 3: 200.4, per 2: 198.9)
+        if (b->multi && b->grid >= 32) stride = 2;
         if (const char* env = dev_env("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
