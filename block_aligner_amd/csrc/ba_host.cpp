@@ -1523,7 +1523,9 @@ static int handle_prepare(BlockImpl* h) {
 }
 
 // One alignment through a handle's persistent state. `profile` non-null: sequence-to-profile (kind PROFILE).
-static void handle_align(BlockImpl* h, int kind, const PaddedBytes* q, const PaddedBytes* r, const AAProfile* profile, const void* matrix,
+// q_s / r_s: a padded image's bytes as the reference keeps them (scan_block.rs:1790-1812: index 0 is the NULL pad, then the converted
+// sequence); r_s unused with a profile.
+static void handle_align(BlockImpl* h, int kind, const uint8_t* q_s, size_t q_len, const uint8_t* r_s, size_t r_len, const AAProfile* profile, const void* matrix,
                          Gaps g, size_t min_size, size_t max_size, int32_t x) {
     if (!h->dev && handle_prepare(h)) die("%s", g_err.c_str());
     BaBatch* b = h->dev.get();
@@ -1532,14 +1534,14 @@ static void handle_align(BlockImpl* h, int kind, const PaddedBytes* q, const Pad
     if (pc < 0) die("max block size %zu not supported by the HIP backend (16..%zu)", max_size, (size_t)BA_MAX_BLOCK);
     const uint32_t mode = h->mode & ~(uint32_t)BA_CIGAR_EQ;
     const bool trace = mode & BA_TRACE;
-    if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > q->len)) die("Min block size must be larger than the query length for FREE_QUERY_END_GAPS!");   // scan_block.rs:860-862
+    if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > q_len)) die("Min block size must be larger than the query length for FREE_QUERY_END_GAPS!");   // scan_block.rs:860-862
     b->kind = kind; b->mode = mode; b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
     b->gap_open = g.open; b->gap_extend = g.extend; b->x_drop = x;
     if (pc == BA_PCLASS_BIG && special_of(mode)) die("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
     b->lds = ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
     // ---- the upload: per-pair words + the two padded images (scan_block.rs:1798-1812), built in the handle's staging buffer
     const size_t pad = max_size + 16;
-    const uint32_t ql = (uint32_t)q->len, rl = (uint32_t)(profile ? profile->str_len : r->len);
+    const uint32_t ql = (uint32_t)q_len, rl = (uint32_t)(profile ? profile->str_len : r_len);
     HandleUpload hu{};
     hu.q_off = HandleUpload::images; hu.q_len = ql; hu.r_len = rl; hu.work_counter = 0;
     const size_t q_img = (1 + (size_t)ql + pad + 3 + 8) & ~(size_t)7;
@@ -1552,10 +1554,10 @@ static void handle_align(BlockImpl* h, int kind, const PaddedBytes* q, const Pad
     memcpy(st, &hu, sizeof hu);
     const uint8_t nb = null_byte(kind);
     uint8_t* qi = st + hu.q_off;
-    qi[0] = nb; memcpy(qi + 1, q->s.data() + 1, ql); memset(qi + 1 + ql, nb, q_img - 1 - ql);
+    qi[0] = nb; memcpy(qi + 1, q_s + 1, ql); memset(qi + 1 + ql, nb, q_img - 1 - ql);
     uint8_t* ri = st + hu.r_off;
     if (profile) profile_image(profile, ba::profile_positions(rl, (uint32_t)max_size), ri);
-    else { ri[0] = nb; memcpy(ri + 1, r->s.data() + 1, rl); memset(ri + 1 + rl, nb, r_img - 1 - rl); }
+    else { ri[0] = nb; memcpy(ri + 1, r_s + 1, rl); memset(ri + 1 + rl, nb, r_img - 1 - rl); }
     memset(st + hu.r_off + r_img, nb, POOL_SLACK);
     b->pool_bytes = used; b->cig_total = trace ? hu.cig_off[1] : 0;
     b->h_q_off.assign(1, hu.q_off); b->h_r_off.assign(1, hu.r_off);
@@ -1602,7 +1604,7 @@ static void block_align_impl(BlockImpl* b, int kind, const PaddedBytes* q, const
     // Allocated::clear (scan_block.rs:1324-1326)
     if (q->len + r->len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
     if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
-    handle_align(b, kind, q, r, nullptr, matrix, g, min_size, max_size, x);
+    handle_align(b, kind, q->s.data(), q->len, r->s.data(), r->len, nullptr, matrix, g, min_size, max_size, x);
 }
 
 static void block_align_profile_impl(BlockImpl* b, const PaddedBytes* q, const AAProfile* pr, SizeRange s, int32_t x) {   // scan_block.rs:942-968
@@ -1614,7 +1616,7 @@ static void block_align_profile_impl(BlockImpl* b, const PaddedBytes* q, const A
     if (min_size > max_size) die("min block size exceeds max block size");
     if (q->len + pr->str_len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
     if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
-    handle_align(b, BA_KIND_PROFILE_, q, nullptr, pr, nullptr, g, min_size, max_size, x);
+    handle_align(b, BA_KIND_PROFILE_, q->s.data(), q->len, nullptr, 0, pr, nullptr, g, min_size, max_size, x);
 }
 
 static void block_cigar_impl(BlockImpl* b, bool eq, const PaddedBytes* q, const PaddedBytes* r, size_t i, size_t j, Cigar* cigar) {
@@ -1665,6 +1667,31 @@ void block_align_generic(BlockHandle b, int kind, const PaddedBytes* q, const Pa
 }
 void block_align_profile_generic(BlockHandle b, const PaddedBytes* q, const AAProfile* p, SizeRange s, int32_t x) {
     block_align_profile_impl((BlockImpl*)b, q, p, s, x);
+}
+// The same two calls for a caller that keeps its own PaddedBytes (the Rust crate behind the `simd_hip` feature: rust/src/): the
+// padded image as the reference stores it -- [NULL] + converted bytes + NULL padding (scan_block.rs:1790-1812) -- by pointer.
+void block_align_padded_generic(BlockHandle bh, int kind, const uint8_t* q_s, uintptr_t q_len, const uint8_t* r_s, uintptr_t r_len, const void* matrix,
+                                Gaps g, SizeRange s, int32_t x) {
+    BlockImpl* b = (BlockImpl*)bh;
+    if (kind < 0 || kind > 2) die("unknown matrix kind %d", kind);
+    const size_t min_size = s.min < 16 ? 16 : s.min, max_size = s.max < 16 ? 16 : s.max;
+    std::string why;
+    if (check_align_params(false, g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    if (min_size > max_size) die("min block size exceeds max block size");
+    if (q_len + r_len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
+    if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
+    handle_align(b, kind, q_s, q_len, r_s, r_len, nullptr, matrix, g, min_size, max_size, x);
+}
+void block_align_profile_padded_generic(BlockHandle bh, const uint8_t* q_s, uintptr_t q_len, const AAProfile* pr, SizeRange s, int32_t x) {
+    BlockImpl* b = (BlockImpl*)bh;
+    const size_t min_size = s.min < 16 ? 16 : s.min, max_size = s.max < 16 ? 16 : s.max;
+    const Gaps g{0, pr->gap_extend};
+    std::string why;
+    if (check_align_params(true, g, min_size, max_size, x, b->mode, &why)) die("%s", why.c_str());
+    if (min_size > max_size) die("min block size exceeds max block size");
+    if (q_len + pr->str_len > b->query_len + b->reference_len) die("sequence lengths exceed the bounds this Block was created with");
+    if (max_size > b->max_size) die("max block size exceeds the bound this Block was created with");
+    handle_align(b, BA_KIND_PROFILE_, q_s, q_len, nullptr, 0, pr, nullptr, g, min_size, max_size, x);
 }
 AlignResult block_res_generic(BlockHandle b) { return ((BlockImpl*)b)->res; }
 void block_cigar_generic(BlockHandle b, uintptr_t i, uintptr_t j, Cigar* c) { block_cigar_impl((BlockImpl*)b, false, nullptr, nullptr, i, j, c); }

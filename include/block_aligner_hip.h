@@ -162,6 +162,13 @@ struct AlignResult block_res_generic(BlockHandle b);
 /* Block::<mode>::align_profile (scan_block.rs:942-968): q must be an AA PaddedBytes; the gap costs come from the profile. */
 void block_align_profile_generic(BlockHandle b, const struct PaddedBytes* q, const struct AAProfile* profile, struct SizeRange s,
                                  int32_t x);
+/* The same two calls for a caller that keeps its own PaddedBytes (the Rust crate behind the `simd_hip` feature, rust/src/): the padded
+ * image as the reference stores it -- [NULL] + converted bytes + NULL x block_size (src/scan_block.rs:1790-1812) -- passed by pointer
+ * (q_s[0] is the NULL pad; q_len the sequence length). */
+void block_align_padded_generic(BlockHandle b, int kind, const uint8_t* q_s, uintptr_t q_len, const uint8_t* r_s, uintptr_t r_len,
+                                const void* matrix, struct Gaps g, struct SizeRange s, int32_t x);
+void block_align_profile_padded_generic(BlockHandle b, const uint8_t* q_s, uintptr_t q_len, const struct AAProfile* profile,
+                                        struct SizeRange s, int32_t x);
 void block_cigar_generic(BlockHandle b, uintptr_t query_idx, uintptr_t reference_idx, struct Cigar* cigar);
 void block_cigar_eq_generic(BlockHandle b, const struct PaddedBytes* q, const struct PaddedBytes* r, uintptr_t query_idx,
                             uintptr_t reference_idx, struct Cigar* cigar);
