@@ -100,3 +100,43 @@ def test_set_bytes_rev_padded(hip, oracle, kind):
     pq2.set_bytes_rev(qb.lower(), block)
     a.align(pq2, pr, matrix, S.Gaps(*gaps), (32, block), 0)
     assert a.res().score == ref["score"]
+
+
+def test_align_padded_images_by_pointer(hip, oracle):
+    """block_align_padded_generic (the Rust shim's entry, rust/src/scan_block_hip.rs): the caller's own padded images --
+    [NULL] + converted bytes + NULL x block_size, scan_block.rs:1790-1812 -- by pointer; same results as the handle objects."""
+    L = hip.lib()
+    rng = np.random.default_rng(3)
+    block = 256
+    r = synth.rand_str(rng, 700, synth.DNA)
+    q = synth.mutate(rng, r, 70, synth.DNA)
+    m = S.NucMatrix.new_simple(2, -3)
+
+    def image(b):   # NucMatrix: convert_char = upper case, NULL = 'Z' (scores.rs:139-216)
+        return np.concatenate([[ord("Z")], np.frombuffer(bytes(b).upper(), np.uint8), np.full(block, ord("Z"))]).astype(np.uint8)
+
+    qi, ri = image(q.tobytes()), image(r.tobytes())
+    L.block_new_generic.restype = C.c_void_p
+    blk = L.block_new_generic(hip.TRACE | hip.X_DROP, len(q), len(r), block)
+    L.block_align_padded_generic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, GapsC, SizeRangeC, C.c_int32]
+    raw = m.raw()
+    L.block_align_padded_generic(blk, 1, qi.ctypes.data, len(q), ri.ctypes.data, len(r), raw.ctypes.data, GapsC(-5, -1), SizeRangeC(32, block), 50)
+    res = L.block_res_generic(blk)
+    ref = oracle.align(m, q.tobytes(), r.tobytes(), (-5, -1), (32, block), 50, ("trace", "x_drop"), cigar_eq=True)
+    assert (res.score, res.query_idx, res.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
+    cg = hip.Cigar(res.query_idx, res.reference_idx)
+    L.block_cigar_eq_generic(blk, None, None, res.query_idx, res.reference_idx, cg._h)
+    assert str(cg) == ref["cigar"]
+    L.block_free_generic(blk)
+    # and a profile through the same kind of entry
+    aq = synth.rand_str(rng, 90, synth.AMINO).tobytes()
+    prof = S.AAProfile.from_bytes(synth.rand_str(rng, 110, synth.AMINO).tobytes(), 64, 2, -1, -3, 0, -3, -1)
+    aimg = np.concatenate([[26], np.frombuffer(aq, np.uint8) - 65, np.full(64, 26)]).astype(np.uint8)   # AAMatrix: c - 'A', NULL = '[' - 'A' = 26
+    native = hip._NativeProfile(prof)
+    blk = L.block_new_generic(hip.TRACE, len(aq), prof.str_len, 64)
+    L.block_align_profile_padded_generic.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, SizeRangeC, C.c_int32]
+    L.block_align_profile_padded_generic(blk, aimg.ctypes.data, len(aq), native._h, SizeRangeC(32, 64), 0)
+    res = L.block_res_generic(blk)
+    ref = oracle.align_profile(aq, prof, (32, 64), 0, ("trace",))
+    assert (res.score, res.query_idx, res.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
+    L.block_free_generic(blk)
