@@ -534,6 +534,63 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
 #endif
 }
 
+// A fill wave that waits for a trace slot while the traceback side makes no progress (its waves may not be on the device yet: a launch
+// that is only partly resident) walks a pending traceback itself instead of giving up: it takes the ring's head entry -- only if the
+// entry is there: compare-and-swap on the head counter after seeing it, so nothing is ever claimed that might not come -- and walks it
+// with lane 0 out of its own LDS region. Returns true if a walk was done (one of this wave's slots may be free now).
+template <int LB = (int)TB_LANE_BYTES>
+__device__ __forceinline__ bool traceback_help_one(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
+    uint32_t entry = 0;
+    if (is_lane(0)) {
+        uint32_t h = __hip_atomic_load(bp.tb_ctrl + 32, BA_RLX_AGENT);
+        if (h < bp.n) {
+            const uint32_t e = __hip_atomic_load(bp.tb_queue + (h & bp.tb_qmask), BA_RLX_AGENT);
+            if (e && __hip_atomic_compare_exchange_strong(bp.tb_ctrl + 32, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                entry = e;
+                __hip_atomic_store(bp.tb_queue + (h & bp.tb_qmask), 0u, BA_RLX_AGENT);
+            }
+        }
+    }
+    entry = (uint32_t)uni((int)entry);
+    if (!entry) return false;
+    if (entry & 0x80000000u) {   // a pair that produced no trace stack
+        if (is_lane(0)) bp.cig_len[entry & 0x7fffffffu] = 0;
+        return true;
+    }
+    unsigned char* lut = tb_lds;
+    unsigned char* lrec = tb_lds + TB_LUT_BYTES;
+    lds_sync();
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const uint32_t idx = (uint32_t)lane_id() + 64u * e;
+        const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);
+        lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
+    }
+    lds_sync();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (is_lane(0)) {
+        const uint32_t eq = bp.flags & flag_mask;
+        TbLane t{};
+        t.qw0 = t.rw0 = 0xffffffffu; t.tw_ok = false;
+        t.slot = entry - 1;
+        const SlotInfo si = bp.slot_info[t.slot];
+        t.pair = si.pair; t.i = si.end_i; t.j = si.end_j; t.bidx = si.nblocks;
+        t.blocks = bp.blocks + (uint64_t)t.slot * bp.blocks_stride;
+        t.trace = bp.trace_arena + (uint64_t)t.slot * bp.trace_stride;
+        t.q = bp.pool + bp.q_off[t.pair]; t.r = bp.pool + bp.r_off[t.pair];
+        t.lo = bp.cig_off[t.pair]; t.wp = bp.cig_off[t.pair + 1];
+        t.status = bp.status[t.pair];
+        if (t.status || (bp.flags & 0x200u)) t.i = t.j = 0;
+        while (t.i > 0 || t.j > 0) tb_step<TB_CELLS_PER_STEP, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
+        tb_emit(t, bp.cig_ops);
+        bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
+        if (t.status) bp.status[t.pair] = t.status;
+        __hip_atomic_store(bp.slot_free + t.slot, 1u, BA_RLX_AGENT);
+    }
+    lds_sync();
+    return true;
+}
+
 // Pair-slot batches (every pair's trace stack stays in its own region until the batch ends): the tracebacks of the whole
 // batch after its fill kernels, one pair per LANE, all 64 lanes of every wave walking (tb_step). Lanes that finish take the
 // next pairs of the batch order (longest first, so the lanes of a wave walk paths of similar length) with one atomic per wave.
@@ -889,7 +946,8 @@ struct Aligner {
     // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done). The wait only
     // gives up when the traceback side as a whole has stopped making progress: no task claimed for ~2 s, scaled by the
     // batch's longest pair (a walk over a multi-Mbp pair alone takes seconds).
-    __device__ __forceinline__ bool acquire_slot(uint32_t slot) {
+    // tb_lds: this wave's LDS region (free between pairs): see traceback_help_one.
+    __device__ __forceinline__ bool acquire_slot(uint32_t slot, const BatchParams& bp, unsigned char* tb_lds) {
         uint32_t seen = 0, idle = 0;
         const uint32_t limit = (1u << 20) * (1u + (uint32_t)(coldp()->blocks_stride >> 15));
         for (;;) {
@@ -905,6 +963,8 @@ struct Aligner {
             head = (uint32_t)uni((int)head);
             if (head != seen) { seen = head; idle = 0; }
             else if (++idle > limit) return false;
+            // nobody has taken a traceback for a few milliseconds: walk one here (a launch whose traceback waves are not resident)
+            else if ((idle & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, tb_lds)) idle = 0;
             __builtin_amdgcn_s_sleep(64);
         }
     }
@@ -1462,6 +1522,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
     if (bp.prof && blockIdx.x == 0 && wave == 1 && is_lane(0)) atomicMax(bp.prof + 43, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
+        if (!(bp.flags & 0x800u))   // (development switch: the traceback waves leave at once, as if they were never resident -- see traceback_help_one)
         traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
                            (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(LCLS), 64u, true);
 #ifdef BA_TIMING
@@ -1545,7 +1606,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             if (TRACE && bp.trace_off) slot = pair;   // pair-slot batches: the pair's own region (never shared, never waited for)
             Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
             BA_TSTAMP(tw0);
-            const bool got_slot = !batch_traceback || al.acquire_slot(slot);
+            const bool got_slot = !batch_traceback || al.acquire_slot(slot, bp, (unsigned char*)base);
             BA_TSTAMP(tw1);
 #ifdef BA_TIMING
             if (bp.prof && is_lane(0)) atomicAdd(bp.prof + 17, tw1 - tw0);

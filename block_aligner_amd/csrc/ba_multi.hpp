@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     unsigned long long t_solo = 0, t_quad = 0, t_wait = 0, n_solo = 0, n_quad = 0;
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
+        if (!(bp.flags & 0x800u))   // (development switch: as if the traceback waves were never resident)
         traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 64u, true);   // (records in this wave's own region)
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -284,6 +285,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                         head = (uint32_t)uni((int)head);
                         if (head != seen) { seen = head; idle_n = 0; }
                         else if (++idle_n > limit) break;
+                        // nobody has taken a traceback for a few milliseconds: walk one here (see traceback_help_one; the wave's LDS region
+                        // is free: the slots' buffers are in the arena while the wave is in solo mode)
+                        else if ((idle_n & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base)) idle_n = 0;
                         __builtin_amdgcn_s_sleep(64);
                     }
 #ifdef BA_TIMING

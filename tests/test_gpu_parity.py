@@ -728,3 +728,18 @@ def test_speculative_grows_are_invisible(hip, oracle, devlib, monkeypatch, mode)
     res2 = compare(hip, oracle, pairs, NUC, (-5, -1), size, 120, mode)
     for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len"):
         assert np.array_equal(res[k], res2[k]), k
+
+
+@pytest.mark.parametrize("size", [(32, 128), (128, 512)])
+def test_fill_waves_walk_when_the_traceback_waves_are_missing(hip, oracle, devlib, monkeypatch, size):
+    """A launch whose traceback waves are not on the device (here: a development switch makes them leave at once) must not fail pairs
+    with BA_ST_SLOT_TIMEOUT: a fill wave that finds nobody taking tracebacks walks pending ones itself (traceback_help_one), and the
+    emptied fill waves walk the rest. (128, 512) takes the multi-pair kernel, (32, 128) the per-pair one."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_NO_TB_WAVES", "1")
+    monkeypatch.setenv("BA_FORCE_MULTI", "1")
+    monkeypatch.setenv("BA_NO_QUAD", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", "1")
+    monkeypatch.setenv("BA_SLOTS_PER_WAVE", "1" if size[0] == 32 else "6")
+    pairs = synth.make_pairs(4000, (400, 1500), (30, 150), 60, synth.DNA, seed=77 + size[0])
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, ("trace", "x_drop"))
