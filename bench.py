@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-baseline-pairs", type=int, default=0, help="0 = size the sample for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / 4 / 5 lines")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive pass (e2e_gcups)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes for input generation (0 = auto; use 1 under rocprofv3)")
     return ap.parse_args()
 
@@ -154,6 +155,41 @@ def secondary_line(np, H, W, o, w, cores):
     return {"config": w.name, "gcups": round(gc, 1), "valu_frac": round(gc * 1e9 * w.ops_per_cell / 1e12 / VALU_PEAK_INT16_TOPS, 4),
             "ops_per_cell": w.ops_per_cell, "kernel_ms": round(ms, 3), "pairs": n, "m_pairs_per_s": round(n / (ms * 1e-3) / 1e6, 3),
             "full_matrix_equiv_gcups": round(w.full_matrix_cells() / (ms * 1e-3) / 1e9, 1), "parity_checked_pairs": checked, "retried": retried}
+
+
+def measure_e2e(np, H, W, w, sets=4):
+    """PCIe-inclusive rate (never `value`): `sets` sets of the batch stream from host memory through two batch objects -- while one
+    set is aligned the host reloads the other object with the next set; scores, end positions and the gathered CIGAR runs (written by
+    the device straight into page-locked host buffers behind the kernels) come back to host arrays."""
+    import time as _t
+    p = w.pairs
+    args = (p.pool, p.q_off, p.q_len, p.r_off, p.r_len)
+    bs = [W.make_batch(H, w), W.make_batch(H, w)]
+    cap = int(p.q_len.astype(np.int64).sum() + p.r_len.astype(np.int64).sum()) // 8 + (1 << 20)   # runs per set: far below one run per 8 residues
+    bufs = [H.pinned_array(cap), H.pinned_array(cap)]
+    for b in bs:
+        b.run()
+    t0 = _t.perf_counter()
+    cells = 0
+    cur, nxt = 0, 1
+    bs[cur].reload(*args); bs[cur].launch(); bs[cur].compact_cigars(bufs[cur])
+    for s in range(sets):
+        if s + 1 < sets:
+            bs[nxt].reload(*args)
+        bs[cur].wait()
+        if s + 1 < sets:
+            bs[nxt].launch(); bs[nxt].compact_cigars(bufs[nxt])
+        res = bs[cur].results()
+        runs, off = bs[cur].cigars(res["cigar_len"], out=bufs[cur])
+        if res["status"].any():
+            raise RuntimeError("bench.py: pairs failed on the device in the end-to-end pass")
+        cells += int(res["cells"].sum())
+        cur, nxt = nxt, cur
+    dt = _t.perf_counter() - t0
+    for b in bs:
+        b.close()
+    return {"gcups": round(cells / dt / 1e9, 1), "sets": sets, "pairs_per_set": len(p), "seconds": round(dt, 3), "cigar_mb_per_set": round(int(off[-1]) * 4 / 1e6, 1),
+            "what": "host pool -> device (reload) -> align -> scores + CIGAR runs in host memory, two batch objects alternating; PCIe and host packing included"}
 
 
 def main():
@@ -273,6 +309,12 @@ def main():
         rescored = self_check(np, w, res, runs, off, range(0, n_rank, max(1, n_rank // 256))) if trace else 0
 
         batch.close()      # the 10 kbp batch's trace arena is most of the device memory: free it before the side configurations
+        e2e = None
+        if trace and world == 1 and not a.no_e2e:
+            try:
+                e2e = measure_e2e(np, H, W, w)
+            except Exception as ex:   # (reported, never fatal for the headline: two arenas may not fit beside another process)
+                e2e = {"gcups": None, "error": str(ex)[:200]}
         # ---- parity check + CPU baseline (the oracle is the checker and the "port" baseline, never the product)
         cpu = None
         secondary = None
@@ -338,7 +380,7 @@ def main():
             "pairs_per_s": round((a.pairs if a.strong else a.pairs * world) * a.steps / elapsed, 1),
             "full_matrix_equiv_gcups": round(full_equiv * (1 if a.strong and world == 1 else world) * a.steps / elapsed / 1e9, 1),
             "computed_cells": cells_rank, "surviving_cells": surviving, "retried": retried_main,
-            "cigar_runs_checked": runs_checked, "cigars_rescored": rescored,
+            "cigar_runs_checked": runs_checked, "cigars_rescored": rescored, "e2e_gcups": (e2e or {}).get("gcups"), "e2e": e2e,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out), flush=True)

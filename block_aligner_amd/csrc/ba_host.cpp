@@ -36,6 +36,8 @@ BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
     extern "C" hipError_t ba_occupancy_big_k##K##_p32(int, int, unsigned, int*);
 BA_DECL_BIG(0) BA_DECL_BIG(1) BA_DECL_BIG(2) BA_DECL_BIG(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
+extern "C" hipError_t ba_launch_cigar_offsets_and_compact(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint64_t*, uint32_t*,
+                                                          unsigned long long*, unsigned long long, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_walk(hipStream_t, const BatchParams*, uint32_t grid);
 extern "C" hipError_t ba_launch_merge_retry(hipStream_t, const uint32_t*, uint32_t, const BatchParams*, const BatchParams*, const uint32_t*, uint32_t*);
@@ -245,6 +247,11 @@ struct BaBatch {
     bool pipe = false;
     DevBuf trace_off, blocks_off;
     uint64_t pipe_words = 0, pipe_recs = 0;   // arena capacities (ba_batch_reload re-cuts them)
+    // CIGAR runs gathered on the device right behind the alignment kernels (ba_batch_compact_cigars): the later ba_batch_cigars is then one
+    // device-to-host copy -- no kernel that would have to wait for room beside another batch's persistent launch
+    DevBuf compact, compact_off, compact_total, dev_of;
+    uint64_t compact_cap = 0, compact_used_cap = 0; bool compacted = false; uint32_t* compact_host = nullptr;
+    unsigned long long* h_total = nullptr;   // page-locked mailbox the gather writes its total to (read without a copy)
     bool handle_mode = false;   // the device state of one Block handle: one pair per launch, CIGARs only on request (k_traceback)
     DevBuf hblk, rblk;          // handle mode: everything uploaded per align / everything read back, one buffer each
     BatchParams params() const {
@@ -278,6 +285,7 @@ struct BaBatch {
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (h_total) (void)hipHostFree(h_total);
         if (ev_l0) (void)hipEventDestroy(ev_l0);
         if (ev_m1) (void)hipEventDestroy(ev_m1);
         if (stream2) (void)hipStreamDestroy(stream2);
@@ -661,6 +669,7 @@ static int upload_images(BaBatch* b, const Packed& P, size_t n) {
     return 0;
 }
 
+static int upload_dev_of(BaBatch* b);
 // `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1); for kind PROFILE the reference comes from
 // `getp(p)` instead.
 template <class GetSeq, class GetProfile = NoProfiles>
@@ -773,9 +782,20 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
 #undef BA_H2D
     lap("host-to-device copies");
     if (hipMemset(b->cig_len.p, 0, n * 4) != hipSuccess || hipMemset(b->status.p, 0, n * 4) != hipSuccess) { fail("hipMemset failed"); return nullptr; }
+    if (upload_dev_of(b.get())) return nullptr;
     return b.release();
 }
 
+
+// device copy of the caller-order -> device-order map (for the gather of CIGAR runs in the caller's order, ba_batch_compact_cigars)
+static int upload_dev_of(BaBatch* b) {
+    if (!(b->mode & BA_TRACE) || b->h_order.empty()) return 0;
+    std::vector<uint32_t> dev_of(b->n);
+    for (uint32_t s = 0; s < b->n; s++) dev_of[b->h_order[s]] = s;
+    if (!b->dev_of.p && b->dev_of.alloc((size_t)b->cap_n * 4)) return 1;
+    HIP_TRY(hipMemcpy(b->dev_of.p, dev_of.data(), (size_t)b->n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
 
 // Replace the pairs of an existing batch (same matrix, gaps, block range and modes); the device buffers -- above all the
 // trace arena, whose allocation dominates the set-up time -- are reused, so the new set must fit what they were sized for.
@@ -809,7 +829,7 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     b->n = (uint32_t)n; b->h_q_off = P.qo; b->h_r_off = P.ro; b->h_order = P.order; b->pool_bytes = P.total;
     b->cig_total = (b->mode & BA_TRACE) ? P.cig_total : 0;
     b->ran = false;
-    return 0;
+    return upload_dev_of(b);
 }
 
 // Enqueue one pass over the batch on its stream and return; batch_wait collects it. (Two batches on two streams
@@ -823,6 +843,7 @@ static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves
 }
 static int batch_launch(BaBatch* b) {
     if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");
+    b->compacted = false;
     if (b->n == 0) return fail("the batch holds no pairs (its last reload failed)");
     HIP_TRY(hipSetDevice(b->device));
     if (!b->handle_mode) {   // (a handle's work counter arrives zeroed with its upload; it has no hand-off structures)
@@ -995,6 +1016,15 @@ static void to_caller_order(const std::vector<uint32_t>& order, T* dst) {
 extern "C" {
 
 const char* ba_last_error(void) { return g_err.c_str(); }
+// Page-locked host memory for a caller's result buffers (CIGAR runs above all: 600 MB per 100 k 10 kbp pairs come back at 5 GB/s into
+// pageable memory, at PCIe speed into this).
+void* ba_host_alloc(uint64_t bytes) {
+    if (ensure_device()) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault) != hipSuccess) { fail("hipHostMalloc(%llu bytes) failed", (unsigned long long)bytes); return nullptr; }
+    return p;
+}
+void ba_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int ba_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1078,11 +1108,50 @@ int ba_batch_surviving_cells(BaBatch* b, uint64_t* cells) {
     for (uint32_t s = 0; s < b->n; s++) cells[b->h_order.empty() ? s : b->h_order[s]] = (uint64_t)w[s] / per_word * 8;
     return 0;
 }
+// Enqueue, behind the launch in flight (call between ba_batch_launch and ba_batch_wait), the gather of every pair's CIGAR runs into one
+// dense device buffer in the caller's pair order. ba_batch_cigars then only copies. Optional: without it ba_batch_cigars gathers on demand.
+int ba_batch_compact_cigars(BaBatch* b, uint32_t* pinned_out, uint64_t pinned_capacity) {
+    if (!b) return fail("null batch");
+    if (!(b->mode & BA_TRACE)) return fail("batch was created without BA_TRACE");
+    if (!b->in_flight) return fail("ba_batch_compact_cigars goes between ba_batch_launch and ba_batch_wait");
+    if (b->adaptive && b->pipe) return 0;   // (pair-slot batches may re-run pairs after the wait: gather on demand)
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->compact_off.p && b->compact_off.alloc((size_t)b->cap_n * 8)) return 1;
+    if (!b->h_total) { HIP_TRY(hipHostMalloc((void**)&b->h_total, 64, hipHostMallocDefault)); }
+    // pinned_out (memory from ba_host_alloc, which the device can write): the gather writes the runs straight into the caller's host
+    // buffer -- over PCIe, inside the stream, right behind the kernels; ba_batch_cigars on the same pointer then has nothing left to copy
+    // (a device-to-host copy issued while another batch's persistent launch fills the machine waits for that launch: copies of this size
+    // are done by copy kernels). Otherwise: into a device buffer.
+    uint32_t* out = pinned_out; uint64_t cap = pinned_capacity;
+    if (!out) {
+        if (!b->compact.p) {
+            // capacity: a third of the worst case (every cell of a pair's path its own run) covers any real alignment; if it ever does not,
+            // the gather is skipped on the device and ba_batch_cigars falls back
+            b->compact_cap = std::max<uint64_t>(b->cap_cig / 3, 1u << 20);
+            if (b->compact.alloc(b->compact_cap * 4)) return 1;
+        }
+        out = b->compact.as<uint32_t>(); cap = b->compact_cap;
+    }
+    HIP_TRY(ba_launch_cigar_offsets_and_compact(b->stream, b->cig_ops.as<uint32_t>(), b->cig_off.as<uint64_t>(), b->cig_len.as<uint32_t>(),
+                                                b->h_order.empty() ? nullptr : b->dev_of.as<uint32_t>(), b->compact_off.as<uint64_t>(), out,
+                                                b->h_total, cap, b->n));
+    b->compacted = true; b->compact_host = pinned_out; b->compact_used_cap = cap;
+    return 0;
+}
 int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
     if (!b) return fail("null batch");
     if (!(b->mode & BA_TRACE)) return fail("batch was created without BA_TRACE");
     if (!b->ran) return fail("ba_batch_run has not been called");
     HIP_TRY(hipSetDevice(b->device));
+    if (b->compacted && b->retried == 0) {   // gathered behind the launch: one copy
+        const unsigned long long total = *(volatile unsigned long long*)b->h_total;   // (written by the gather; the stream was synchronised by ba_batch_wait)
+        if (total <= b->compact_used_cap) {
+            if (total > capacity) return fail("cigar buffer too small: need %llu entries", total);
+            if (b->compact_host) { if (runs != b->compact_host && total) memcpy(runs, b->compact_host, total * 4); }   // already in host memory
+            else if (total) HIP_TRY(hipMemcpy(runs, b->compact.p, total * 4, hipMemcpyDeviceToHost));
+            return 0;
+        }
+    }
     std::vector<uint32_t> len(b->n);
     if (d2h(b->cig_len, len.data(), b->n)) return 1;
     // runs go out pair after pair in the caller's order; the device arrays are in device order

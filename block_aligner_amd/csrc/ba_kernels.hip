@@ -148,6 +148,46 @@ __global__ void __launch_bounds__(256) k_compact_cigars(const uint32_t* __restri
         for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) out[dst + k] = ops[src + k];
     }
 }
+// Offsets of the compacted CIGAR runs, pair after pair in the CALLER's order (dev_of[p] = device position of the caller's pair p):
+// out_off[dev_of[p]] = sum of cig_len[dev_of[p']] over p' < p; *total = the sum over all pairs. One workgroup: per-thread chunk sums,
+// a scan over the 1024 partial sums, a second pass.
+__global__ void __launch_bounds__(1024) k_cigar_offsets(const uint32_t* __restrict__ cig_len, const uint32_t* __restrict__ dev_of, uint64_t* __restrict__ out_off,
+                                                        unsigned long long* __restrict__ total, uint32_t n) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(t * per, n), hi = min(lo + per, n);
+    unsigned long long sum = 0;
+    for (uint32_t p = lo; p < hi; p++) sum += cig_len[dev_of ? dev_of[p] : p];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive scan
+        const unsigned long long v = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long at = part[t] - sum;
+    for (uint32_t p = lo; p < hi; p++) { const uint32_t s = dev_of ? dev_of[p] : p; out_off[s] = at; at += cig_len[s]; }
+    if (t == 1023) *total = part[1023];
+}
+// the gather itself, only if everything fits (else *total says how much is needed and nothing is written)
+__global__ void __launch_bounds__(256) k_compact_cigars_checked(const uint32_t* __restrict__ ops, const uint64_t* __restrict__ cig_off,
+                                                                const uint32_t* __restrict__ cig_len, const uint64_t* __restrict__ out_off,
+                                                                uint32_t* __restrict__ out, uint32_t n, const unsigned long long* __restrict__ total, unsigned long long capacity) {
+    if (*total > capacity) return;
+    for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
+        const uint32_t len = cig_len[p];
+        const uint64_t src = cig_off[p + 1] - len, dst = out_off[p];
+        for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) out[dst + k] = ops[src + k];
+    }
+}
+extern "C" hipError_t ba_launch_cigar_offsets_and_compact(hipStream_t s, const uint32_t* ops, const uint64_t* cig_off, const uint32_t* cig_len, const uint32_t* dev_of,
+                                                          uint64_t* out_off, uint32_t* out, unsigned long long* total, unsigned long long capacity, uint32_t n) {
+    k_cigar_offsets<<<dim3(1), dim3(1024), 0, s>>>(cig_len, dev_of, out_off, total, n);
+    const unsigned grid = n < 4096 ? (n ? n : 1) : 4096;
+    k_compact_cigars_checked<<<dim3(grid), dim3(256), 0, s>>>(ops, cig_off, cig_len, out_off, out, n, total, capacity);
+    return hipGetLastError();
+}
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t s, const uint32_t* ops, const uint64_t* cig_off, const uint32_t* cig_len,
                                                const uint64_t* out_off, uint32_t* out, uint32_t n) {
     const unsigned grid = n < 4096 ? (n ? n : 1) : 4096;

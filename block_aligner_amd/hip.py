@@ -75,6 +75,9 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         vp, sz, u32, i32, i8, u8p = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32, C.c_int8, C.c_char_p
         L.ba_last_error.restype = C.c_char_p
+        L.ba_host_alloc.restype = vp
+        L.ba_host_alloc.argtypes = [C.c_uint64]
+        L.ba_host_free.argtypes = [vp]
         L.ba_set_device.argtypes = [C.c_int]
         L.block_percent_len.restype = sz
         L.block_percent_len.argtypes = [sz, C.c_float]
@@ -120,6 +123,7 @@ def lib() -> C.CDLL:
         L.ba_batch_wait.argtypes = [vp, C.POINTER(C.c_float)]
         L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
+        L.ba_batch_compact_cigars.argtypes = [vp, vp, C.c_uint64]
         L.ba_batch_surviving_cells.argtypes = [vp, vp]
         L.ba_batch_retried.argtypes = [vp]
         L.ba_device_memory.argtypes = [vp, vp]
@@ -136,6 +140,15 @@ def lib() -> C.CDLL:
         _lib = L
         _loaded[LIB_PATH] = L
     return _lib
+
+
+def pinned_array(n: int, dtype=np.uint32) -> np.ndarray:
+    """A numpy array over page-locked host memory (ba_host_alloc): pass it as `out=` to BatchAligner.cigars. Lives until the process ends."""
+    nbytes = int(n) * np.dtype(dtype).itemsize
+    p = lib().ba_host_alloc(nbytes)
+    if not p:
+        raise RuntimeError(last_error())
+    return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)).view(dtype)
 
 
 def last_error() -> str:
@@ -389,6 +402,12 @@ class BatchAligner:
         if lib().ba_batch_launch(self._h):
             raise RuntimeError(last_error())
 
+    def compact_cigars(self, pinned_out=None) -> None:
+        """Between launch() and wait(): gather the CIGAR runs on the device behind the kernels -- straight into `pinned_out` (an array
+        from pinned_array(); pass the same array as cigars(out=...)) or into a device buffer (cigars() is then one copy)."""
+        if lib().ba_batch_compact_cigars(self._h, pinned_out.ctypes.data if pinned_out is not None else None, pinned_out.size if pinned_out is not None else 0):
+            raise RuntimeError(last_error())
+
     def wait(self) -> float:
         ms = C.c_float()
         if lib().ba_batch_wait(self._h, C.byref(ms)):
@@ -403,13 +422,15 @@ class BatchAligner:
             raise RuntimeError(last_error())
         return out
 
-    def cigars(self, cigar_len=None):
-        """-> (runs, offsets): runs[offsets[p]:offsets[p+1]] are pair p's packed (len << 4 | op) runs."""
+    def cigars(self, cigar_len=None, out=None):
+        """-> (runs, offsets): runs[offsets[p]:offsets[p+1]] are pair p's packed (len << 4 | op) runs. out: a uint32 array to reuse
+        (a fresh 600 MB array costs more in page faults than the copy into it)."""
         if cigar_len is None:
             cigar_len = self.results()["cigar_len"]
         off = np.zeros(self.n + 1, np.uint64)
         np.cumsum(cigar_len, out=off[1:])
-        runs = np.zeros(int(off[-1]), np.uint32)
+        total = int(off[-1])
+        runs = out[:total] if out is not None and out.size >= total else np.empty(total, np.uint32)
         if lib().ba_batch_cigars(self._h, runs.ctypes.data, runs.size):
             raise RuntimeError(last_error())
         return runs, off

@@ -119,6 +119,9 @@ BA_DECLARE_BLOCK_FNS(aa_trace_xdrop, block_cigar_aa_trace_xdrop, block_cigar_eq_
 
 /* thread-local message for the last failing Part 2 call */
 const char* ba_last_error(void);
+/* Page-locked host memory for result buffers (device-to-host copies into it run at PCIe speed; into pageable memory at a fraction). */
+void* ba_host_alloc(uint64_t bytes);
+void ba_host_free(void* p);
 /* number of usable HIP devices (0 if the runtime is unusable); ba_set_device selects the one later calls OF THE CALLING
  * THREAD use (the selection is per host thread, so one thread can drive each GPU) */
 int ba_device_count(void);
@@ -224,6 +227,11 @@ int ba_batch_results(BaBatch* batch, int32_t* score, uint32_t* query_idx, uint32
 /* CIGAR runs of all pairs, concatenated in pair order (pair p occupies cigar_len[p] entries after the pairs before it).
  * `capacity` = number of uint32 entries available in `runs`; fails if too small. */
 int ba_batch_cigars(BaBatch* batch, uint32_t* runs, uint64_t capacity);
+/* Optional, between ba_batch_launch and ba_batch_wait: gather the CIGAR runs on the device right behind the alignment kernels -- into
+ * `pinned_out` (memory from ba_host_alloc, capacity in runs; after ba_batch_wait the runs are in host memory and ba_batch_cigars on the same
+ * pointer copies nothing), or with pinned_out = NULL into a device buffer (ba_batch_cigars is then one device-to-host copy). Either way no
+ * kernel or copy has to find room beside another batch's launch afterwards. */
+int ba_batch_compact_cigars(BaBatch* batch, uint32_t* pinned_out, uint64_t pinned_capacity);
 /* TRACE batches: per pair, the sum of width x height over the rectangles left on its trace stack (Trace::blocks(),
  * scan_block.rs:1676-1691; the numerator of the reference's "DP fraction", examples/uc_accuracy.rs:88-89). */
 int ba_batch_surviving_cells(BaBatch* batch, uint64_t* cells);

@@ -141,3 +141,25 @@ def test_release_library_ignores_the_development_switches(hip, oracle, monkeypat
     assert np.array_equal(base_runs, again_runs)
     ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (32, 256), 80, mode, cigar_eq=True, threads=8)
     assert np.array_equal(ref["scores"], base["score"]) and np.array_equal(ref["cig_len"], base["cigar_len"])
+
+
+def test_cigars_gathered_behind_the_launch(hip, oracle):
+    """ba_batch_compact_cigars between launch and wait: ba_batch_cigars is then a plain copy of the same runs, in the caller's order
+    (the device works on the pairs longest first)."""
+    pairs = synth.make_pairs(3000, (100, 1200), (10, 120), 40, synth.DNA, seed=606)
+    mode = ("trace", "x_drop")
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 80, mode_bits(hip, mode, True), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    b.run()
+    res0 = b.results()
+    runs0, off0 = b.cigars(res0["cigar_len"])          # gathered on demand
+    pinned = hip.pinned_array(runs0.size + 1000)
+    for out in (None, None, pinned, pinned):
+        b.launch(); b.compact_cigars(out); b.wait()
+        res = b.results()
+        runs, off = b.cigars(res["cigar_len"], out=out)   # gathered behind the launch: one copy / already in host memory
+        assert np.array_equal(off, off0) and np.array_equal(runs, runs0)
+        if out is not None:
+            out[:] = 0
+    ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (128, 512), 80, mode, cigar_eq=True, threads=8)
+    assert np.array_equal(runs0, flat_oracle_runs(ref, len(pairs)))
+    b.close()

@@ -9,7 +9,7 @@ pairs=${2:-100000}
 cd "$(dirname "$0")/.."
 out=gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
-B="bench.py --pairs $pairs --gen-workers 1 --no-cpu-baseline"
+B="bench.py --pairs $pairs --gen-workers 1 --no-cpu-baseline --no-e2e"
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift
   rm -rf /tmp/prof_$name
