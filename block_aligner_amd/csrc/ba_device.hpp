@@ -378,6 +378,9 @@ struct TileCtx {
     int corner0;                // !first: D of the cell above the tile in the column left of the rectangle (already re-based)
     const short* topD; const short* topR;   // !first: D and R of the row above, per column (the tile above wrote them; overwritten in place)
     bool break_armed;           // the whole rectangle's early-break condition (scan_block.rs:1216-1224)
+    // FREE_QUERY_END_GAPS over tiles: per column, the running maximum of the tracked vector lane over the tiles so far (fqR) and the
+    // best value with which a tracked vector tied or raised the maximum of everything above it in its column (fqT); see place_rect
+    short* fqR; short* fqT;
 };
 // uniform value from memory this kernel also writes: a vector load (never the scalar cache), then broadcast
 __device__ __forceinline__ int load_uniform_i16(const short* p) {
@@ -460,7 +463,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     int top_d_hold = below ? tc->corner0 : 0, top_d_next = 0, top_r_next = 0;
     if (below) { top_d_next = load_uniform_i16(tc->topD); top_r_next = load_uniform_i16(tc->topR); }
     const int rz2 = splat(rel_zero);
-    const uint32_t zwords = (width >> 2) * (uint32_t)(NCH * nl);   // SP_LOCAL: the zero mask follows the rectangle's trace words
+    const uint32_t zwords = (width >> 2) * (uint32_t)((tc ? tc->nch_total : NCH) * nl);   // SP_LOCAL: the zero mask follows the (whole) rectangle's trace words
     int corner_cur = corner;
     int cvec = PDIR == 1 ? 0 : (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
     // Profiles, blocks up to 256 cells: the scores (and per-position gap costs) of a whole group of 8 columns are fetched
@@ -546,6 +549,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         }
         const int jp1 = splat((int)j + 1);
         int r_last = 0;
+        int fq_cm = -32768, fq_rec = -32768;   // (SP_FQE over tiles, see below)
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
             // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
@@ -588,7 +592,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 nib = pk_mad_k<8>(nRo, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
                 if ((sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
-                    trace_out[zwords + (j * NCH + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);
+                    trace_out[zwords + (j * NCHT + CHB + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);
             }
             if (sp & SP_FQE) {
                 // D_max / argmax_j of vector lane k = len % 16 in the reference's visiting order (columns outer, vectors
@@ -599,9 +603,18 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 const int v = mine ? ((k & 1) ? (int)as_s(dn).y : (int)as_s(dn).x) : -32768;
                 const int pm = wave_prefix_max(v);
                 const uint32_t vec_base = start_i + ch * 128 + ((2 * lane) & ~15);
+                if (tc) {
+                    // Row tiles visit the cells tile by tile, not column by column: here only what this tile's part of the column
+                    // says -- its maximum (fq_cm) and the best value with which one of its tracked vectors tied or raised everything
+                    // above it in the tile (fq_rec) --; the columns are put together after the last tile (Aligner::run).
+                    const bool rec = mine && vec_base + 16 > lenV && v == max(pm, fq_cm);
+                    fq_rec = max(fq_rec, wave_max(rec ? v : -32768));
+                    fq_cm = max(fq_cm, __builtin_amdgcn_readlane(pm, 63));
+                } else {
                 const bool hit = mine && vec_base + 16 > lenV && v == max(pm, fqM);
                 if (__any(hit)) fqJ = (int)j;
                 fqM = max(fqM, __builtin_amdgcn_readlane(pm, 63));
+                }
             }
             dmax[ch] = vmax(dmax[ch], dn);
             if (LOC) {   // jlast = 1 + last column whose cell ties or raises its row's running max
@@ -620,6 +633,10 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
         if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
+        if ((sp & SP_FQE) && tc) {   // this tile's share of column j into the per-column arrays (a record of the tile counts if it also beats the tiles above)
+            const int Rb = tc->first ? -32768 : load_uniform_i16(tc->fqR + j), Tb = tc->first ? -32768 : load_uniform_i16(tc->fqT + j);
+            if (last_lane) { tc->fqT[j] = (short)max(Tb, fq_rec >= Rb ? fq_rec : -32768); tc->fqR[j] = (short)max(Rb, fq_cm); }
+        }
         cells += height;
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {

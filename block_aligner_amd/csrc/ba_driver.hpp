@@ -942,6 +942,7 @@ struct Aligner {
         lds_sync();
     }
     __device__ __forceinline__ static int ckpt_load(const short* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }
+    __device__ __forceinline__ static short ckpt_load16(const short* p) { return __hip_atomic_load(p, BA_RLX_AGENT); }   // (past the L1: the wave reads back its own stores)
 
     // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done). The wait only
     // gives up when the traceback side as a whole has stopped making progress: no task claimed for ~2 s, scaled by the
@@ -1177,7 +1178,7 @@ struct Aligner {
 #pragma unroll
                 for (uint32_t t = 1; t < 16; t++)
                     corner_t[t] = t < ntiles ? uni((int)as_s(adds(splat((int)Dc[t * BIG_TILE - 1]), splat(off_add))).x) : 0;
-                const bool brk = !XDROP && (ri + rh > lenV);
+                const bool brk = !XDROP && !(sp & SP_FQE) && (ri + rh > lenV);
                 for (uint32_t t = 0; t < ntiles; t++) {
                     TileCtx tc;
                     tc.ch_base = (int)(t * (BIG_TILE / 128)); tc.nch_total = (int)(rh / 128); tc.first = t == 0; tc.last = t + 1 == ntiles;
@@ -1185,10 +1186,11 @@ struct Aligner {
 #pragma unroll
                     for (uint32_t u = 1; u < 16; u++) if (u == t) tc.corner0 = corner_t[u];
                     tc.topD = big_top; tc.topR = big_top + big_array_shorts(h_max_size); tc.break_armed = brk;
+                    tc.fqR = big_top + 2 * big_array_shorts(h_max_size); tc.fqT = big_top + 3 * big_array_shorts(h_max_size);
                     short* oD = tc.last ? Dr : big_top; short* oR = tc.last ? Rr : big_top + big_array_shorts(h_max_size);
                     Best part;
 #define BA_TILE1(PD) part = place_rect<(int)(BIG_TILE / 128), KIND, TRACE, XDROP, PD>(L, fc, seqV, seqC, lenV, lenC, ri + t * BIG_TILE, rj, rw, BIG_TILE, \
-                                   Dc + t * BIG_TILE, Cc + t * BIG_TILE, oD, oR, t == 0 ? corner : 0, rz, off_add, tout, cells, prof, 0u, nullptr, &pv, &tc)
+                                   Dc + t * BIG_TILE, Cc + t * BIG_TILE, oD, oR, t == 0 ? corner : 0, rz, off_add, tout, cells, prof, sp, nullptr, &pv, &tc)
                     if constexpr (KIND == KIND_PROFILE) { if (right) BA_TILE1(1); else BA_TILE1(2); } else BA_TILE1(0);
 #undef BA_TILE1
                     part.row += (int)(t * BIG_TILE);
@@ -1201,6 +1203,26 @@ struct Aligner {
                     }
                     if (take) cur = part;
                     lds_sync();
+                }
+                if (sp & SP_FQE) {
+                    // FREE_QUERY_END_GAPS (scan_block.rs:1189-1201) from the per-column arrays of the tiles: in the reference's order
+                    // (columns outer) a tracked vector of column j records j when its value ties or raises the maximum of everything
+                    // before it -- all earlier columns (A, starting at MIN = 0) and the cells above it in column j, which is what fqT[j]
+                    // was filtered by. M = the overall maximum; j = the last recording column.
+                    const short* fR = big_top + 2 * big_array_shorts(h_max_size); const short* fT = big_top + 3 * big_array_shorts(h_max_size);
+                    int A = 0, jbest = 0;
+                    for (uint32_t j0 = 0; j0 < rw; j0 += 64) {
+                        const uint32_t j = j0 + (uint32_t)lane_id();
+                        const bool in = j < rw;
+                        const int Rj = in ? (int)ckpt_load16(fR + j) : -32768, Tj = in ? (int)ckpt_load16(fT + j) : -32768;
+                        const int incl = wave_prefix_max(Rj);                                  // max of R over this chunk's columns up to and including j
+                        int excl = __builtin_amdgcn_update_dpp(-32768, incl, 0x138, 0xf, 0xf, false);   // ... up to j - 1 (wave_shr:1, lane 0: nothing)
+                        excl = max(excl, A);
+                        const unsigned long long hits = __ballot(in && Tj >= excl);
+                        if (hits) jbest = (int)(j0 + 63u - (uint32_t)__builtin_clzll(hits));
+                        A = max(A, __builtin_amdgcn_readlane(incl, 63));
+                    }
+                    fq.M = A; fq.j = jbest;
                 }
             }
             else if (fast) {

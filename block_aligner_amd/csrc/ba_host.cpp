@@ -35,6 +35,10 @@ BA_DECL_KIND(0) BA_DECL_KIND(1) BA_DECL_KIND(2) BA_DECL_KIND(3)
     extern "C" hipError_t ba_launch_big_k##K##_p32(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
     extern "C" hipError_t ba_occupancy_big_k##K##_p32(int, int, unsigned, int*);
 BA_DECL_BIG(0) BA_DECL_BIG(1) BA_DECL_BIG(2) BA_DECL_BIG(3)
+#define BA_DECL_BIGS(K)                                                                                                 \
+    extern "C" hipError_t ba_launch_bigs_k##K##_p32(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);   \
+    extern "C" hipError_t ba_occupancy_bigs_k##K##_p32(int, int, unsigned, int*);
+BA_DECL_BIGS(0) BA_DECL_BIGS(1) BA_DECL_BIGS(2) BA_DECL_BIGS(3)
 extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint64_t*, uint32_t*, uint32_t);
 extern "C" hipError_t ba_launch_cigar_offsets_and_compact(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint64_t*, uint32_t*,
                                                           unsigned long long*, unsigned long long, uint32_t);
@@ -75,8 +79,11 @@ extern "C" hipError_t ba_quad_grid_k3(int, int, unsigned*);
 typedef hipError_t (*QuadGridFn)(int, int, unsigned*);
 static const QuadGridFn g_quad_grid[4] = {ba_quad_grid_k0, ba_quad_grid_k1, ba_quad_grid_k2, ba_quad_grid_k3};
 static const QuadFn g_launch_quad[4] = {ba_launch_quad_k0, ba_launch_quad_k1, ba_launch_quad_k2, ba_launch_quad_k3};
-static const LaunchFn g_launch_big[4] = {ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32};
-static const OccFn g_occ_big[4] = {ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32};
+// [special modes?][kind]
+static const LaunchFn g_launch_big[2][4] = {{ba_launch_big_k0_p32, ba_launch_big_k1_p32, ba_launch_big_k2_p32, ba_launch_big_k3_p32},
+                                            {ba_launch_bigs_k0_p32, ba_launch_bigs_k1_p32, ba_launch_bigs_k2_p32, ba_launch_bigs_k3_p32}};
+static const OccFn g_occ_big[2][4] = {{ba_occupancy_big_k0_p32, ba_occupancy_big_k1_p32, ba_occupancy_big_k2_p32, ba_occupancy_big_k3_p32},
+                                      {ba_occupancy_bigs_k0_p32, ba_occupancy_bigs_k1_p32, ba_occupancy_bigs_k2_p32, ba_occupancy_bigs_k3_p32}};
 constexpr int BA_PCLASS_BIG = 5;
 static inline int special_of(uint32_t mode) { return (mode & (BA_LOCAL_START | BA_FREE_QUERY_START_GAPS | BA_FREE_QUERY_END_GAPS)) ? 1 : 0; }
 constexpr int BA_KIND_PROFILE_ = ba::KIND_PROFILE;   // batches whose "reference" is an AAProfile (sequence bytes: AA alphabet)
@@ -520,7 +527,6 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
-    if (pc == BA_PCLASS_BIG && special_of(mode)) return fail("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
     // (k_multi's traceback waves keep their records in their own wave's region: no extra space)
     b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
@@ -528,7 +534,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[kind] : (b->multi ? g_occ_m[kind][pc] : g_occ[special_of(mode)][kind][pc]);
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? g_occ_m[kind][pc] : g_occ[special_of(mode)][kind][pc]);
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
@@ -856,7 +862,7 @@ static int batch_launch(BaBatch* b) {
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->ev_l0) HIP_TRY(hipEventRecord(b->ev_l0, b->stream));   // (a re-run sub-batch: batch_retry re-uses ev0 for the merge)
-    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[b->kind] : (b->multi ? g_launch_m[b->kind][b->pclass] : g_launch[special_of(b->mode)][b->kind][b->pclass]);
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? g_launch_m[b->kind][b->pclass] : g_launch[special_of(b->mode)][b->kind][b->pclass]);
     if (b->quad && b->n <= b->cap_n) {
         // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
         // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a
@@ -1606,7 +1612,6 @@ static void handle_align(BlockImpl* h, int kind, const uint8_t* q_s, size_t q_le
     if ((mode & BA_FREE_QUERY_END_GAPS) && !(min_size > q_len)) die("Min block size must be larger than the query length for FREE_QUERY_END_GAPS!");   // scan_block.rs:860-862
     b->kind = kind; b->mode = mode; b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
     b->gap_open = g.open; b->gap_extend = g.extend; b->x_drop = x;
-    if (pc == BA_PCLASS_BIG && special_of(mode)) die("LOCAL_START / FREE_QUERY_*_GAPS are supported up to a max block size of 2048");
     b->lds = ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
     // ---- the upload: per-pair words + the two padded images (scan_block.rs:1798-1812), built in the handle's staging buffer
     const size_t pad = max_size + 16;

@@ -16,7 +16,10 @@
 
 #define BA_CAT_(a, b, c, d) a##b##c##d
 #define BA_CAT(a, b, c, d) BA_CAT_(a, b, c, d)
-#if BA_BIG   // blocks of 4096 .. 32768 cells (one class per kind; the special alignment modes stop at 2048)
+#if BA_BIG && BA_SPECIAL   // blocks of 4096 .. 32768 cells with LOCAL_START / FREE_QUERY_*_GAPS
+#define BA_LAUNCH BA_CAT(ba_launch_bigs_k, BA_KIND, _p, BA_PMAX)
+#define BA_OCC BA_CAT(ba_occupancy_bigs_k, BA_KIND, _p, BA_PMAX)
+#elif BA_BIG   // blocks of 4096 .. 32768 cells (one class per kind)
 #define BA_LAUNCH BA_CAT(ba_launch_big_k, BA_KIND, _p, BA_PMAX)
 #define BA_OCC BA_CAT(ba_occupancy_big_k, BA_KIND, _p, BA_PMAX)
 #elif BA_SPECIAL

@@ -110,7 +110,7 @@ struct BatchParams {
 // blocks of 4096 .. 32768 cells: borders in an L2-resident arena, rectangles filled in row tiles of BIG_TILE cells
 constexpr uint32_t BIG_TILE = 2048;
 BA_HD constexpr uint64_t big_array_shorts(uint32_t max_size) { return (uint64_t)max_size + 64; }
-BA_HD constexpr uint64_t big_wave_shorts(uint32_t max_size) { return 6 * big_array_shorts(max_size); }
+BA_HD constexpr uint64_t big_wave_shorts(uint32_t max_size) { return 8 * big_array_shorts(max_size); }   // 4 borders, 2 row hand-off arrays, 2 per-column arrays of the FREE_QUERY_END_GAPS bookkeeping
 
 constexpr uint32_t MQ_B_HOST = 128;   // k_multi: block size of a slot (ba_driver.hpp MQ_B)
 // k_multi: per wave and slot two state buffers and a record in the `big` arena (ba_multi.hpp)

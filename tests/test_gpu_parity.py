@@ -743,3 +743,21 @@ def test_fill_waves_walk_when_the_traceback_waves_are_missing(hip, oracle, devli
     monkeypatch.setenv("BA_SLOTS_PER_WAVE", "1" if size[0] == 32 else "6")
     pairs = synth.make_pairs(4000, (400, 1500), (30, 150), 60, synth.DNA, seed=77 + size[0])
     compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, ("trace", "x_drop"))
+
+
+@pytest.mark.parametrize("mode", [("trace", "local_start"), ("trace", "free_query_start_gaps"), ("trace", "free_query_end_gaps"), ("free_query_end_gaps",),
+                                  ("trace", "x_drop", "local_start"), ("trace", "free_query_end_gaps", "free_query_start_gaps")])
+@pytest.mark.parametrize("size", [(128, 4096), (2048, 16384)])
+def test_special_modes_in_the_tiled_block_class(hip, oracle, mode, size):
+    """LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS with blocks above 2048 cells (the reference takes any power of two
+    below 2^16 - 1 for every mode, scan_block.rs:855): rectangles filled in row tiles, the zero masks in the whole rectangle's layout,
+    the per-lane FREE_QUERY_END_GAPS bookkeeping put together from per-column arrays after the last tile."""
+    if "free_query_end_gaps" in mode:
+        pairs = _substring_pairs(8, 3 + size[0], qlen=(40, size[0] - 20), rlen=(15000, 30000), edits=(0, 30))
+    else:
+        # (LOCAL_START keeps a zero mask of 4 words per trace word: the reference's trace bound for a pair -- x 5 -- has to stay below the
+        # library's 2^30 words per pair, which at a maximum of 16384 cells means pairs of ~15 kbp)
+        lens = (25000, 40000) if size[1] == 4096 else (11000, 15000)
+        pairs = synth.make_pairs(5, lens, (1500, 3000), 300, synth.DNA, seed=size[1] + len(mode), indels=4, indel_len=(800, 5000), workers=4)
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 400, mode)
+    assert res["cells"].max() > 0
