@@ -169,6 +169,139 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
     return (uint32_t)(out_hi - wp);
 }
 
+// ------------------------------------------------------------------ one path walked by a whole wave
+// The lane walks above advance one path at ~0.55 us per cell whichever way they are used (a chain of ~200 dependent instructions and one
+// memory round trip per rectangle), so a batch ends one longest-path walk after its last fill: 10 ms for the 8881-residue pair of the
+// protein set. Here the wave's 64 lanes work on ONE path: they fetch the next 64 rectangle records (one per lane, kept in registers)
+// and copy those rectangles' trace words into the wave's LDS region with coalesced loads, as many as fit; the walk itself -- same
+// rules as traceback() above, scan_block.rs:1576-1670 -- then runs on wave-uniform values (scalar registers, scalar branches): a
+// rectangle's record by v_readlane, the cell's trace word by one broadcast LDS read, the move table (OP_LUT, scan_block.rs:1532-1558)
+// and 256-byte windows of both sequences in registers read by v_readlane, finished runs collected in a register (v_writelane) and
+// stored 64 at a time. A rectangle larger than the LDS region is walked out of global memory. CIGAR_EQ is the only mode bit taken:
+// the special modes keep traceback().
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t x, uint32_t lane) {
+    uint32_t s = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)s, d, 64);
+        s += lane >= (uint32_t)d ? o : 0u;
+    }
+    return s - x;
+}
+template <bool L2OK>
+__device__ __forceinline__ uint32_t walk_wave(const BlockRec* __restrict__ blocks, uint32_t nblocks_in, const uint32_t* __restrict__ trace,
+                                              uint32_t i_in, uint32_t j_in, const uint8_t* __restrict__ q, const uint8_t* __restrict__ r, bool eq,
+                                              uint32_t* __restrict__ out, uint64_t out_lo, uint64_t out_hi, uint32_t* status,
+                                              uint32_t* __restrict__ lds, uint32_t budget) {
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t lutv0, lutv1;
+    {
+        const Move a = tb_lut(false, lane & 3, (lane >> 2) & 1, (lane >> 4) & 3), b = tb_lut(true, lane & 3, (lane >> 2) & 1, (lane >> 4) & 3);
+        lutv0 = a.op | (a.di << 3) | (a.dj << 4) | (a.next << 5);
+        lutv1 = b.op | (b.di << 3) | (b.dj << 4) | (b.next << 5);
+    }
+    uint32_t i = (uint32_t)uni((int)i_in), j = (uint32_t)uni((int)j_in), bidx = (uint32_t)uni((int)nblocks_in);
+    uint32_t table = 0, run_op = 0, run_len = 0, nrun = 0, runbuf = 0, st = 0;
+    uint64_t wp = out_hi;
+    uint32_t qw0 = 0, rw0 = 0, qwin = 0, rwin = 0;
+    auto load_q = [&]() { qw0 = i >= 252u ? (i - 252u) & ~3u : 0u; const uint32_t a = qw0 + 4u * lane; qwin = a <= i ? *(const uint32_t*)(q + a) : 0u; };
+    auto load_r = [&]() { rw0 = j >= 252u ? (j - 252u) & ~3u : 0u; const uint32_t a = rw0 + 4u * lane; rwin = a <= j ? *(const uint32_t*)(r + a) : 0u; };
+    if (eq) { load_q(); load_r(); }
+    auto flush = [&]() {
+        if (lane < nrun) out[wp - 1u - lane] = runbuf;
+        wp -= nrun; nrun = 0;
+    };
+    auto emit = [&]() -> bool {   // false: the runs do not fit
+        if (!run_len) return true;
+        if (wp - nrun == out_lo) return false;
+        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(runbuf) : "s"(__builtin_amdgcn_readfirstlane((int)((run_len << 4) | run_op))), "s"(__builtin_amdgcn_readfirstlane((int)nrun)) : "m0");
+        if (++nrun == 64u) flush();
+        return true;
+    };
+    bool ok = true;
+    while (ok && (i > 0 || j > 0)) {
+        if (bidx == 0) { st = ST_TRACEBACK_LOST; ok = false; break; }
+        // ---- stage: the next records, one per lane (lane k: record bidx - 1 - k), and their trace words
+        const uint32_t nvalid = min(bidx, 64u);
+        uint4 rec = uint4{0, 0, 0, 0};
+        if (lane < nvalid) rec = *(const uint4*)(blocks + (bidx - 1u - lane));
+        const bool untr = rec.w & 0x40000000u;
+        const uint32_t words = untr ? 0u : (rec.z & 0xffffu) * (rec.z >> 16) / 8u;
+        const uint32_t tb = rec.w & 0x3fffffffu;
+        uint32_t toff = wave_excl_sum(lane < nvalid ? words : 0u, lane);
+        const uint32_t nfit = (uint32_t)__popcll(__ballot(lane < nvalid && toff + words <= budget));
+        // (a stack's rectangles are stacked: record k's words end where record k - 1's begin -- then one flat copy)
+        const uint32_t tb_up = (uint32_t)__shfl_up((int)tb, 1, 64);
+        const bool flat = nfit > 1 && !__any(lane > 0 && lane < nfit && tb + words != tb_up);
+        if (nfit > 0) {
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(toff + words), (int)(nfit - 1u));
+            if (flat) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)(nfit - 1u));
+                for (uint32_t x = lane; x < total; x += 64u) lds[x] = trace[lo + x];
+                toff = tb - lo;
+            } else {
+                for (uint32_t k = 0; k < nfit; k++) {
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)k), sz = (uint32_t)__builtin_amdgcn_readlane((int)words, (int)k);
+                    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)toff, (int)k);
+                    for (uint32_t x = lane; x < sz; x += 64u) lds[off + x] = trace[base + x];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        const bool direct = nfit == 0;                 // the top rectangle alone exceeds the region: walk it out of global memory
+        const uint32_t ntake = direct ? 1u : nfit;
+        auto walk_rects = [&](auto direct_c) {
+        constexpr bool DIRECT = decltype(direct_c)::value;
+        uint32_t cur = 0;
+        while (cur < ntake && ok && (i > 0 || j > 0)) {
+            const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, (int)cur), bj = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, (int)cur);
+            const uint32_t bi = rx & 0x7fffffffu;
+            if (!(i >= bi && j >= bj)) { cur++; continue; }
+            const uint32_t rz = (uint32_t)__builtin_amdgcn_readlane((int)rec.z, (int)cur), rw = (uint32_t)__builtin_amdgcn_readlane((int)rec.w, (int)cur);
+            if (rw & 0x40000000u) { st = ST_TRACEBACK_LOST; ok = false; break; }   // a speculative grow that was never materialised: must not be on a path
+            const uint32_t off = DIRECT ? (rw & 0x3fffffffu) : (uint32_t)__builtin_amdgcn_readlane((int)toff, (int)cur);
+            const bool right = rw >> 31, l2 = L2OK && (rx >> 31);
+            const uint32_t Hv = right ? (rz & 0xffffu) : (rz >> 16);
+            const uint32_t nch = Hv > 128u ? Hv / 128u : 1u, nl = Hv > 128u ? 64u : Hv / 2u;
+            const uint32_t lutr = right ? lutv1 : lutv0;
+            while (i >= bi && j >= bj && (i > 0 || j > 0)) {
+                const uint32_t ci = i - bi, cj = j - bj;
+                const uint32_t v = right ? ci : cj, w = right ? cj : ci;
+                uint32_t widx, sh;
+                if (l2) { widx = (v >> 3) * 8u + (w >> 1) * 2u + ((v >> 2) & 1u); sh = (v & 3u) * 8u + (w & 1u) * 4u; }
+                else { widx = ((w >> 2) * nch + (v >> 7)) * nl + ((v & 127u) >> 1); sh = (v & 1u) * 16u + (w & 3u) * 4u; }
+                uint32_t word;
+                if constexpr (DIRECT) word = (uint32_t)uni((int)trace[off + widx]); else word = (uint32_t)uni((int)lds[off + widx]);
+                const uint32_t nib = ((word >> sh) ^ 15u) & 15u;                                // all four bits are stored as "differs"
+                table = tb_resolve(right, table, nib);
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)lutr, (int)((table << 4) | nib));
+                uint32_t op = m & 7u;
+                const uint32_t di = (m >> 3) & 1u, dj = (m >> 4) & 1u;
+                if (eq && op == 1u) {
+                    if (i < qw0) load_q();
+                    if (j < rw0) load_r();
+                    const uint32_t qd = (uint32_t)__builtin_amdgcn_readlane((int)qwin, (int)((i - qw0) >> 2)), rd = (uint32_t)__builtin_amdgcn_readlane((int)rwin, (int)((j - rw0) >> 2));
+                    op = ((qd >> ((i & 3u) * 8u)) & 255u) == ((rd >> ((j & 3u) * 8u)) & 255u) ? 2u : 3u;
+                }
+                if (di > i || dj > j) { st = ST_TRACEBACK_LOST; ok = false; break; }            // would leave the matrix: corrupt trace
+                i -= di; j -= dj; table = tb_next(right, m >> 5, v);
+                if (op == run_op) run_len++;
+                else {
+                    if (!emit()) { st = ST_CIGAR_OVERFLOW; ok = false; break; }
+                    run_op = op; run_len = 1;
+                }
+            }
+        }
+        };
+        if (direct) walk_rects(std::true_type{}); else walk_rects(std::false_type{});
+        bidx -= ntake;
+    }
+    if (ok && !emit()) { st = ST_CIGAR_OVERFLOW; ok = false; }
+    if (!ok) { *status |= st; return 0; }
+    flush();
+    return (uint32_t)(out_hi - wp);
+}
+
 // ------------------------------------------------------------------ traceback lanes (batch path)
 // In a TRACE batch the fill waves do not walk their own tracebacks: a walk is ~(|q|+|r|) dependent steps and would
 // idle 63 lanes for as long as the fill itself takes. Finished trace stacks are handed to traceback waves of the same
@@ -610,6 +743,36 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     // small-block batches walk in two launches: the pairs k_quad finished (cont_mode 1: flag 0) while the per-pair kernel is still
     // at work on the others, then those (cont_mode 2). 0: every pair.
     const uint32_t filter = bp.cont_mode;
+    // The batch order is longest first and the launch ends with its longest walk: the first bp.walk_wave_n paths (ba_host.cpp plan_walks)
+    // go one to a wave (walk_wave), one at a time from their own counter (work_counter[1]); the lanes start behind them. Few: such a walk
+    // is scalar code, and a CU has one scalar unit for all its waves.
+    const uint32_t n_wave = (bp.flags & (F_LOCAL | F_FQS)) ? 0u : min(bp.walk_wave_n, bp.n);
+    if (n_wave) {
+        for (;;) {
+            uint32_t p = 0;
+            if (is_lane(0)) p = atomicAdd(bp.work_counter + 1, 1u);
+            p = (uint32_t)uni((int)p);
+            if (p >= n_wave) break;
+            bool mine = true;
+            if (filter) mine = (bp.cont_in_flag[p] == 0) == (filter == 1);
+            SlotInfo si{0, 0, 0, 0};
+            if (mine) { si = bp.slot_info[p]; mine = si.nblocks != ~0u; }
+            if (!mine) continue;
+            uint32_t st = bp.status[p], ncig = 0;
+            if (!st && !(bp.flags & 0x200u))
+                ncig = walk_wave<false>(bp.blocks + bp.blocks_off[p], si.nblocks, bp.trace_arena + bp.trace_off[p], si.end_i, si.end_j, bp.pool + bp.q_off[p],
+                                        bp.pool + bp.r_off[p], eq != 0, bp.cig_ops, bp.cig_off[p], bp.cig_off[p + 1], &st, (uint32_t*)tb_lds, TB_LDS_BYTES / 4u);
+            if (is_lane(0)) { bp.cig_len[p] = st ? 0u : ncig; if (st) bp.status[p] = st; }
+        }
+        lds_sync();
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint32_t idx = (uint32_t)lane_id() + 64u * e;
+            const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);
+            lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
+        }
+        lds_sync();
+    }
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the batch order: 64 pairs per atomic (a returning atomic is a full memory
                                       // round trip that every lane of the wave waits for: one per finished lane would double the walk time)
     for (;;) {
@@ -617,7 +780,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             if (w_next == w_end) {
                 uint32_t base = 0;
                 if (is_lane(0)) base = atomicAdd(bp.work_counter, 64u);
-                base = (uint32_t)uni((int)base);
+                base = (uint32_t)uni((int)base) + n_wave;
                 if (base >= bp.n) { more = false; base = 0; w_next = w_end = 0; }
                 else { w_next = base; w_end = min(base + 64u, bp.n); }
             }
@@ -1413,10 +1576,19 @@ struct Aligner {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            if (is_lane(0)) {
+            if constexpr (SPECIAL) {
+                if (is_lane(0)) {
+                    uint32_t st = 0;
+                    ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, h_flags, coldp()->cig_ops, coldp()->cig_off[pair], coldp()->cig_off[pair + 1], &st);
+                    status |= st;
+                }
+            } else {
+                // the whole wave on this one path, out of the border arrays' LDS space (the pair is finished: nothing in it is live)
                 uint32_t st = 0;
-                ncig = traceback(blocks, nblocks, trace, ri, rj, q, r, SPECIAL ? h_flags : (h_flags & F_CIGAR_EQ), coldp()->cig_ops,
-                                 coldp()->cig_off[pair], coldp()->cig_off[pair + 1], &st);
+                lds_sync();
+                ncig = walk_wave<MULTI>(blocks, nblocks, trace, ri, rj, q, r, (h_flags & F_CIGAR_EQ) != 0, coldp()->cig_ops, coldp()->cig_off[pair],
+                                        coldp()->cig_off[pair + 1], &st, (uint32_t*)L.D_col, lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u));
+                lds_sync();
                 status |= st;
             }
         }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -245,6 +246,7 @@ struct BaBatch {
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
     uint32_t mq_drain = 0;      // k_multi: pairs at the end of the batch that are run one at a time (BatchParams::mq_drain)
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
+    uint32_t walk_wave_n = 0;   // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (plan_walks)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
     DevBuf cq_queue, cq_ctrl;   // the queue those pairs travel through (ba_params.h)
@@ -273,6 +275,7 @@ struct BaBatch {
         bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !dev_env("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
         bp.cig_off = cig_off.as<uint64_t>(); bp.cig_start = nullptr; bp.cig_len = cig_len.as<uint32_t>();
         bp.cells = cells.as<unsigned long long>(); bp.status = status.as<uint32_t>(); bp.nblocks_out = nblocks.as<uint32_t>(); bp.slot_out = pair_slot.as<uint32_t>(); bp.trace_words_out = trace_words.as<uint32_t>();
+        bp.walk_wave_n = walk_wave_n;
         bp.trace_arena = trace.as<uint32_t>(); bp.trace_stride = trace_stride;
         bp.blocks = blocks.as<BlockRec>(); bp.blocks_stride = blocks_stride;
         bp.trace_off = pipe ? trace_off.as<uint64_t>() : nullptr; bp.blocks_off = pipe ? blocks_off.as<uint64_t>() : nullptr;
@@ -676,6 +679,7 @@ static int upload_images(BaBatch* b, const Packed& P, size_t n) {
 }
 
 static int upload_dev_of(BaBatch* b);
+static void plan_walks(BaBatch* b, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rl);
 // `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1); for kind PROFILE the reference comes from
 // `getp(p)` instead.
 template <class GetSeq, class GetProfile = NoProfiles>
@@ -713,6 +717,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     std::vector<uint64_t>& cig_off = P.cig_off;
     const uint64_t total = P.total, maxlen2 = P.maxlen2, cig_total = P.cig_total;
     b->h_q_off = qo; b->h_r_off = ro; b->h_order = P.order;
+    plan_walks(b.get(), ql, rl);
     b->cap_n = n; b->cap_pool = total; b->cap_cig = cig_total; b->cap_maxlen2 = maxlen2;
     b->pool_bytes = total;
 
@@ -833,6 +838,7 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     HIP_TRY(hipMemset(b->cig_len.p, 0, n * 4));
     HIP_TRY(hipMemset(b->status.p, 0, n * 4));
     b->n = (uint32_t)n; b->h_q_off = P.qo; b->h_r_off = P.ro; b->h_order = P.order; b->pool_bytes = P.total;
+    plan_walks(b, P.ql, P.rl);
     b->cig_total = (b->mode & BA_TRACE) ? P.cig_total : 0;
     b->ran = false;
     return upload_dev_of(b);
@@ -840,12 +846,28 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
 
 // Enqueue one pass over the batch on its stream and return; batch_wait collects it. (Two batches on two streams
 // overlap; with ba_batch_reload the host packs the next set while the device aligns the current one.)
+// k_walk ends with its longest walk. A lane walks at ~0.55 us per cell, a whole wave on one path (walk_wave) several times faster but one
+// path at a time and in scalar code (one scalar unit per CU: a few such walks per CU at most): the leading pairs of the batch order with at
+// least 1 / BA_WALK_WAVE_FRAC of the longest pair's |q| + |r| -- at most BA_WALK_WAVE_MAX of them -- go one to a wave, the others one to a
+// lane beside them, and the launch's makespan becomes the longest path at the wave's pace.
+static void plan_walks(BaBatch* b, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rl) {
+    uint32_t frac = 3, kmax = 1024;
+    if (const char* e = dev_env("BA_WALK_WAVE_FRAC")) frac = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = dev_env("BA_WALK_WAVE_MAX")) kmax = (uint32_t)std::max(0, atoi(e));
+    const size_t n = ql.size();
+    uint32_t longest = 0;
+    for (size_t p = 0; p < n; p++) longest = std::max(longest, ql[p] + rl[p]);
+    const uint32_t from = std::max(longest / frac, 512u);
+    size_t cnt = 0;
+    while (cnt < n && cnt < kmax && ql[cnt] + rl[cnt] >= from) cnt++;   // (device order: longest first)
+    b->walk_wave_n = (uint32_t)cnt;
+}
 static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves x 64 walking lanes each)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) return 1;
     uint32_t per_cu = 8;
     if (const char* env = dev_env("BA_WALK_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = (uint32_t)v; }
-    return std::min((b->n + 255u) / 256u, (uint32_t)prop.multiProcessorCount * per_cu);
+    return std::min((b->n + 255u) / 256u + (b->walk_wave_n + 3u) / 4u, (uint32_t)prop.multiProcessorCount * per_cu);
 }
 static int batch_launch(BaBatch* b) {
     if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");

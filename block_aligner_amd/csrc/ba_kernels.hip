@@ -126,13 +126,17 @@ extern "C" hipError_t BA_CAT(ba_quad_grid_k, BA_KIND, , )(int trace, int xdrop, 
 // Traceback from an arbitrary end cell over slot 0's trace (the per-handle API: block_cigar_* after block_align_*).
 __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {
     using namespace ba;
-    if (lane_id() != 0) return;
-    uint32_t st = 0;
-    const uint32_t n = traceback(bp.blocks + (uint64_t)bp.tb_slot * bp.blocks_stride, bp.tb_nblocks,
-                                 bp.trace_arena + (uint64_t)bp.tb_slot * bp.trace_stride, bp.tb_i, bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0],
-                                 bp.flags, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
-    bp.cig_len[0] = n;
-    bp.status[0] = st;
+    __shared__ uint32_t words[4096];
+    uint32_t st = 0, n = 0;
+    if (bp.flags & (F_LOCAL | F_FQS)) {
+        if (lane_id() == 0)
+            n = traceback(bp.blocks + (uint64_t)bp.tb_slot * bp.blocks_stride, bp.tb_nblocks, bp.trace_arena + (uint64_t)bp.tb_slot * bp.trace_stride, bp.tb_i,
+                          bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0], bp.flags, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st);
+    } else
+        n = walk_wave<false>(bp.blocks + (uint64_t)bp.tb_slot * bp.blocks_stride, bp.tb_nblocks, bp.trace_arena + (uint64_t)bp.tb_slot * bp.trace_stride, bp.tb_i,
+                             bp.tb_j, bp.pool + bp.q_off[0], bp.pool + bp.r_off[0], (bp.flags & F_CIGAR_EQ) != 0, bp.cig_ops, bp.cig_off[0], bp.cig_off[1], &st,
+                             words, 4096u);
+    if (lane_id() == 0) { bp.cig_len[0] = n; bp.status[0] = st; }
 }
 
 // Pair-slot batches: all tracebacks of the batch, one pair per lane (ba_driver.hpp traceback_all).

@@ -101,6 +101,7 @@ struct BatchParams {
     uint32_t ckpt_wave0;         // this launch's first wave in the checkpoint arena (two per-pair kernels of one batch run side by side)
     uint32_t mq_drain;           // k_multi: the last mq_drain pairs of the batch are not taken into slots (four pairs per wave, each four times as long in
                                  // flight) but one at a time by waves whose slots have emptied, and run on all lanes to their end: a finer ragged end
+    uint32_t walk_wave_n;        // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (walk_wave), the others one to a lane
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;
