@@ -724,6 +724,44 @@ __device__ __forceinline__ bool traceback_help_one(const BatchParams& bp, uint32
     return true;
 }
 
+// An emptied fill wave at the end of a batch: it serves hand-offs like a traceback lane (a ticket, then the entry), but with all of
+// its lanes on one path at a time (walk_wave) -- the batch ends one walk after its last fill, and this walk is the short one.
+template <bool L2OK>
+__device__ __forceinline__ void traceback_helper_wave(const BatchParams& bp, uint32_t* lds, uint32_t budget) {
+    uint32_t* head = bp.tb_ctrl + 32;
+    for (;;) {
+        uint32_t claimed = 0;
+        if (is_lane(0)) claimed = __hip_atomic_fetch_add(head, 1u, BA_RLX_AGENT);
+        claimed = (uint32_t)uni((int)claimed);
+        if (claimed >= bp.n) break;
+        uint32_t entry = 0;
+        for (;;) {
+            if (is_lane(0)) entry = __hip_atomic_load(bp.tb_queue + (claimed & bp.tb_qmask), BA_RLX_AGENT);
+            entry = (uint32_t)uni((int)entry);
+            if (entry) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (is_lane(0)) __hip_atomic_store(bp.tb_queue + (claimed & bp.tb_qmask), 0u, BA_RLX_AGENT);
+        if (entry & 0x80000000u) { if (is_lane(0)) bp.cig_len[entry & 0x7fffffffu] = 0; continue; }   // a pair that produced no trace stack
+        const uint32_t slot = entry - 1;
+        const SlotInfo si = bp.slot_info[slot];
+        const uint32_t pair = (uint32_t)uni((int)si.pair);
+        uint32_t st = bp.status[pair], ncig = 0;
+        lds_sync();
+        if (!st && !(bp.flags & 0x200u))
+            ncig = walk_wave<L2OK>(bp.blocks + (uint64_t)slot * bp.blocks_stride, si.nblocks, bp.trace_arena + (uint64_t)slot * bp.trace_stride, si.end_i, si.end_j,
+                                   bp.pool + bp.q_off[pair], bp.pool + bp.r_off[pair], (bp.flags & F_CIGAR_EQ) != 0, bp.cig_ops, bp.cig_off[pair], bp.cig_off[pair + 1],
+                                   &st, lds, budget);
+        lds_sync();
+        if (is_lane(0)) {
+            bp.cig_len[pair] = st ? 0u : ncig;
+            if (st) bp.status[pair] = st;
+            __hip_atomic_store(bp.slot_free + slot, 1u, BA_RLX_AGENT);   // the arena may be reused
+        }
+    }
+}
+
 // Pair-slot batches (every pair's trace stack stays in its own region until the batch ends): the tracebacks of the whole
 // batch after its fill kernels, one pair per LANE, all 64 lanes of every wave walking (tb_step). Lanes that finish take the
 // next pairs of the batch order (longest first, so the lanes of a wave walk paths of similar length) with one atomic per wave.

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
         if (!(bp.flags & 0x800u))   // (development switch: as if the traceback waves were never resident)
         traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 64u, true);   // (records in this wave's own region)
 #ifdef BA_TIMING
-        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        if (bp.prof && is_lane(0)) atomicMax(bp.prof + 42, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
         return;
     }
@@ -598,9 +598,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     if (batch_traceback) {
         lds_sync();
 #ifndef MQ_HELPER_LANES
-#define MQ_HELPER_LANES 4u   // (the batch's last walks: 1 -> 4 lanes per emptied fill wave +1.5 % at config 3)
+#define MQ_HELPER_LANES 0u   // 0: the emptied wave walks one path at a time with all its lanes (walk_wave); k > 0: k paths, one per lane (1 -> 4 lanes: +1.5 % at config 3; 4 lanes -> the whole wave: +3 %)
 #endif
+#if MQ_HELPER_LANES == 0
+        traceback_helper_wave<true>(bp, (uint32_t*)base, 2048u);
+#else
         traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, MQ_HELPER_LANES, false);
+#endif
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timers from a -DBA_TIMING build (make -C block_aligner_amd/csrc EXTRA=-DBA_TIMING OBJ=_build_t LIB=../lib/libblock_aligner_hip_timing.so).
+"""Phase timers from a -DBA_TIMING build (make -C block_aligner_amd/csrc EXTRA=-DBA_TIMING OBJ=_build_t LIB=../lib/libblock_aligner_hip_timing.so DEVLIB=../lib/libblock_aligner_hip_timing_dev.so -- without DEVLIB= the development library is overwritten with a timing build).
 usage: gpu_timing.py <pairs> <trace 0|1> [max_block]"""
 import sys, os, ctypes as C
 import numpy as np
@@ -32,6 +32,7 @@ if prof[26]:
 if prof[43]:
     t0, tf, tw = float(prof[43]), float(prof[40]), float(prof[41])
     print(f"wall clock (100 MHz counter): last fill wave done at {(tf-t0)/1e5:.2f} ms, last traceback wave done at {(tw-t0)/1e5:.2f} ms after launch start")
+    if prof[42]: print(f"  (k_multi: the last dedicated traceback wave done at {(float(prof[42])-t0)/1e5:.2f} ms, the last helper at {(tw-t0)/1e5:.2f} ms)")
 if prof[55]:
     w = float(prof[55])
     print(f"k_multi fill waves={w:.0f}: solo ticks/wave={prof[50]/w:.0f} (episodes {prof[53]/w:.1f}, of which waiting for a trace slot {prof[52]/w:.0f}) step-loop ticks/wave={prof[51]/w:.0f} (steps {prof[54]/w:.0f}, {float(prof[51])/max(float(prof[54]),1):.1f} ticks/step)")
