@@ -74,6 +74,9 @@ extern "C" {
     pub fn ba_batch_wait(batch: *mut c_void, kernel_ms: *mut f32) -> i32;
     pub fn ba_batch_results(batch: *mut c_void, score: *mut i32, query_idx: *mut u32, reference_idx: *mut u32, cells: *mut u64, cigar_len: *mut u32, status: *mut u32) -> i32;
     pub fn ba_batch_cigars(batch: *mut c_void, runs: *mut u32, capacity: u64) -> i32;
+    pub fn ba_batch_compact_cigars(batch: *mut c_void, pinned_out: *mut u32, pinned_capacity: u64) -> i32;
+    pub fn ba_host_alloc(bytes: u64) -> *mut c_void;
+    pub fn ba_host_free(p: *mut c_void);
     pub fn ba_batch_surviving_cells(batch: *mut c_void, cells: *mut u64) -> i32;
     pub fn ba_batch_destroy(batch: *mut c_void);
     // Block::align_exp / align_profile_exp over a batch (scan_block.rs:884-902, 974-992): reached_min[p] = 0 where the crate returns None
@@ -122,6 +125,16 @@ impl HipBatch {
     pub fn run(&mut self) -> Result<f32, String> {
         let mut ms = 0f32;
         if unsafe { ba_batch_run(self.h, &mut ms) } != 0 { Err(last_error()) } else { Ok(ms) }
+    }
+    /// Asynchronous halves of `run` (two `HipBatch` objects alive: reload and launch one while the other runs).
+    pub fn launch(&mut self) -> Result<(), String> { if unsafe { ba_batch_launch(self.h) } != 0 { Err(last_error()) } else { Ok(()) } }
+    pub fn wait(&mut self) -> Result<f32, String> {
+        let mut ms = 0f32;
+        if unsafe { ba_batch_wait(self.h, &mut ms) } != 0 { Err(last_error()) } else { Ok(ms) }
+    }
+    /// Between `launch` and `wait`: gather the CIGAR runs on the device behind the alignment kernels (`cigars` is then one copy).
+    pub fn gather_cigars(&mut self) -> Result<(), String> {
+        if unsafe { ba_batch_compact_cigars(self.h, std::ptr::null_mut(), 0) } != 0 { Err(last_error()) } else { Ok(()) }
     }
     pub fn results(&self) -> Result<Vec<AlignResult>, String> {
         let (mut s, mut qi, mut ri, mut st) = (vec![0i32; self.n], vec![0u32; self.n], vec![0u32; self.n], vec![0u32; self.n]);
