@@ -140,3 +140,47 @@ def test_align_padded_images_by_pointer(hip, oracle):
     ref = oracle.align_profile(aq, prof, (32, 64), 0, ("trace",))
     assert (res.score, res.query_idx, res.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
     L.block_free_generic(blk)
+
+
+@pytest.mark.parametrize("size", [(32, 256), (128, 4096)])
+def test_handle_cigars_from_the_end_and_from_interior_cells(hip, oracle, size):
+    """block_cigar_* walks one path with a whole wave (ba_driver.hpp walk_wave): rectangle records 64 at a time, trace words staged
+    in LDS -- or, for rectangles larger than the LDS region (a grow to 4096 cells), read from global memory. The CIGAR from the
+    end cell equals the oracle's; from any other cell of the computed region it must still be a valid path to the origin
+    (Trace::cigar takes any cell, scan_block.rs:1469-1480) that consumes exactly (i, j)."""
+    rng = np.random.default_rng(size[1])
+    ps = synth.make_pairs(1, (5000, 5001), (300, 301), 200, synth.DNA, seed=size[1], indels=2, indel_len=(600, 900))
+    qb, rb = ps.query(0), ps.reference(0)
+    m = S.NucMatrix.new_simple(2, -3)
+    pq = hip.PaddedBytes.from_bytes(qb, size[1], S.NucMatrix); pr = hip.PaddedBytes.from_bytes(rb, size[1], S.NucMatrix)
+    a = hip.Block(len(qb), len(rb), size[1], trace=True)
+    a.align(pq, pr, m, S.Gaps(-5, -1), size, 0)
+    res = a.res()
+    ref = oracle.align(m, qb, rb, (-5, -1), size, 0, ("trace",), cigar_eq=True)
+    assert (res.score, res.query_idx, res.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
+    cg = hip.Cigar(res.query_idx, res.reference_idx)
+    a.trace().cigar_eq(pq, pr, res.query_idx, res.reference_idx, cg)
+    assert str(cg) == ref["cigar"]
+    if size[1] == 4096:
+        assert max(h for _, _, w, h in a.trace().blocks()) >= 2048      # the long indels really grew the block
+    # interior cells of the path itself: every prefix of the alignment is again a path from that cell
+    step = {"M": (1, 1), "=": (1, 1), "X": (1, 1), "I": (1, 0), "D": (0, 1)}
+
+    def consumed(c):
+        i = j = 0
+        ends = []
+        for op, ln in c.to_vec():
+            if not op:
+                continue
+            di, dj = step[hip.OP_CHARS[op]]
+            i += di * ln; j += dj * ln
+            ends.append((i, j))
+        return ends
+
+    ends = consumed(cg)
+    assert ends[-1] == (res.query_idx, res.reference_idx)
+    for (ci, cj) in ends[len(ends) // 3:: max(1, len(ends) // 7)]:
+        part = hip.Cigar(ci, cj)
+        a.trace().cigar_eq(pq, pr, ci, cj, part)
+        assert consumed(part)[-1] == (ci, cj)
+        assert str(cg).startswith(str(part))      # the path below a cell of the path is the path's own prefix
