@@ -558,7 +558,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
 // hand-offs are left to these late helpers, one lane per wave on a SIMD that has nothing else left to do (the
 // dedicated waves stop claiming tickets once the ticket counter reaches that reserve).
 template <int LB = (int)TB_LANE_BYTES>
-__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds, uint32_t nlanes, bool dedicated) {
+__device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds, uint32_t nlanes, bool dedicated, int prio = -1) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
     int phase = (uint32_t)lane_id() < nlanes ? IDLE : RETIRED;
     uint32_t claimed = 0, pend = 0;
@@ -581,7 +581,7 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
 #ifndef BA_TB_PRIO
 #define BA_TB_PRIO 3
 #endif
-    __builtin_amdgcn_s_setprio(BA_TB_PRIO);
+    if (prio == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(BA_TB_PRIO);   // (k_multi: below its solo mode's priority, ten trace slots per wave give the walks slack: +0.8 %)
 #ifdef BA_TIMING
     unsigned long long c_sec[3] = {};
     unsigned long long c_iters = 0, c_walk_lanes = 0, c_walk_iters = 0, c_poll_iters = 0, c_walk_ticks = 0, c_t0 = __builtin_amdgcn_s_memtime();
