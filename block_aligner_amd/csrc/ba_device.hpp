@@ -756,11 +756,20 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
             key[c8][k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
         }
     }
-    const bool break_armed = !XDROP && (start_i + height > lenV);
-    int cvec = (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
+    // (scan_block.rs:1216-1224: a column at or beyond the end of the column sequence is the last one computed when the rectangle
+    // reaches below the vector sequence's end -- known before the loop)
+    if (!XDROP && start_i + height > lenV) width = min(width, (lenC > start_j ? lenC - start_j : 0u) + 1u);
+    // Chunks in a skewed order: iteration t takes chunk c8 through column t - c8. A chunk needs from the chunk above it the R carry of
+    // the same column and the last D of the previous column -- both produced one iteration earlier -- so the NC8 chunk computations of
+    // an iteration are independent of each other and their dependent chains (in-lane chain, 64-lane scan) interleave; in column
+    // order chunk c8 + 1 waits for chunk c8's scan. Same operations on the same values.
+    // Column bytes: a window of 16 (lanes 0 .. 15), the 8 columns around the leading chunk's next column and the 8 before them.
+    auto load_cols = [&](int base) { const int col = max(base + (lane & 15), 0); return (int)seqC[start_j + (uint32_t)col]; };
+    int cbase = -8;
+    int cvec = load_cols(cbase);
     int sc_next[NC8][4];
     {
-        const int cb0 = __builtin_amdgcn_readlane(cvec, 0);
+        const int cb0 = __builtin_amdgcn_readlane(cvec, 8);   // column 0
 #pragma unroll
         for (int c8 = 0; c8 < NC8; c8++)
 #pragma unroll
@@ -768,33 +777,32 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
     }
     const bool last_lane = is_lane(63);
     const uint32_t tw_lane = (uint32_t)((lane >> 4) * 64 + (lane & 15) * 4);   // this lane's four words inside a 512-cell chunk of one column group
-    int corner_cur = corner;
-    for (uint32_t j = 0; j < width; j++) {
-        int sc[NC8][4];
+    int up_cap[NC8], carry_cap[NC8];   // chunk c8's last D before / last R after its column of the previous iteration: for chunk c8 + 1
 #pragma unroll
-        for (int c8 = 0; c8 < NC8; c8++)
+    for (int c8 = 0; c8 < NC8; c8++) { up_cap[c8] = 0; carry_cap[c8] = 0; }
+    const uint32_t iters = width + (uint32_t)NC8 - 1u;
+    for (uint32_t t = 0; t < iters; t++) {
+        if (((t + 1) & 7) == 0) { cbase = (int)(t + 1) - 8; cvec = load_cols(cbase); }   // (t + 1 - c8 >= cbase for every chunk: NC8 <= 4)
 #pragma unroll
-            for (int k = 0; k < 4; k++) sc[c8][k] = sc_next[c8][k];
-        // scores of the next column are fetched while this one is computed
-        if (((j + 1) & 7) == 0 && j + 1 < width) cvec = (int)seqC[start_j + j + 1 + (lane & 7)];
-        {
-            const int cbn = __builtin_amdgcn_readlane(cvec, (int)((j + 1) & 7));
+        for (int c8 = NC8 - 1; c8 >= 0; c8--) {   // (descending: a chunk reads what the chunk above it left in the previous iteration)
+            const uint32_t jc = t - (uint32_t)c8;
+            if (jc >= width) continue;            // (also t < c8)
+            int sc[4];
 #pragma unroll
-            for (int c8 = 0; c8 < NC8; c8++)
+            for (int k = 0; k < 4; k++) sc[k] = sc_next[c8][k];
+            {   // scores of this chunk's next column are fetched while this one is computed
+                const int cbn = __builtin_amdgcn_readlane(cvec, (int)(jc + 1) - cbase);
 #pragma unroll
                 for (int k = 0; k < 4; k++) sc_next[c8][k] = fetch_score<KIND>(L.table, key[c8][k], cbn);
-        }
-        int up_d = (int)((uint32_t)corner_cur << 16);   // D of the cell above the chunk, previous column (hi half)
-        corner_cur = 0;
-        int carry_r = 0;                                 // R of the cell above the chunk, this column: MIN at the top
-        const int jp1 = splat((int)j + 1);
-        int r_last = 0;
-#pragma unroll
-        for (int c8 = 0; c8 < NC8; c8++) {
+            }
+            // D of the cell above the chunk, previous column (hi half): the corner for the first column of the top chunk
+            const int up_d = c8 == 0 ? (jc == 0 ? (int)((uint32_t)corner << 16) : 0) : up_cap[c8 - 1];
+            const int carry_r = c8 == 0 ? 0 : carry_cap[c8 - 1];   // R of the cell above the chunk, this column: MIN at the top
+            const int jp1 = splat((int)jc + 1);
             // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
             int prev = wave_shr1_z(d[c8][3]);
             if (up_d != 0) prev = set_lane0(prev, up_d);
-            if (NC8 > 1) up_d = __builtin_amdgcn_readlane(d[c8][3], 63);
+            if (NC8 > 1 && c8 < NC8 - 1) up_cap[c8] = __builtin_amdgcn_readlane(d[c8][3], 63);
             int d00[4];
             d00[0] = __builtin_amdgcn_alignbit(d[c8][0], prev, 16);
 #pragma unroll
@@ -802,8 +810,8 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
             int d11[4], copen[4], cn[4], x[4], r[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                d11[k] = adds(d00[k], sc[c8][k]);
-                if (c8 == 0 && k == 0 && j == 0 && start_i == 0 && start_j == 0) {   // cell (0,0) starts from the relative zero (scan_block.rs:1130-1132): lane 0, low half
+                d11[k] = adds(d00[k], sc[k]);
+                if (c8 == 0 && k == 0 && jc == 0 && start_i == 0 && start_j == 0) {   // cell (0,0) starts from the relative zero (scan_block.rs:1130-1132): lane 0, low half
                     const int v0 = __builtin_amdgcn_readlane(d11[0], 0);
                     d11[0] = set_lane0(d11[0], (v0 & (int)0xffff0000) | (rel_zero & 0xffff));
                 }
@@ -820,12 +828,12 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
             // what the cells above this lane contribute: lanes above in this chunk, or (lane * 8g + carry) from above the chunk,
             // which is MIN = 0 at the top of the column
             int cin = add_shr1(pm, lanem1KG);
-            cin = max(max(cin, NC8 > 1 ? laneKG + carry_r : laneKG), -32768);
+            cin = max(max(cin, c8 > 0 ? laneKG + carry_r : laneKG), -32768);
             const s16x2 cs = as_s(cin);
             const int csp = as_i(s16x2{cs.x, cs.x});
 #pragma unroll
             for (int k = 0; k < 4; k++) r[k] = vmax(vmax(r[k], adds(csp, G[k])), vart[k]);
-            if (NC8 > 1) carry_r = (int)(short)(__builtin_amdgcn_readlane(r[3], 63) >> 16);
+            if (NC8 > 1 && c8 < NC8 - 1) carry_cap[c8] = (int)(short)(__builtin_amdgcn_readlane(r[3], 63) >> 16);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int dn = vmax(d11[k], r[k]);
@@ -839,30 +847,18 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
                 if (LOC) jlast[c8][k] = vmaxu(jlast[c8][k], pk_mul(eq01(dmax[c8][k], dn, fc.ones), jp1));   // 1 + last column whose cell ties or raises its row's running max
                 d[c8][k] = dn; c[c8][k] = cn[k];
             }
-            if (c8 == NC8 - 1) r_last = r[3];
-        }
-        if (TRACE && (j & 3) == 3) {
-#pragma unroll
-            for (int c8 = 0; c8 < NC8; c8++) {
-                *(int4*)(trace_out + ((j >> 2) * NCH + c8 * 4) * 64 + tw_lane) = int4{tacc[c8][0], tacc[c8][1], tacc[c8][2], tacc[c8][3]};
+            if (TRACE && ((jc & 3) == 3 || jc + 1 == width)) {
+                // (a last, unfinished column group -- only after the early break: its columns so far sit in the high nibbles)
+                const int sh = 4 * (3 - (int)(jc & 3));
+                *(int4*)(trace_out + ((jc >> 2) * NCH + c8 * 4) * 64 + tw_lane) =
+                    int4{(int)((uint32_t)tacc[c8][0] >> sh), (int)((uint32_t)tacc[c8][1] >> sh), (int)((uint32_t)tacc[c8][2] >> sh), (int)((uint32_t)tacc[c8][3] >> sh)};
                 tacc[c8][0] = tacc[c8][1] = tacc[c8][2] = tacc[c8][3] = 0;
             }
-        }
-        // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-        if (last_lane) { Dr[j] = (short)(d[NC8 - 1][3] >> 16); Rr[j] = (short)(r_last >> 16); }
-        cells += height;
-        if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
-            if (TRACE && (j & 3) != 3) {            // (the words of the unfinished column group: its columns so far sit in the high nibbles)
-#pragma unroll
-                for (int c8 = 0; c8 < NC8; c8++) {
-                    const int sh = 4 * (3 - (int)(j & 3));
-                    *(int4*)(trace_out + ((j >> 2) * NCH + c8 * 4) * 64 + tw_lane) =
-                        int4{(int)((uint32_t)tacc[c8][0] >> sh), (int)((uint32_t)tacc[c8][1] >> sh), (int)((uint32_t)tacc[c8][2] >> sh), (int)((uint32_t)tacc[c8][3] >> sh)};
-                }
-            }
-            break;
+            // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
+            if (c8 == NC8 - 1 && last_lane) { Dr[jc] = (short)(d[NC8 - 1][3] >> 16); Rr[jc] = (short)(r[3] >> 16); }
         }
     }
+    cells += (unsigned long long)height * width;
     // ---- write the vector-axis border back
 #pragma unroll
     for (int c8 = 0; c8 < NC8; c8++) {
