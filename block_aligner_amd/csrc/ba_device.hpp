@@ -781,12 +781,16 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
 #pragma unroll
     for (int c8 = 0; c8 < NC8; c8++) { up_cap[c8] = 0; carry_cap[c8] = 0; }
     const uint32_t iters = width + (uint32_t)NC8 - 1u;
-    for (uint32_t t = 0; t < iters; t++) {
+    // (GUARD: the first and last NC8 - 1 iterations, where some chunk has no column; the iterations between run every chunk without a
+    // branch in between -- one basic block, which is what lets the scheduler interleave the chunks)
+    auto iteration = [&](uint32_t t, auto guard_c) {
+        constexpr bool GUARD = decltype(guard_c)::value;
         if (((t + 1) & 7) == 0) { cbase = (int)(t + 1) - 8; cvec = load_cols(cbase); }   // (t + 1 - c8 >= cbase for every chunk: NC8 <= 4)
+        int d_last = 0, r_last = 0;
 #pragma unroll
         for (int c8 = NC8 - 1; c8 >= 0; c8--) {   // (descending: a chunk reads what the chunk above it left in the previous iteration)
             const uint32_t jc = t - (uint32_t)c8;
-            if (jc >= width) continue;            // (also t < c8)
+            if (GUARD && jc >= width) continue;   // (also t < c8)
             int sc[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) sc[k] = sc_next[c8][k];
@@ -801,7 +805,7 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
             const int jp1 = splat((int)jc + 1);
             // D00: previous column shifted down one cell (scan_block.rs:1125); lane 0 takes the cell above the chunk
             int prev = wave_shr1_z(d[c8][3]);
-            if (up_d != 0) prev = set_lane0(prev, up_d);
+            prev = set_lane0(prev, up_d);          // (0 where there is no cell above: what the shift put there anyway; no branch)
             if (NC8 > 1 && c8 < NC8 - 1) up_cap[c8] = __builtin_amdgcn_readlane(d[c8][3], 63);
             int d00[4];
             d00[0] = __builtin_amdgcn_alignbit(d[c8][0], prev, 16);
@@ -811,7 +815,7 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 d11[k] = adds(d00[k], sc[k]);
-                if (c8 == 0 && k == 0 && jc == 0 && start_i == 0 && start_j == 0) {   // cell (0,0) starts from the relative zero (scan_block.rs:1130-1132): lane 0, low half
+                if ((GUARD || NC8 == 1) && c8 == 0 && k == 0 && jc == 0 && start_i == 0 && start_j == 0) {   // (NC8 > 1: column 0 of the top chunk is a guarded iteration)   // cell (0,0) starts from the relative zero (scan_block.rs:1130-1132): lane 0, low half
                     const int v0 = __builtin_amdgcn_readlane(d11[0], 0);
                     d11[0] = set_lane0(d11[0], (v0 & (int)0xffff0000) | (rel_zero & 0xffff));
                 }
@@ -854,9 +858,17 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
                     int4{(int)((uint32_t)tacc[c8][0] >> sh), (int)((uint32_t)tacc[c8][1] >> sh), (int)((uint32_t)tacc[c8][2] >> sh), (int)((uint32_t)tacc[c8][3] >> sh)};
                 tacc[c8][0] = tacc[c8][1] = tacc[c8][2] = tacc[c8][3] = 0;
             }
-            // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
-            if (c8 == NC8 - 1 && last_lane) { Dr[jc] = (short)(d[NC8 - 1][3] >> 16); Rr[jc] = (short)(r[3] >> 16); }
+            if (c8 == NC8 - 1) { d_last = d[NC8 - 1][3]; r_last = r[3]; }
         }
+        // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
+        const uint32_t jl = t - (uint32_t)(NC8 - 1);
+        if (last_lane && (!GUARD || jl < width)) { Dr[jl] = (short)(d_last >> 16); Rr[jl] = (short)(r_last >> 16); }
+    };
+    {
+        uint32_t t = 0;
+        for (; t < (uint32_t)(NC8 - 1) && t < iters; t++) iteration(t, std::true_type{});
+        for (; t < width; t++) iteration(t, std::false_type{});
+        for (; t < iters; t++) iteration(t, std::true_type{});
     }
     cells += (unsigned long long)height * width;
     // ---- write the vector-axis border back
