@@ -557,7 +557,7 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
 // dependent iterations whose length grows with the number of lanes walking in lockstep, so the last `tb_reserve`
 // hand-offs are left to these late helpers, one lane per wave on a SIMD that has nothing else left to do (the
 // dedicated waves stop claiming tickets once the ticket counter reaches that reserve).
-template <int LB = (int)TB_LANE_BYTES, int CELLS = TB_CELLS_PER_STEP>
+template <int LB = (int)TB_LANE_BYTES, int CELLS = TB_CELLS_PER_STEP, int DEPTH = BA_RING_DEPTH>
 __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds, uint32_t nlanes, bool dedicated, int prio = -1) {
     enum { IDLE = 0, WAIT = 1, WALK = 2, RETIRED = 3 };
     int phase = (uint32_t)lane_id() < nlanes ? IDLE : RETIRED;
@@ -632,14 +632,14 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
         if (walking) {
 #ifdef BA_TIMING
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-            if (t.i > 0 || t.j > 0) tb_step<CELLS, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut, c_sec);
+            if (t.i > 0 || t.j > 0) tb_step<CELLS, DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut, c_sec);
             c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
 #else
             // (an emptied fill wave's few lanes -- the batch's last walks, each a chain of memory round trips that ends the launch --
             // take more cells per call and look further ahead; dedicated waves share their SIMD with fill waves: see tb_step)
             if (t.i > 0 || t.j > 0) {
                 if (BA_HELPER_CELLS != CELLS && !dedicated) tb_step<BA_HELPER_CELLS, BA_WALK_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
-                else tb_step<CELLS, BA_RING_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
+                else tb_step<CELLS, DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
             }
 #endif
             if (!(t.i > 0 || t.j > 0)) {
