@@ -101,6 +101,10 @@
 #define J_SADU16(r) "v_sad_u16 " r ", " r ", %9, " r "\n"
 #define J_MIX2(r) "v_pk_add_i16 " r ", " r ", %8 clamp\n v_max_i16 " r ", " r ", %9\n"
 #define J_MIX3(r) "v_add_f32 " r ", " r ", %9\n v_max_i16 " r ", " r ", %9\n"
+#define K_CNDE64(r) "v_cndmask_b32_e64 " r ", " r ", %9, s[20:21]\n"
+#define K_CNDMIX(r) "v_cndmask_b32 " r ", " r ", %9, vcc\n v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_add_i16 " r ", " r ", %9 clamp\n"
+#define K_CND0(r) "v_cndmask_b32_e64 " r ", " r ", %9, s[22:23]\n"
+#define K_CNDEXEC(r) "v_cndmask_b32_e64 " r ", " r ", %9, exec\n"
 
 struct Case { const char* name; int id; int per_group; };   // per_group: VALU instructions counted per accumulator visit
 
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(256) k(int* out, unsigned long long* ticks, in
     int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const int vb = threadIdx.x * 3 + 1;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc");
+    asm volatile("s_mov_b64 vcc, 0x5555\n s_mov_b64 s[20:21], 0x3333\n s_mov_b64 s[22:23], 0" ::: "vcc", "s20", "s21", "s22", "s23");
     for (int i = 0; i < iters; i++) {
 #define CASE(N, INS) if (KIND == N) { REP8(asm volatile(ALL8(INS) : ACC : "s"(s), "v"(vb) : "s20", "s21", "vcc", "scc");) }
         CASE(0, I_PKADD) CASE(1, I_PKMAX) CASE(2, I_PKMAXSEL) CASE(3, I_PKSUBU) CASE(4, I_PKMINU) CASE(5, I_PKMAD) CASE(6, I_PKASHR)
@@ -124,6 +128,7 @@ __global__ void __launch_bounds__(256) k(int* out, unsigned long long* ticks, in
         CASE(61, J_MULI24) CASE(62, J_MOV) CASE(63, J_CVTF) CASE(64, J_CVTI) CASE(65, J_NOT) CASE(66, J_MAXF32DPP) CASE(67, J_MAXF32DPPB)
         CASE(68, J_ADDF32DPP) CASE(69, J_MAXI16DPP) CASE(70, J_ASHRDPP) CASE(71, J_MED3I) CASE(72, J_MED3F) CASE(73, J_MAX3F) CASE(74, J_ADD3)
         CASE(75, J_MAXF32E64) CASE(76, J_PKMAXF16) CASE(77, J_PKADDF16) CASE(78, J_ADDF32S) CASE(79, J_ADDF32K) CASE(80, J_CNDMASK2)
+        CASE(88, K_CNDE64) CASE(89, K_CNDMIX) CASE(90, K_CND0) CASE(91, K_CNDEXEC)
         CASE(81, J_MAXI16S) CASE(82, J_SUBREV) CASE(83, J_LSHLADD) CASE(84, J_ADDLSHL) CASE(85, J_SADU16) CASE(86, J_MIX2) CASE(87, J_MIX3)
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -166,7 +171,9 @@ int main(int argc, char** argv) {
                 "accumulators per wave, 64 groups per loop iteration). First number: from the HIP-event wall time at the nominal 2.4 GHz;\n"
                 "second: from each wave's own s_memtime delta (shader clock). A group is ONE instruction unless the name says otherwise.\n\n"
                 "| instruction | W=1 | W=2 | W=4 | W=8 |\n|---|---|---|---|---|\n", p.name, p.multiProcessorCount, p.clockRate);
-#define RUN(N, NAME) run<N>(NAME, md);
+#define RUN(N, NAME) if (N >= first) run<N>(NAME, md);
+    const int first = argc > 2 ? atoi(argv[2]) : 0;
+    if (first) { RUN(24, "v_cndmask_b32 vcc") RUN(88, "v_cndmask_b32_e64 sgpr pair") RUN(89, "group: v_cndmask vcc + 3 v_pk_add_i16") RUN(90, "v_cndmask_b32_e64 sgpr pair = 0") RUN(91, "v_cndmask_b32_e64 exec") RUN(16, "v_bfi_b32") fclose(md); return 0; }
     RUN(0, "v_pk_add_i16 clamp") RUN(1, "v_pk_max_i16") RUN(2, "v_pk_max_i16 op_sel_hi") RUN(3, "v_pk_sub_u16") RUN(4, "v_pk_min_u16 inline const")
     RUN(5, "v_pk_mad_u16") RUN(6, "v_pk_ashrrev_i16") RUN(7, "v_add_u32") RUN(8, "v_max_i32") RUN(9, "v_max3_i32") RUN(10, "v_max_i32_dpp row_shr:1")
     RUN(11, "v_max_i32_dpp row_bcast:15") RUN(12, "v_mov_b32_dpp wave_shr:1") RUN(13, "v_add_u32_dpp wave_shr:1") RUN(14, "v_alignbit_b32")
