@@ -786,6 +786,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     // is scalar code, and a CU has one scalar unit for all its waves.
     const uint32_t n_wave = (bp.flags & (F_LOCAL | F_FQS)) ? 0u : min(bp.walk_wave_n, bp.n);
     if (n_wave) {
+        __builtin_amdgcn_s_setprio(3);   // (the launch's longest chains: ahead of the lanes' walks on the same SIMD -- protein set with traceback +4 %)
         for (;;) {
             uint32_t p = 0;
             if (is_lane(0)) p = atomicAdd(bp.work_counter + 1, 1u);
@@ -802,6 +803,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
                                         bp.pool + bp.r_off[p], eq != 0, bp.cig_ops, bp.cig_off[p], bp.cig_off[p + 1], &st, (uint32_t*)tb_lds, TB_LDS_BYTES / 4u);
             if (is_lane(0)) { bp.cig_len[p] = st ? 0u : ncig; if (st) bp.status[p] = st; }
         }
+        __builtin_amdgcn_s_setprio(0);
         lds_sync();
 #pragma unroll
         for (int e = 0; e < 2; e++) {
