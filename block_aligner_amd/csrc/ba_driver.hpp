@@ -1771,9 +1771,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
         uint32_t turn = 0;
         uint32_t w_next = 0, w_end = 0;   // this wave's share of the work counter: bp.work_chunk pairs per atomic
         bool closing = false;             // queue mode: every producer wave has been seen done
-#ifdef BA_SIDE_PRIO
-        if (bp.cont_mode == 2 && bp.cq_side) __builtin_amdgcn_s_setprio(BA_SIDE_PRIO);   // (the pairs that leave k_quad are the batch's longest serial chains)
-#endif
+        // (score-only batches: the pairs that leave k_quad are the batch's longest serial chains -- protein set +3 %; with traceback the
+        // same priority costs 1 - 3 %: the walks of k_walk and of this kernel are then the longer chains)
+        if (!TRACE && bp.cont_mode == 2 && bp.cq_side) __builtin_amdgcn_s_setprio(3);
         if (bp.cont_mode == 2 && bp.cq_side) {
             // The launch beside k_quad: a queue ticket, once taken, is served (an abandoned one would be a lost pair), so no ticket
             // is taken before k_quad is known to be on the device -- from then on its resident waves finish the batch's pairs whatever
