@@ -106,7 +106,7 @@ pub(crate) fn op_of(code: u8) -> Operation {   // cigar.rs:10-33 / c/block_align
 }
 
 /// Many pairs, one launch: what to use instead of a loop over `Block::align` (a loop of single-pair launches costs a launch and a
-/// device round trip per pair: ~60 us for a pair that fits one block, ~1 ms for a 900-residue pair -- slower than the CPU it
+/// device round trip per pair: ~50 us per call for a pair that fits one block, ~0.8 ms for a 900-residue pair -- slower than the CPU it
 /// replaces; the batch keeps the whole device busy: INTEGRATION.md). Sequences are raw bytes in one pool; results come back in
 /// the caller's order.
 pub struct HipBatch { h: *mut c_void, n: usize, trace: bool }
