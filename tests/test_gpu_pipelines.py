@@ -163,3 +163,20 @@ def test_cigars_gathered_behind_the_launch(hip, oracle):
     ref = oracle.batch_align(NUC, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, (-5, -1), (128, 512), 80, mode, cigar_eq=True, threads=8)
     assert np.array_equal(runs0, flat_oracle_runs(ref, len(pairs)))
     b.close()
+
+
+@pytest.mark.parametrize("kind", ["dna-xdrop", "protein"])
+def test_whole_wave_walks_for_every_path_of_a_pipeline_batch(hip, oracle, devlib, monkeypatch, kind):
+    """k_walk gives a whole wave only to the batch's longest paths (ba_host.cpp plan_walks); here the development switches hand it every
+    pair of at least 512 residues, so thousands of random paths -- with =/X runs (DNA) and without (protein), finished by k_quad and by
+    the per-pair kernel -- go through walk_wave and are compared run by run."""
+    monkeypatch.setenv("BA_FORCE_QUAD", "1")
+    monkeypatch.setenv("BA_FORCE_PIPE", "1")
+    monkeypatch.setenv("BA_WALK_WAVE_FRAC", "1000")
+    monkeypatch.setenv("BA_WALK_WAVE_MAX", "1000000")
+    if kind == "dna-xdrop":
+        pairs = synth.make_pairs(3000, (200, 1500), (10, 150), 40, synth.DNA, seed=31, indels=1, indel_len=(5, 60))
+        run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 80, ("trace", "x_drop"), True, ("wave walks", kind))
+    else:
+        pairs = synth.make_pairs(3000, (100, 1200), (0, 250), 0, synth.AMINO, seed=32, indels=1, indel_len=(3, 40))
+        run_and_compare(hip, oracle, pairs, S.BLOSUM62, (-11, -1), (32, 256), 0, ("trace",), False, ("wave walks", kind))
