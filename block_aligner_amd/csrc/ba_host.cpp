@@ -595,7 +595,13 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
         b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
     }
-    if (trace && (b->grid >= 32 || (dev_env("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !b->pipe && !dev_env("BA_INLINE_TRACEBACK")) {
+    // Few pairs: while the batch gives a resident wave no more than about two pairs, the wave walks each path itself with all its lanes
+    // (walk_wave: ~0.2 - 0.35 us per cell) instead of handing it to a traceback lane (64 walks in lockstep: 0.55 - 0.9 us per cell, the
+    // better use of the machine once every wave has pairs waiting) -- 10 kbp pairs, block 128..1024, same box: 256 pairs 22.7 -> 12.6 ms,
+    // 2048: 25.3 -> 13.2, 4096 (one per wave): 26.3 -> 19.3, 8192: 35.8 -> 33.5, 12000: 40.3 -> 48.1 (kept on the lanes).
+    // (one pair per wave at most: in every block class; two: measured for the classes with large LDS regions only)
+    const bool few_pairs = !special_of(mode) && n <= (lds_class_cells(pc) >= 512 ? 2u : 1u) * (uint64_t)grid * ba::WAVES_PER_WG && !dev_env("BA_FORCE_TB");
+    if (trace && (b->grid >= 32 || (dev_env("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !few_pairs && !b->pipe && !dev_env("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
         // b % 8, so the traceback waves sit on XCDs 0 and 4 only; measured against stride 3 / 5 -- all XCDs -- this makes
