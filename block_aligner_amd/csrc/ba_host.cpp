@@ -740,7 +740,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // Small batches are bound by their longest pair's chain of steps, which the hand-over only lengthens: the pipeline is taken
     // from the sizes where it wins (measured, GCUPS with / without: protein pairs 32k 371 / 405, 64k 745 / 527, 400k 1375 / 597;
     // PSSM 8k 108 / 105, 20k 211 / 162, 80k 458 / 172; 1 kbp DNA 200k 1347 / 606). BA_FORCE_QUAD / BA_NO_QUAD override.
-    const size_t quad_from = kind == BA_KIND_AA ? 65536u : (profile ? 8192u : 2048u);
+    // (1 kbp DNA, round 3 -- the per-pair kernel walks with whole waves now: 2.5 k pairs 0.78 / 1.89 ms without / with traceback against
+    // 1.34 / 2.96 through the pipeline, 4 k 0.82 / 1.96 against 1.40 / 3.07, 8 k 1.37 / 3.18 against 1.44 / 3.31, 10 k 3.59 against 3.33)
+    const size_t quad_from = kind == BA_KIND_AA ? 65536u : 8192u;
     b->quad = !special_of(mode) && pc != BA_PCLASS_BIG && min_size == 32 && !dev_env("BA_NO_QUAD") && (dev_env("BA_FORCE_QUAD") || n >= quad_from);
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small

@@ -1,5 +1,5 @@
 """The multi-kernel pipelines at the batch sizes from which the library itself picks them -- no development switch, the release
-library: k_quad -> queue -> per-pair kernel -> k_walk for batches that start at 32 cells (from 2048 DNA pairs, 8192 PSSMs, 65536
+library: k_quad -> queue -> per-pair kernel -> k_walk for batches that start at 32 cells (from 8192 DNA pairs or PSSMs, 65536
 protein pairs: ba_host.cpp batch_build), k_multi for batches that start at 128 cells (from 16384 pairs). Every pair of every
 batch is compared with the oracle: score, end positions, computed cells, every CIGAR run."""
 import numpy as np
@@ -59,9 +59,9 @@ def run_and_compare(H, oracle, pairs, matrix, gaps, size, x_drop, mode, cigar_eq
 
 @pytest.mark.parametrize("mode", MODES)
 def test_dna_small_blocks_at_threshold(hip, oracle, mode):
-    """4 k+ DNA pairs at 32..256 (threshold 2048): k_quad, the queue, the per-pair kernel and (with traceback) k_walk."""
+    """9 k DNA pairs at 32..256 (threshold 8192): k_quad, the queue, the per-pair kernel and (with traceback) k_walk."""
     assert hip.lib().ba_dev_build() == 0
-    pairs = synth.make_pairs(5000, (0, 1500), (0, 150), 40, synth.DNA, seed=811, indels=1, indel_len=(5, 60))
+    pairs = synth.make_pairs(9000, (0, 1500), (0, 150), 40, synth.DNA, seed=811, indels=1, indel_len=(5, 60))
     run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 100, mode, True, ("dna 32..256", mode))
 
 
