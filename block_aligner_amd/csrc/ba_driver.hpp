@@ -765,10 +765,14 @@ __device__ __forceinline__ void traceback_helper_wave(const BatchParams& bp, uin
 // Pair-slot batches (every pair's trace stack stays in its own region until the batch ends): the tracebacks of the whole
 // batch after its fill kernels, one pair per LANE, all 64 lanes of every wave walking (tb_step). Lanes that finish take the
 // next pairs of the batch order (longest first, so the lanes of a wave walk paths of similar length) with one atomic per wave.
+// L2OK: the batch holds slot rectangles of k_small (words of 4 cells x 2 columns, see multi_rect): the lanes' records are TB_LANE_BYTES_L2 bytes
+template <bool L2OK = false>
 __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
+    constexpr int LB = L2OK ? (int)TB_LANE_BYTES_L2 : (int)TB_LANE_BYTES;
+    constexpr uint32_t WAVE_LDS = L2OK ? TB_LDS_BYTES_L2 : TB_LDS_BYTES;
     const uint32_t eq = bp.flags & flag_mask;
     unsigned char* lut = tb_lds;
-    unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * TB_LANE_BYTES;
+    unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * (uint32_t)LB;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const uint32_t idx = (uint32_t)lane_id() + 64u * e;
@@ -799,8 +803,8 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             if (!mine) continue;
             uint32_t st = bp.status[p], ncig = 0;
             if (!st && !(bp.flags & 0x200u))
-                ncig = walk_wave<false>(bp.blocks + bp.blocks_off[p], si.nblocks, bp.trace_arena + bp.trace_off[p], si.end_i, si.end_j, bp.pool + bp.q_off[p],
-                                        bp.pool + bp.r_off[p], eq != 0, bp.cig_ops, bp.cig_off[p], bp.cig_off[p + 1], &st, (uint32_t*)tb_lds, TB_LDS_BYTES / 4u);
+                ncig = walk_wave<L2OK>(bp.blocks + bp.blocks_off[p], si.nblocks, bp.trace_arena + bp.trace_off[p], si.end_i, si.end_j, bp.pool + bp.q_off[p],
+                                       bp.pool + bp.r_off[p], eq != 0, bp.cig_ops, bp.cig_off[p], bp.cig_off[p + 1], &st, (uint32_t*)tb_lds, WAVE_LDS / 4u);
             if (is_lane(0)) { bp.cig_len[p] = st ? 0u : ncig; if (st) bp.status[p] = st; }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -851,8 +855,8 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             // (no fill wave shares the SIMD here: a call walks on while its window lasts; the mode bits as constants: a walk is a
             // serial chain of ~200 instructions per cell whose length, for the batch's longest pair, ends the launch)
             if (t.i > 0 || t.j > 0) {
-                if (eq) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH>(t, (uint32_t)F_CIGAR_EQ, bp.cig_ops, lrec, lut);
-                else tb_step<BA_WALK_CELLS, BA_WALK_DEPTH>(t, 0u, bp.cig_ops, lrec, lut);
+                if (eq) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, (uint32_t)F_CIGAR_EQ, bp.cig_ops, lrec, lut);
+                else tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, 0u, bp.cig_ops, lrec, lut);
             }
             if (!(t.i > 0 || t.j > 0)) {
                 tb_emit(t, bp.cig_ops);
@@ -882,9 +886,11 @@ enum { MM_NONE = -1, MM_FRESH = 0, MM_RESUME = 1 };
 // SPECIAL: the batch uses LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS. A separate instantiation, so the
 // common kernels carry none of that state (it costs registers: +30 % spills when folded into one kernel).
 struct NoState { int exited; };
-// MULTI: the instantiation k_multi (ba_multi.hpp) runs in its solo mode (entry / exit with a PairState; everything else is the per-pair driver)
-template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL, bool MULTI = false>
+// MULTI: the instantiation k_multi (ba_multi.hpp) / k_small (ba_small.hpp) runs in its solo mode (entry / exit with a PairState; everything
+// else is the per-pair driver); SLOT_B: the block size at which a pair goes back to its slot (128: k_multi, 32: k_small)
+template <int PMAX, int KIND, bool TRACE, bool XDROP, bool SPECIAL, bool MULTI = false, int SLOT_B_ = 128>
 struct Aligner {
+    static constexpr uint32_t SLOT_B = (uint32_t)SLOT_B_;
     typedef std::conditional_t<MULTI, PairState, NoState> RunOut;
     // The batch descriptor lives in device memory. Only the scalars the step loop needs are copied into registers;
     // everything else (a couple of dozen per-pair output pointers) is re-read where it is used, once per pair, so it
@@ -1327,7 +1333,7 @@ struct Aligner {
             BA_TSTAMP(tsa);
             const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
-            if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && fast && !forced && block_size == MQ_B && min_size == MQ_B && !chain && !no_spec) {
+            if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && fast && !forced && block_size == SLOT_B && min_size == SLOT_B && !chain && !no_spec) {
                 // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
                 // four pairs to a wave. The borders are in LDS (cell order); the checkpoint follows them at entries MQ_B .. 2 MQ_B.
                 step_budget++;   // (the step this iteration counted has not been taken)
@@ -1338,15 +1344,17 @@ struct Aligner {
                 st.ck_i = (uint32_t)unpark<0>(parked); st.ck_j = (uint32_t)unpark<1>(parked); st.ck_off = unpark<2>(parked);
                 st.ck_tt = (uint32_t)unpark<3>(parked); st.ck_nb = (uint32_t)unpark<4>(parked);
                 st.trace_top = trace_top; st.nblocks = nblocks; st.status = status;
-                if (MQ_B < max_size) {
+                if (SLOT_B < max_size) {
                     const uint32_t k = 2 * lane_id(), ms = h_max_size;
                     lds_sync();
+                    if (SLOT_B >= 128 || k < SLOT_B) {
                     if (ck_in_regs) {
-                        *(int*)(L.D_col + MQ_B + k) = ck_reg[0]; *(int*)(L.C_col + MQ_B + k) = ck_reg[1];
-                        *(int*)(L.D_row + MQ_B + k) = ck_reg[2]; *(int*)(L.R_row + MQ_B + k) = ck_reg[3];
+                        *(int*)(L.D_col + SLOT_B + k) = ck_reg[0]; *(int*)(L.C_col + SLOT_B + k) = ck_reg[1];
+                        *(int*)(L.D_row + SLOT_B + k) = ck_reg[2]; *(int*)(L.R_row + SLOT_B + k) = ck_reg[3];
                     } else {
-                        *(int*)(L.D_col + MQ_B + k) = ckpt_load(ckpt + k); *(int*)(L.C_col + MQ_B + k) = ckpt_load(ckpt + ms + k);
-                        *(int*)(L.D_row + MQ_B + k) = ckpt_load(ckpt + 2 * ms + k); *(int*)(L.R_row + MQ_B + k) = ckpt_load(ckpt + 3 * ms + k);
+                        *(int*)(L.D_col + SLOT_B + k) = ckpt_load(ckpt + k); *(int*)(L.C_col + SLOT_B + k) = ckpt_load(ckpt + ms + k);
+                        *(int*)(L.D_row + SLOT_B + k) = ckpt_load(ckpt + 2 * ms + k); *(int*)(L.R_row + SLOT_B + k) = ckpt_load(ckpt + 3 * ms + k);
+                    }
                     }
                     lds_sync();
                 }
@@ -1437,7 +1445,7 @@ struct Aligner {
                     rs.si = si; rs.sj = sj; rs.dir = dir; rs.prev_dir = prev_dir; rs.off = off; rs.prev_off = prev_off; rs.off_max = off_max;
                     rs.off_add = off_add; rs.best_max = best_max; rs.y_drop_iter = y_drop_iter; rs.x_drop_iter = x_drop_iter; rs.D_corner = D_corner;
                     rs.step_budget = step_budget; rs.run_exit = RUN_EXIT_POST; rs.cur = cur; rs.fo = fo;
-                    rs = fast_run(rs, corner, block_size, min_size, max_size, MULTI && mmode != MM_NONE && allow_quad && block_size == MQ_B && min_size == MQ_B);
+                    rs = fast_run(rs, corner, block_size, min_size, max_size, MULTI && mmode != MM_NONE && allow_quad && block_size == SLOT_B && min_size == SLOT_B);
                     si = rs.si; sj = rs.sj; dir = rs.dir; prev_dir = rs.prev_dir; off = rs.off; prev_off = rs.prev_off; off_max = rs.off_max;
                     off_add = rs.off_add; best_max = rs.best_max; y_drop_iter = rs.y_drop_iter; x_drop_iter = rs.x_drop_iter; D_corner = rs.D_corner;
                     step_budget = rs.step_budget; run_exit = rs.run_exit; cur = rs.cur; fo = rs.fo;
@@ -1652,8 +1660,9 @@ struct Aligner {
     // location (returned in best_i / best_j; scan_block.rs:370-404) and the borders the reference's checkpoint holds (406-427).
     __device__ __forceinline__ void import_slot(const int (&reg)[16], const int (&ckr)[16], uint32_t pair_in, bool have_ck, bool ck_pre, int ck_dir, int ck_offadd, int ck_corner,
                                                 uint32_t ck_i, uint32_t ck_j, uint32_t& best_i, uint32_t& best_j) {
-        const int lane = lane_id(), l8 = 8 * (lane & 15);
-        const bool mine = lane < 16;
+        constexpr int SLOT_LANES = (int)SLOT_B / 8;   // the slot's lanes (8 cells each): 16 (k_multi) or 4 (k_small)
+        const int lane = lane_id(), l8 = 8 * (lane & (SLOT_LANES - 1));
+        const bool mine = lane < SLOT_LANES;
         q = coldp()->pool + coldp()->q_off[pair_in]; r = coldp()->pool + coldp()->r_off[pair_in];
         if (have_ck) {
             lds_sync();
@@ -1669,17 +1678,18 @@ struct Aligner {
                 constexpr int PR_DIST = (int)(lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u) / 2);
                 const bool cright = ck_dir == DIR_RIGHT;
                 const uint8_t* seqV = cright ? q : r; const uint8_t* seqC = cright ? r : q;
-                const uint32_t cri = cright ? ck_i : ck_j, crj = (cright ? ck_j : ck_i) + MQ_B - STEP;
-                const int vc = (int)*(const unsigned short*)(seqV + cri + 2 * lane);
+                const uint32_t cri = cright ? ck_i : ck_j, crj = (cright ? ck_j : ck_i) + SLOT_B - STEP;
+                constexpr int FL = (int)SLOT_B / 2;   // lanes of the per-pair layout that hold cells
+                const int vc = 2 * lane < (int)SLOT_B ? (int)*(const unsigned short*)(seqV + cri + 2 * lane) : 0;
                 const unsigned long long cb = load_cols(seqC + crj);
                 FastOut fo{};
                 if constexpr (KIND != KIND_PROFILE) {
-                    if (cright) fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, 64, ck_corner, ck_offadd, -1, nullptr, fo);
-                    else fast_rect<KIND, false, XDROP, 64, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, 64, ck_corner, ck_offadd, -1, nullptr, fo);
+                    if (cright) fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
+                    else fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
                 }
                 if (XDROP) {
-                    if (cright) { best_i = ck_i + (uint32_t)fo.row; best_j = ck_j + (MQ_B - STEP) + (uint32_t)fo.col; }
-                    else { best_i = ck_i + (MQ_B - STEP) + (uint32_t)fo.col; best_j = ck_j + (uint32_t)fo.row; }
+                    if (cright) { best_i = ck_i + (uint32_t)fo.row; best_j = ck_j + (SLOT_B - STEP) + (uint32_t)fo.col; }
+                    else { best_i = ck_i + (SLOT_B - STEP) + (uint32_t)fo.col; best_j = ck_j + (uint32_t)fo.row; }
                 }
                 lds_sync();
             }

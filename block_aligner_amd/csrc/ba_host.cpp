@@ -68,6 +68,17 @@ BA_DECL_M_KIND(0) BA_DECL_M_KIND(1) BA_DECL_M_KIND(2)
 #define BA_MOROW(K) {ba_occupancy_m_k##K##_p1, ba_occupancy_m_k##K##_p2, ba_occupancy_m_k##K##_p4, ba_occupancy_m_k##K##_p8, ba_occupancy_m_k##K##_p16}
 static const LaunchFn g_launch_m[3][5] = {BA_MROW(0), BA_MROW(1), BA_MROW(2)};
 static const OccFn g_occ_m[3][5] = {BA_MOROW(0), BA_MOROW(1), BA_MOROW(2)};
+// k_small (ba_small.hpp): sixteen pairs per wave at 32 cells; sequence kinds, block classes up to 1024 cells
+#define BA_DECL_SM(K, P)                                                                                              \
+    extern "C" hipError_t ba_launch_sm_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
+    extern "C" hipError_t ba_occupancy_sm_k##K##_p##P(int, int, unsigned, int*);
+#define BA_DECL_SM_KIND(K) BA_DECL_SM(K, 1) BA_DECL_SM(K, 2) BA_DECL_SM(K, 4) BA_DECL_SM(K, 8)
+BA_DECL_SM_KIND(0) BA_DECL_SM_KIND(1) BA_DECL_SM_KIND(2)
+#define BA_SMROW(K) {ba_launch_sm_k##K##_p1, ba_launch_sm_k##K##_p2, ba_launch_sm_k##K##_p4, ba_launch_sm_k##K##_p8}
+#define BA_SMOROW(K) {ba_occupancy_sm_k##K##_p1, ba_occupancy_sm_k##K##_p2, ba_occupancy_sm_k##K##_p4, ba_occupancy_sm_k##K##_p8}
+static const LaunchFn g_launch_sm[3][4] = {BA_SMROW(0), BA_SMROW(1), BA_SMROW(2)};
+static const OccFn g_occ_sm[3][4] = {BA_SMOROW(0), BA_SMOROW(1), BA_SMOROW(2)};
+extern "C" hipError_t ba_launch_walk_l2(hipStream_t, const BatchParams*, uint32_t grid);
 typedef hipError_t (*QuadFn)(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k0(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k1(int, int, unsigned, hipStream_t, const BatchParams*);
@@ -247,6 +258,7 @@ struct BaBatch {
     uint32_t mq_drain = 0;      // k_multi: pairs at the end of the batch that are run one at a time (BatchParams::mq_drain)
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
     uint32_t walk_wave_n = 0;   // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (plan_walks)
+    bool small = false;         // small-block batch: sixteen pairs per wave while their block is 32 cells, everything else by the same wave (ba_small.hpp)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
     DevBuf cq_queue, cq_ctrl;   // the queue those pairs travel through (ba_params.h)
@@ -531,20 +543,21 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
     // (k_multi's traceback waves keep their records in their own wave's region: no extra space)
-    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u);
+    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : (b->small ? ba::sm_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u));
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? g_occ_m[kind][pc] : g_occ[special_of(mode)][kind][pc]);
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? g_occ_m[kind][pc] : (b->small ? g_occ_sm[kind][pc] : g_occ[special_of(mode)][kind][pc]));
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
     if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
     if (const char* env = dev_env("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
     uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
-    const uint64_t need = (n + ba::WAVES_PER_WG - 1) / ba::WAVES_PER_WG;
+    const uint64_t per_wg = (uint64_t)ba::WAVES_PER_WG * (b->small ? ba::SM_SLOTS : 1u);
+    const uint64_t need = (n + per_wg - 1) / per_wg;
     if (grid > need) grid = need;
     // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
     // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
@@ -594,6 +607,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t waves = grid * ba::WAVES_PER_WG;
         const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
         b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
+        if (b->small) b->work_chunk = 4;   // (sixteen slots refill one by one; pairs come longest first: a long chunk would queue the longest pairs on one wave)
     }
     // Few pairs: while the batch gives a resident wave no more than about two pairs, the wave walks each path itself with all its lanes
     // (walk_wave: ~0.2 - 0.35 us per cell) instead of handing it to a traceback lane (64 walks in lockstep: 0.55 - 0.9 us per cell, the
@@ -657,7 +671,7 @@ static int batch_alloc_scratch(BaBatch* b) {
     BA_ALLOC(blocks, b->pipe ? b->pipe_recs * sizeof(BlockRec) : b->blocks_stride * sizeof(BlockRec) * b->slots);
     BA_ALLOC(ckpt, (size_t)(b->grid + b->cq_grid) * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
     BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short)
-                                              : (b->multi ? (size_t)b->grid * ba::WAVES_PER_WG * ba::MQ_WAVE_BYTES : 0));
+                                              : (b->multi ? (size_t)b->grid * ba::WAVES_PER_WG * ba::MQ_WAVE_BYTES : (b->small ? (size_t)b->grid * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES : 0)));
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
 #undef BA_ALLOC
@@ -744,24 +758,29 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // 1.34 / 2.96 through the pipeline, 4 k 0.82 / 1.96 against 1.40 / 3.07, 8 k 1.37 / 3.18 against 1.44 / 3.31, 10 k 3.59 against 3.33)
     const size_t quad_from = kind == BA_KIND_AA ? 65536u : 8192u;
     b->quad = !special_of(mode) && pc != BA_PCLASS_BIG && min_size == 32 && !dev_env("BA_NO_QUAD") && (dev_env("BA_FORCE_QUAD") || n >= quad_from);
+    // Round 4: sequence kinds take k_small instead (ba_small.hpp) -- sixteen pairs per wave at 32 cells, eight cells per lane, and the grow /
+    // shrink / X-drop end game of a pair by the same wave in solo mode: no queue, no launch beside. Block classes up to 1024 cells.
+    b->small = !profile && !special_of(mode) && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= quad_from && !dev_env("BA_FORCE_QUAD")));
+    if (b->small) b->quad = false;
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
     // blocks take it in place of the hand-off ring (50..500 positions, 20k pairs: 143 -> 158 GCUPS, 80k: 172 -> 225). Short
     // sequence pairs do not: their walks are few hundred steps, cheapest done at once by the fill wave's lane 0 (protein pairs,
     // 8k..65k pairs: 3 .. 20 % slower with k_walk, whose latest wave ends one longest-path walk after the fill).
     std::vector<uint64_t> toff, boff;
-    if (trace && !special_of(mode) && pc != BA_PCLASS_BIG && (b->quad || (profile && n >= 4096) || dev_env("BA_FORCE_PIPE"))) {
+    if (trace && !special_of(mode) && pc != BA_PCLASS_BIG && (b->quad || b->small || (profile && n >= 4096) || dev_env("BA_FORCE_PIPE"))) {
         const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * (64 + sizeof(ba::PairCont) + 40);
         if (!dev_env("BA_NO_PIPE") && !pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) {
             b->pipe = true; b->pipe_words = toff[n] + toff[n] / 8; b->pipe_recs = boff[n] + boff[n] / 8;   // (headroom for ba_batch_reload)
         }
     }
-    if (trace && !b->pipe) b->quad = false;   // with TRACE the pipeline needs every pair's trace stack resident until the end
+    if (trace && !b->pipe) b->quad = b->small = false;   // with TRACE the pipeline needs every pair's trace stack resident until the end
     // Batches that start at 128 cells (the reference's nanopore set-up, examples/nanopore_bench.rs: 1 % .. 10 % of 10 kbp): four pairs
     // per wave while a pair's block is 128 cells (ba_multi.hpp), from the sizes at which every wave still finds four pairs.
     b->multi = !profile && !special_of(mode) && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || n >= 16384);
     if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
-    if (!b->multi)
+    if (b->small && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->small = false;   // (e.g. LDS: falls back to the per-pair kernel)
+    if (!b->multi && !b->small)
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
     if (b->pipe) b->adaptive = true;
     b->cig_total = trace ? cig_total : 0;
@@ -935,6 +954,15 @@ static int batch_launch(BaBatch* b) {
         if (walk2) {
             BatchParams w2 = bp; w2.cont_mode = 2; w2.cont_in_flag = flagA; w2.work_counter = b->counter.as<uint32_t>() + 12;
             HIP_TRY(ba_launch_walk(b->stream, &w2, walk_grid(b)));
+        }
+    } else if (b->small) {
+        // k_small takes every pair from start to end (slots at 32 cells, everything else by the same wave in solo mode); TRACE: a pair-slot
+        // batch -- the fill only stacks, k_walk (its form for slot rectangles) walks all paths afterwards
+        BatchParams p1 = bp; p1.cig_ops = nullptr; p1.inline_len2 = ~0u;
+        HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
+        if ((b->mode & BA_TRACE) && bp.cig_ops) {
+            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+            HIP_TRY(ba_launch_walk_l2(b->stream, &bp, walk_grid(b)));
         }
     } else if (b->pipe) {   // pair-slot batch: the fill stacks, k_walk walks
         BatchParams p1 = bp; p1.cig_ops = nullptr; p1.inline_len2 = ~0u;
@@ -1220,6 +1248,7 @@ int ba_batch_info(BaBatch* b, uint64_t out[4]) {
     out[0] = (uint64_t)b->grid * ba::WAVES_PER_WG; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
     return 0;
 }
+int ba_batch_kernel(BaBatch* b) { return !b ? -1 : (b->small ? 3 : (b->quad ? 2 : (b->multi ? 1 : 0))); }
 int ba_batch_retried(BaBatch* b) { return b ? (int)b->retried : -1; }
 void ba_batch_destroy(BaBatch* b) { delete b; }
 

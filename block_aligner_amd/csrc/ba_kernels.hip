@@ -88,6 +88,37 @@ extern "C" hipError_t BA_CAT(ba_occupancy_m_k, BA_KIND, _p, BA_PMAX)(int trace, 
 }
 #endif
 
+#if BA_KIND != 3 && !BA_SPECIAL && !BA_BIG && BA_PMAX <= 8
+// sixteen pairs per wave while the block is 32 cells, everything else by the same wave on all its lanes (ba_small.hpp): one kernel per
+// kind and block class (up to 1024 cells: the solo driver's LDS borders fit in the slots' region)
+#include "ba_small.hpp"
+template <bool TRACE, bool XDROP>
+static hipError_t launch_small(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_small<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_small<BA_PMAX, BA_KIND, TRACE, XDROP><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP>
+static hipError_t occ_small(int* blocks_per_cu, unsigned lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_small<BA_PMAX, BA_KIND, TRACE, XDROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_small<BA_PMAX, BA_KIND, TRACE, XDROP>, ba::WAVES_PER_WG * 64, lds);
+}
+extern "C" hipError_t BA_CAT(ba_launch_sm_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch_small<true, true>(grid, lds, s, *bp) : launch_small<true, false>(grid, lds, s, *bp);
+    return xdrop ? launch_small<false, true>(grid, lds, s, *bp) : launch_small<false, false>(grid, lds, s, *bp);
+}
+extern "C" hipError_t BA_CAT(ba_occupancy_sm_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    if (trace) return xdrop ? occ_small<true, true>(blocks_per_cu, lds) : occ_small<true, false>(blocks_per_cu, lds);
+    return xdrop ? occ_small<false, true>(blocks_per_cu, lds) : occ_small<false, false>(blocks_per_cu, lds);
+}
+#endif
+
 #if BA_PMAX == 1 && !BA_SPECIAL && !BA_BIG
 // four pairs per wave while the block is 32 cells (ba_quad.hpp): one kernel per kind
 #include "ba_quad.hpp"
@@ -144,6 +175,12 @@ constexpr int WALK_WAVES = 4;
 __global__ void __launch_bounds__(WALK_WAVES * 64) k_walk(const ba::BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char walk_lds[];
     ba::traceback_all(bp, (uint32_t)ba::F_CIGAR_EQ, walk_lds + ((uint32_t)threadIdx.x >> 6) * ba::TB_LDS_BYTES);
+}
+
+// ... of a k_small batch (slot rectangles: words of 4 cells x 2 columns; the lanes' records are larger)
+__global__ void __launch_bounds__(WALK_WAVES * 64) k_walk_l2(const ba::BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char walk_lds[];
+    ba::traceback_all<true>(bp, (uint32_t)ba::F_CIGAR_EQ, walk_lds + ((uint32_t)threadIdx.x >> 6) * ba::TB_LDS_BYTES_L2);
 }
 
 __global__ void __launch_bounds__(256) k_compact_cigars(const uint32_t* __restrict__ ops, const uint64_t* __restrict__ cig_off,
@@ -264,6 +301,10 @@ extern "C" hipError_t ba_launch_merge_retry(hipStream_t s, const uint32_t* idx, 
 }
 extern "C" hipError_t ba_launch_walk(hipStream_t s, const ba::BatchParams* bp, uint32_t grid) {
     k_walk<<<dim3(grid), dim3(WALK_WAVES * 64), WALK_WAVES * ba::TB_LDS_BYTES, s>>>(*bp);
+    return hipGetLastError();
+}
+extern "C" hipError_t ba_launch_walk_l2(hipStream_t s, const ba::BatchParams* bp, uint32_t grid) {
+    k_walk_l2<<<dim3(grid), dim3(WALK_WAVES * 64), WALK_WAVES * ba::TB_LDS_BYTES_L2, s>>>(*bp);
     return hipGetLastError();
 }
 extern "C" hipError_t ba_launch_traceback(hipStream_t s, const ba::BatchParams* bp) {

@@ -119,6 +119,12 @@ constexpr uint32_t MQ_BUF_BYTES = 4 * 256 + 64, MQ_SLOT_BYTES = 2 * MQ_BUF_BYTES
 // k_multi: while the slots run, the same buffers live in the wave's LDS region (the solo borders' space, which the slots do not need):
 // 4 slots x 2 buffers x 1 KB of borders, then 8 x 9 scalars
 constexpr uint32_t MQ_LDS_SCALARS = 8192, MQ_LDS_BYTES = 8192 + 8 * 36 + 32;
+// k_small (ba_small.hpp): sixteen pairs per wave while the block is 32 cells -- slots of 4 lanes x 8 cells. Per wave and slot in the `big`
+// arena: two state buffers (4 border arrays x 4 lanes x 16 bytes + 8 scalars) and a 128-byte record; while the slots run the buffers live in
+// the wave's LDS region (16 slots x 2 buffers x 256 bytes of borders, then 16 x 2 x 8 scalars)
+constexpr uint32_t SM_B_HOST = 32, SM_SLOTS = 16;
+constexpr uint32_t SM_BUF_BYTES = 4 * 64 + 32, SM_SLOT_BYTES = 2 * SM_BUF_BYTES + 128, SM_WAVE_BYTES = SM_SLOTS * SM_SLOT_BYTES;
+constexpr uint32_t SM_LDS_SCALARS = 8192, SM_LDS_BYTES = 8192 + SM_SLOTS * 2 * 32;
 constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
@@ -128,10 +134,14 @@ BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ?
 BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
 BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > 8512u ? lds_wave_bytes_h(max_size) : 8512u; }   // k_multi (MQ_LDS_BYTES)
 BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * mq_wave_bytes_h(max_size); }
+BA_HD constexpr uint32_t sm_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > SM_LDS_BYTES ? lds_wave_bytes_h(max_size) : SM_LDS_BYTES; }   // k_small
+BA_HD constexpr uint32_t sm_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * sm_wave_bytes_h(max_size); }
 // TRACE batches: one more region behind the waves' for the workgroup's traceback wave (ba_driver.hpp tb_step): per lane
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
 constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;
 constexpr uint32_t TB_LANE_BYTES_L2 = 100;   // k_multi's traceback waves (16 trace words per window): their records sit in the wave's own LDS region   // table first, then the records (a helper fill wave uses one)
+constexpr uint32_t TB_LDS_BYTES_L2 = 6656;   // k_walk over a k_small batch: the move table + 64 records of TB_LANE_BYTES_L2
+static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= TB_LDS_BYTES_L2, "k_walk LDS (slot rectangles)");
 static_assert(MQ_LDS_BYTES <= 8512u && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= 8512u, "k_multi LDS");
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES <= lds_wave_bytes_h(128), "traceback LDS regions");
 

@@ -1,0 +1,611 @@
+// block_aligner_amd — sixteen pairs per wavefront while the block is 32 cells, inside ONE persistent kernel.
+//
+// Batches that start at the reference's usual minimum block size (examples/uc_bench.rs:85-100, pssm_bench.rs:94-100: 32..=256;
+// nanopore_bench.rs at 1 kbp) used to run through k_quad (ba_quad.hpp: four pairs per wave, two cells per lane) and a queue to
+// the per-pair kernel for everything that is not a plain shift step. k_small joins the two ideas of ba_multi.hpp and ba_quad.hpp:
+//   * slots of FOUR lanes x EIGHT cells (multi_rect's column code: the gap scan is an in-lane chain over the lane's four packed
+//     registers followed by a two-step DPP scan inside the quad, border shifts are DPP quad permutes), sixteen pairs per wave;
+//   * a slot takes a pair from the batch by itself, runs its first block (scan_block.rs:260-305 with prev_size = 0) as four right
+//     steps of 8 columns over zeroed borders, then plain shift steps at 32 cells, and finishes a global alignment whose last step
+//     has reached the end of both sequences (scan_block.rs:560-570, 1216-1224) -- all inside the loop of steps;
+//   * whatever else a pair needs -- a grow, the steps at larger block sizes, a shrink, X-drop termination, the early column break
+//     -- is done by the SAME wave in solo mode: the slots' state goes to memory, Aligner::run (ba_driver.hpp: all 64 lanes on that
+//     one pair, the code of the per-pair kernel) takes the pair until it is finished or its next step is again a plain shift step
+//     at 32 cells. No queue, no second launch, no PairCont round trip.
+// As in k_multi a slot keeps no location of its steps' maxima: the state BEFORE the last improving step is the checkpoint (two LDS
+// buffers per slot that change roles), and the solo driver repeats that step once (Aligner::import_slot). A pair whose last
+// improving step is still its first block when it leaves the slot is simply run again from the start by the solo driver.
+// TRACE batches are pair-slot batches (ba_params.h): trace words of a slot's rectangle are 4 cells x 2 columns per word (bit 31 of
+// BlockRec::i), the first block is four records of 32 x 8 cells; k_walk (its L2 form) walks all paths after the fill.
+#pragma once
+#include "ba_multi.hpp"
+
+namespace ba {
+
+constexpr int SM_B = 32, SM_LW = 4, SM_NS = 16;
+enum { MR_FLAGS = MR_WORDS, MR_BOOT, MR_BMX, SM_MR_WORDS };   // flags: bit 0 = run the pair from its start in solo mode
+static_assert(SM_MR_WORDS <= 32 && SM_B == (int)SM_B_HOST && SM_NS == (int)SM_SLOTS, "k_small record");
+
+template <int N>
+__device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(v, v, N | (N << 2) | (N << 4) | (N << 6), 0xf, 0xf, false); }
+// inclusive prefix max inside every quad: quad_perm [0,0,1,2] then [0,1,0,1]
+__device__ __forceinline__ int quad_prefix_max(int v) {
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+// max over the quad, in every lane: [1,0,3,2] then [2,3,0,1]
+__device__ __forceinline__ int quad_all_max(int v) {
+    asm volatile(
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
+// lane l <- src[l - 1] & mask[l] inside the quad (mask = 0 in quad lane 0: nothing above it)
+__device__ __forceinline__ int quad_shr1_and(int src, int mask) {
+    int t;
+    asm volatile("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(src), "v"(mask));
+    return t;
+}
+// lane l <- l == 3 ? last[l] : src[l + 1] inside the quad, for the eight registers of the orthogonal border pair at once (one mask set-up)
+__device__ __forceinline__ void quad_shl1_keep8(int (&d)[4], int (&r)[4], const int (&sd)[4], const int (&sr)[4], const int (&ld)[4], const int (&lr)[4], unsigned long long last_mask) {
+    asm volatile(
+        "s_mov_b64 vcc, %16\n\ts_nop 1\n\t"
+        "v_cndmask_b32_dpp %0, %8, %17, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %9, %18, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %10, %19, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %11, %20, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %4, %12, %21, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %5, %13, %22, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %6, %14, %23, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %7, %15, %24, vcc quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(sd[0]), "v"(sd[1]), "v"(sd[2]), "v"(sd[3]), "v"(sr[0]), "v"(sr[1]), "v"(sr[2]), "v"(sr[3]), "s"(last_mask),
+          "v"(ld[0]), "v"(ld[1]), "v"(ld[2]), "v"(ld[3]), "v"(lr[0]), "v"(lr[1]), "v"(lr[2]), "v"(lr[3])
+        : "vcc");
+}
+
+struct SmallConsts {
+    int G[4];            // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
+    int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g (quad lane 0: 0 -- its candidate is replaced by -32768, see small_rect)
+    int vtop[4];         // per cell: max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column)
+    int nz;              // 0 in quad lane 0, -1 elsewhere
+};
+
+// One 8-column shift step for the sixteen slots of a wave (multi_rect for quads). first_cell: this lane holds cell (0, 0) of a pair's
+// first block (scan_block.rs:1130-1132). fin_any / fin_col / dsel: a global alignment's last step is among the slots: D of column fin_col.
+template <int KIND, bool TRACE, bool FIN>
+__device__ __forceinline__ void small_rect(const char* table, const FillConsts& fc, const SmallConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
+                                           int (&Pd)[4], int (&Pr)[4], uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, bool first_cell,
+                                           uint32_t* __restrict__ tout, bool store, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o) {
+    const int offa = splat(off_add);
+    int d[4], c[4], pd[4], pr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // just_offset (scan_block.rs:1003-1012)
+        d[k] = adds(Ad[k], offa); c[k] = adds(Ac[k], offa); pd[k] = adds(Pd[k], offa); pr[k] = adds(Pr[k], offa);
+    }
+    o.corner_new = quad_bcast<0>(pd[3]) >> 16;   // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based
+    ScoreKey<KIND> key[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t w = k < 2 ? vb.x : vb.y;
+        key[k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
+    }
+    int dmax[4] = {0, 0, 0, 0}, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int nvD[4] = {0, 0, 0, 0}, nvR[4] = {0, 0, 0, 0};   // the last cells of the 8 new columns: the orthogonal border's new entries (quad lane 3)
+    int holdD = 0, holdR = 0;
+#pragma unroll
+    for (int j = 0; j < STEP; j++) {
+        const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
+        int sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sc[k] = fetch_score<KIND>(table, key[k], cb);
+        // D00: the previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
+        int prev = quad_shr1_and(d[3], mc.nz);
+        if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
+        int d00[4];
+        d00[0] = __builtin_amdgcn_alignbit(d[0], prev, 16);
+#pragma unroll
+        for (int k = 1; k < 4; k++) d00[k] = __builtin_amdgcn_alignbit(d[k], d[k - 1], 16);
+        int d11[4], copen[4], cn[4], x[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            d11[k] = adds(d00[k], sc[k]);
+            if (j == 0 && k == 0) d11[0] = first_cell ? (int)(((uint32_t)d11[0] & 0xffff0000u) | (uint32_t)ZERO) : d11[0];   // cell (0,0) starts from the relative zero
+            copen[k] = adds(d[k], fc.go2);
+            cn[k] = vmax(adds(c[k], fc.ge2), copen[k]);
+            d11[k] = vmax(d11[k], cn[k]);
+            x[k] = adds(d11[k], fc.ome2);                                  // D11_open
+            r[k] = vmax(x[k], splat_lo(adds(x[k], fc.ge2)));               // inside the register
+        }
+        // R11: the chain over the lane's registers, then a scan over the quad's four lanes on values re-based by l * 8g
+#pragma unroll
+        for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(splat_hi(r[k - 1]), mc.G[0]));
+        const int pm = quad_prefix_max((int)as_s(r[3]).y - mc.laneKG);
+        // R of the lane above's last cell; quad lane 0 has no lane above: a candidate that never wins
+        int cin = __builtin_amdgcn_update_dpp(pm, pm, 0x90, 0xf, 0xf, false) + mc.lanem1KG;
+        cin = l == 0 ? -32768 : cin;
+        const int cs = splat_lo(cin);
+        int dn[4];
+        uint32_t sC[4], sR[4], sCo[4], sRo[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), mc.vtop[k]);
+            dn[k] = vmax(d11[k], r[k]);
+            if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect); packed below, two registers at a time
+                sC[k] = (uint32_t)subs(cn[k], dn[k]); sR[k] = (uint32_t)subs(r[k], dn[k]); sCo[k] = (uint32_t)subs(copen[k], cn[k]); sRo[k] = (uint32_t)subs(x[k], r[k]);
+            }
+            dmax[k] = vmax(dmax[k], dn[k]);
+            d[k] = dn[k]; c[k] = cn[k];
+        }
+        if (FIN && fin_any) {   // (wave-uniform branch)
+#pragma unroll
+            for (int k = 0; k < 4; k++) dsel[k] = fin_col == (uint32_t)j ? dn[k] : dsel[k];
+        }
+        if (TRACE) {   // trace words: see multi_rect (4 consecutive cells x 2 columns per word, a lane's eight words contiguous)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; p2++) {
+                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[2 * p2 + 1], (int)sC[2 * p2], 0x07050301), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[2 * p2 + 1], (int)sR[2 * p2], 0x07050301);
+                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[2 * p2 + 1], (int)sCo[2 * p2], 0x07050301), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[2 * p2 + 1], (int)sRo[2 * p2], 0x07050301);
+                const uint32_t hi2 = bfi(0x80808080u, pRo, pCo >> 1), lo2 = bfi(0x80808080u, pR, pC >> 1);
+                const uint32_t nib = bfi(0xC0C0C0C0u, hi2, lo2 >> 2);   // bits 7..4 of every byte
+                if (j & 1) tacc[2 * (j >> 1) + p2] = (int)bfi(0xF0F0F0F0u, nib, (uint32_t)tacc[2 * (j >> 1) + p2]);
+                else tacc[2 * (j >> 1) + p2] = (int)(nib >> 4);
+            }
+        }
+        // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
+        if (j & 1) { nvD[j >> 1] = __builtin_amdgcn_perm(dn[3], holdD, 0x07060302); nvR[j >> 1] = __builtin_amdgcn_perm(r[3], holdR, 0x07060302); }
+        else { holdD = dn[3]; holdR = r[3]; }
+    }
+    if (TRACE) {
+        if (store) { *(int4*)tout = int4{tacc[0], tacc[1], tacc[2], tacc[3]}; *(int4*)(tout + 4) = int4{tacc[4], tacc[5], tacc[6], tacc[7]}; }
+    }
+    // shift_and_offset (scan_block.rs:1040-1061): 8 entries = one lane
+    quad_shl1_keep8(Pd, Pr, pd, pr, nvD, nvR, 0x8888888888888888ull);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { Ad[k] = d[k]; Ac[k] = c[k]; }
+    {   // max of the first 8 entries of both borders (quad lane 0), to every lane of the slot (scan_block.rs:1020-1022)
+        const int ma = vmax(vmax(d[0], d[1]), vmax(d[2], d[3])), mb = vmax(vmax(Pd[0], Pd[1]), vmax(Pd[2], Pd[3]));
+        const s16x2 sa = as_s(ma), sb = as_s(mb);
+        const int xa = vmax(ma, as_i(s16x2{sa.y, sa.x})), xb = vmax(mb, as_i(s16x2{sb.y, sb.x}));
+        const s16x2 rr = as_s(quad_bcast<0>(__builtin_amdgcn_perm(xb, xa, 0x05040100)));
+        o.act_max8 = rr.x; o.pas_max8 = rr.y;
+    }
+    const int mm = vmax(vmax(dmax[0], dmax[1]), vmax(dmax[2], dmax[3]));
+    const int m32 = max(mm & 0xffff, (int)((uint32_t)mm >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
+    o.mx = quad_all_max(m32);
+}
+
+template <int PMAX, int KIND, bool TRACE, bool XDROP>
+__global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_small(const BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), l = lane & (SM_LW - 1), g = lane >> 2;
+    const int wave = uni((int)threadIdx.x >> 6);
+    {   // workgroup-shared scoring table, as in k_align
+        char* tab = smem;
+        if (KIND == KIND_NUC) {
+            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
+                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
+                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
+            }
+        } else {
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
+        }
+    }
+    __syncthreads();
+    constexpr uint32_t LCLS = (uint32_t)PMAX * 128u;
+    constexpr uint32_t ab = lds_array_bytes_h(LCLS);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * sm_wave_bytes_h(LCLS);
+    WaveLds L;
+    L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
+    L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
+    L.misc = (short*)(base + 4 * ab);
+    L.table = smem;
+    const int gx = bp.gap_extend;
+    const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
+    const uint32_t max_size = bp.max_size;
+    const bool keep_pre = XDROP || (uint32_t)SM_B < max_size;   // a slot keeps the state before its last improving step
+    char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * SM_WAVE_BYTES;
+
+    // (values derived again after the per-pair driver instead of being kept across it: laundered so that they are not hoisted)
+    auto coldp_big = [&]() { const __attribute__((address_space(4))) BatchParams* p = (const __attribute__((address_space(4))) BatchParams*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p->big; };
+    auto fill_wave_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); return b * WAVES_PER_WG + w; };
+    uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
+    uint32_t w_next = 0, w_end = 0;
+    bool more = true;
+
+    for (;;) {
+        // ================= solo mode: the pairs whose step was rolled back (or that a slot cannot take), one at a time on all 64 lanes
+        while (pend_m) {
+            int solo = __builtin_ctz(pend_m);
+            FillConsts fc;   // two cells per lane (as k_align)
+            {
+                fc.gap_extend = gx;
+                fc.go2 = splat(bp.gap_open); fc.ge2 = splat(gx); fc.ome2 = splat(clamp16(bp.gap_open - gx));
+                fc.g12 = pk(gx, 2 * gx);
+                fc.ones = 0x00010001;
+                fc.laneKG = lane * 2 * gx; fc.lanem1KG = lane ? (lane - 1) * 2 * gx : -32768;
+                int v[2];
+                for (int h = 0; h < 2; h++) {
+                    const int k = (2 * lane + h) & 15;
+                    const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
+                    v[h] = mult ? max(-32768, mult * gx) : -32768;
+                }
+                fc.vconst = pk(v[0], v[1]);
+                fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
+            }
+            Aligner<PMAX, KIND, TRACE, XDROP, false, true, SM_B> al(bp, L, fc);
+            PairState st{};
+            char* const smem_s = wave_mem + (uint32_t)solo * SM_SLOT_BYTES;
+            char* const rec = smem_s + 2 * SM_BUF_BYTES;
+            const int rv = lane < SM_MR_WORDS ? mq_load(rec + 4 * lane) : 0;   // the slot's record: lane k holds word k
+#define BA_W(v, k) __builtin_amdgcn_readlane(v, k)
+            uint32_t s_pair = (uint32_t)BA_W(rv, MR_PAIR);
+            bool fresh = (BA_W(rv, MR_FLAGS) & 1) != 0;
+            if (!fresh) {
+                const uint32_t s_sel = (uint32_t)BA_W(rv, MR_SEL);
+                const char* live_b = smem_s + (s_sel ^ 1u) * SM_BUF_BYTES; const char* ck_b = smem_s + s_sel * SM_BUF_BYTES;
+                const int cv = lane < 8 ? mq_load(ck_b + 256 + 4 * lane) : 0;   // the checkpoint's scalars
+                const int flag = BA_W(cv, 0) & 0xff;
+                if (flag == 2 && keep_pre) fresh = true;   // the last improving step is still the first block: once more from the start
+                else {
+                    st.si = (uint32_t)BA_W(rv, MR_SI); st.sj = (uint32_t)BA_W(rv, MR_SJ); st.dir = BA_W(rv, MR_DIR); st.prev_dir = BA_W(rv, MR_PREV_DIR);
+                    st.off = BA_W(rv, MR_OFF); st.off_max = BA_W(rv, MR_OFF_MAX); st.best_max = BA_W(rv, MR_BEST_MAX);
+                    st.y_drop_iter = (uint32_t)BA_W(rv, MR_Y_DROP); st.x_drop_iter = BA_W(rv, MR_X_ITER); st.D_corner = BA_W(rv, MR_D_CORNER);
+                    st.trace_top = (uint32_t)BA_W(rv, MR_TRACE_TOP); st.nblocks = (uint32_t)BA_W(rv, MR_NBLOCKS);
+                    const uint32_t ns = (uint32_t)BA_W(rv, MR_NSTEPS);
+                    st.best_i = (uint32_t)BA_W(rv, MR_BEST_I); st.best_j = (uint32_t)BA_W(rv, MR_BEST_J);
+                    st.cells = ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_LO) | ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_HI) << 32)) + (unsigned long long)ns * (STEP * SM_B);
+                    const uint32_t bud = (uint32_t)BA_W(rv, MR_BUDGET);
+                    st.step_budget = bud > ns ? bud - ns : 1u;
+                    st.status = (uint32_t)BA_W(rv, MR_STATUS);
+                    const bool ck_pre = flag != 0;
+                    st.ck_i = (uint32_t)BA_W(cv, 1); st.ck_j = (uint32_t)BA_W(cv, 2); st.ck_off = BA_W(cv, 3);
+                    st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * SM_B / 8 : 0u); st.ck_nb = (uint32_t)BA_W(cv, 5) + (flag ? 1u : 0u);
+                    const int ck_dir = (BA_W(cv, 0) >> 8) & 0xff, ck_offadd = BA_W(cv, 6), ck_corner = BA_W(cv, 7);
+                    {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 3), into the canonical order D_col, C_col, D_row, R_row
+                        int reg[16], ckr[16];
+                        const bool lr = st.dir == DIR_RIGHT, cr = ck_dir == DIR_RIGHT;
+                        const uint32_t oAd = (lr ? 0u : 128u) + l * 16, oAc = (lr ? 64u : 192u) + l * 16, oPd = (lr ? 128u : 0u) + l * 16, oPr = (lr ? 192u : 64u) + l * 16;
+                        const uint32_t cAd = (cr ? 0u : 128u) + l * 16, cAc = (cr ? 64u : 192u) + l * 16, cPd = (cr ? 128u : 0u) + l * 16, cPr = (cr ? 192u : 64u) + l * 16;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            reg[k] = mq_load(live_b + oAd + 4 * k); reg[4 + k] = mq_load(live_b + oAc + 4 * k); reg[8 + k] = mq_load(live_b + oPd + 4 * k); reg[12 + k] = mq_load(live_b + oPr + 4 * k);
+                            ckr[k] = mq_load(ck_b + cAd + 4 * k); ckr[4 + k] = mq_load(ck_b + cAc + 4 * k); ckr[8 + k] = mq_load(ck_b + cPd + 4 * k); ckr[12 + k] = mq_load(ck_b + cPr + 4 * k);
+                        }
+                        al.import_slot(reg, ckr, s_pair, ck_pre || (uint32_t)SM_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j);
+                    }
+                }
+            }
+#undef BA_W
+            if (TRACE) { al.trace = bp.trace_arena + bp.trace_off[s_pair]; al.blocks = bp.blocks + bp.blocks_off[s_pair]; }
+            else { al.trace = bp.trace_arena; al.blocks = bp.blocks; }
+            al.ckpt = bp.ckpt + (uint64_t)(fill_wave + bp.ckpt_wave0) * 8 * bp.max_size;
+            // The per-pair driver needs every scalar register: what the wave keeps across it is parked in the lanes of one VGPR
+            int keepv = 0;
+            park<0>(keepv, (int)live_m); park<1>(keepv, (int)pend_m); park<2>(keepv, (int)w_next); park<3>(keepv, (int)w_end);
+            park<4>(keepv, (more ? 1 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair);
+            // (a pair in solo mode keeps the wave's other fifteen slots waiting: its dependent chain goes first among the SIMD's waves)
+            __builtin_amdgcn_s_setprio(MQ_SOLO_PRIO);
+            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, true, !fresh);
+            __builtin_amdgcn_s_setprio(0);
+            live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
+            more = unpark<4>(keepv) & 1; solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv);
+            char* const smem_s2 = (char*)coldp_big() + (uint64_t)fill_wave_of() * SM_WAVE_BYTES + (uint32_t)solo * SM_SLOT_BYTES;
+            char* const rec2 = smem_s2 + 2 * SM_BUF_BYTES;
+            pend_m &= ~(1u << solo);
+            if (st.exited) {   // the pair's next step is a plain shift step at 32 cells: into the slot (its memory)
+                const bool rgt = st.dir == DIR_RIGHT;
+                if (lane < SM_LW) {
+                    const int l8 = 8 * l;
+                    const int4 a_d = *(const int4*)((rgt ? L.D_col : L.D_row) + l8), a_c = *(const int4*)((rgt ? L.C_col : L.R_row) + l8);
+                    const int4 p_d = *(const int4*)((rgt ? L.D_row : L.D_col) + l8), p_r = *(const int4*)((rgt ? L.R_row : L.C_col) + l8);
+                    char* b1 = smem_s2 + SM_BUF_BYTES;   // the state at the top of the loop: buffer 1 (sel = 0)
+                    *(int4*)(b1 + l * 16) = a_d; *(int4*)(b1 + 64 + l * 16) = a_c; *(int4*)(b1 + 128 + l * 16) = p_d; *(int4*)(b1 + 192 + l * 16) = p_r;
+                    if ((uint32_t)SM_B < max_size) {   // the checkpoint as the reference keeps it (after its step): buffer 0
+                        char* b0 = smem_s2;
+                        *(int4*)(b0 + l * 16) = *(const int4*)(L.D_col + SM_B + l8); *(int4*)(b0 + 64 + l * 16) = *(const int4*)(L.C_col + SM_B + l8);
+                        *(int4*)(b0 + 128 + l * 16) = *(const int4*)(L.D_row + SM_B + l8); *(int4*)(b0 + 192 + l * 16) = *(const int4*)(L.R_row + SM_B + l8);
+                    }
+                }
+                if (is_lane(0)) {
+                    char* b0 = smem_s2;
+                    *(int4*)(b0 + 256) = int4{0 | (DIR_RIGHT << 8), (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + 272) = int4{(int)st.ck_tt, (int)st.ck_nb, 0, 0};
+                    int* rc = (int*)rec2;
+                    rc[MR_PAIR] = (int)s_pair; rc[MR_BEST_I] = (int)st.best_i; rc[MR_BEST_J] = (int)st.best_j; rc[MR_CELLS_LO] = (int)(uint32_t)st.cells; rc[MR_CELLS_HI] = (int)(uint32_t)(st.cells >> 32);
+                    rc[MR_BUDGET] = (int)st.step_budget; rc[MR_STATUS] = (int)st.status; rc[MR_TSLOT] = (int)s_pair; rc[MR_SI] = (int)st.si; rc[MR_SJ] = (int)st.sj; rc[MR_DIR] = st.dir;
+                    rc[MR_PREV_DIR] = st.prev_dir; rc[MR_OFF] = st.off; rc[MR_OFF_MAX] = st.off_max; rc[MR_BEST_MAX] = st.best_max; rc[MR_Y_DROP] = (int)st.y_drop_iter;
+                    rc[MR_X_ITER] = st.x_drop_iter; rc[MR_D_CORNER] = st.D_corner; rc[MR_NSTEPS] = 0; rc[MR_TRACE_TOP] = (int)st.trace_top; rc[MR_NBLOCKS] = (int)st.nblocks; rc[MR_SEL] = 0;
+                    rc[MR_FLAGS] = 0; rc[MR_BOOT] = 0; rc[MR_BMX] = 0;
+                }
+                lds_sync();
+                live_m |= 1u << solo;
+            } else live_m &= ~(1u << solo);
+        }
+        if (!live_m && !more) break;
+
+        // ================= the slots: registers from memory, steps until a slot needs solo mode (or the batch is done), registers to memory
+        {
+            char* const slot_mem = wave_mem + (uint32_t)g * SM_SLOT_BYTES;   // this lane's slot
+            const int x_drop = bp.x_drop;
+            const uint32_t total = bp.n;
+            FillConsts fq;   // only the three gap constants (wave-uniform)
+            fq.go2 = splat(bp.gap_open); fq.ge2 = splat(gx); fq.ome2 = splat(clamp16(bp.gap_open - gx));
+            SmallConsts mc;  // eight cells per lane
+            mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : 0; mc.nz = l ? -1 : 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+                int t[2];
+                for (int h = 0; h < 2; h++) {
+                    const int cell = 8 * l + 2 * k + h, k16 = cell & 15;
+                    const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
+                    const int art = mult ? max(-32768, mult * gx) : -32768;
+                    t[h] = max(art, max(-32768, (cell + 1) * gx));
+                }
+                mc.vtop[k] = pk(t[0], t[1]);
+            }
+            // ---- slot state (row-uniform, replicated over the slot's lanes)
+            const bool live0 = (live_m >> g) & 1u;
+            const char* rec = slot_mem + 2 * SM_BUF_BYTES;
+#define BA_R(k) (live0 ? mq_load(rec + 4 * (k)) : 0)
+            uint32_t pair = live0 ? (uint32_t)mq_load(rec + 4 * MR_PAIR) : ~0u;
+            uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ), y_drop = (uint32_t)BA_R(MR_Y_DROP), nsteps = (uint32_t)BA_R(MR_NSTEPS);
+            uint32_t trace_top = (uint32_t)BA_R(MR_TRACE_TOP), nblocks = (uint32_t)BA_R(MR_NBLOCKS), sel = (uint32_t)BA_R(MR_SEL);
+            uint32_t flags = (uint32_t)BA_R(MR_FLAGS), boot = (uint32_t)BA_R(MR_BOOT);
+            int dir = BA_R(MR_DIR), prev_dir = BA_R(MR_PREV_DIR), off = BA_R(MR_OFF), off_max = BA_R(MR_OFF_MAX), best_max = BA_R(MR_BEST_MAX);
+            int x_iter = BA_R(MR_X_ITER), D_corner = BA_R(MR_D_CORNER), bmx = BA_R(MR_BMX);
+#undef BA_R
+            uint32_t qlen = live0 ? bp.q_len[pair] : 0u, rlen = live0 ? bp.r_len[pair] : 0u;
+            const uint8_t* qp = bp.pool + (live0 ? bp.q_off[pair] : 0ull); const uint8_t* rp = bp.pool + (live0 ? bp.r_off[pair] : 0ull);
+            uint32_t* tr = bp.trace_arena; BlockRec* bl = bp.blocks; uint32_t tcap = 0, bcap = 0;
+            if (TRACE && live0) {
+                const uint64_t t0 = bp.trace_off[pair], b0 = bp.blocks_off[pair];
+                tr = bp.trace_arena + t0; bl = bp.blocks + b0;
+                tcap = (uint32_t)min(bp.trace_off[pair + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[pair + 1] - b0, (uint64_t)0x7fffffffu);
+            }
+            int A_d[4], A_c[4], P_d[4], P_r[4];   // borders: (A) along the vector axis of the step at `dir`, (P) orthogonal
+            {
+                const char* b = slot_mem + (sel ^ 1u) * SM_BUF_BYTES + l * 16;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    A_d[k] = live0 ? mq_load(b + 4 * k) : 0; A_c[k] = live0 ? mq_load(b + 64 + 4 * k) : 0;
+                    P_d[k] = live0 ? mq_load(b + 128 + 4 * k) : 0; P_r[k] = live0 ? mq_load(b + 192 + 4 * k) : 0;
+                }
+            }
+            // While the slots run, the two buffers of every slot live in this wave's LDS region (the solo borders' space): the checkpoint
+            // (buffer `sel`) comes from the arena now and goes back after the loop; the other one is rewritten before every step.
+            char* const lbuf = base + (uint32_t)g * 512u;                        // this slot's buffers: + which * 256
+            int* const lsc = (int*)(base + SM_LDS_SCALARS) + (uint32_t)g * 16u;   // their scalars: + which * 8
+            lds_sync();
+            if (live0) {
+                const char* cb = slot_mem + sel * SM_BUF_BYTES;
+                char* d = lbuf + sel * 256u + l * 16;
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const char* sp = cb + a * 64 + l * 16;
+                    *(int4*)(d + a * 64) = int4{mq_load(sp), mq_load(sp + 4), mq_load(sp + 8), mq_load(sp + 12)};
+                }
+                lsc[sel * 8u + l] = mq_load(cb + 256 + 4 * l); lsc[sel * 8u + 4 + l] = mq_load(cb + 272 + 4 * l);
+            }
+            lds_sync();
+            // sequence bytes of the next step, fetched one step ahead for both possible directions
+            uint2 pf_qv = {0, 0}, pf_rv = {0, 0}, pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
+            bool leave = false;
+            // the slot's registers and the scalars of the step at the top into the buffer `which` (see ba_multi.hpp)
+            auto stage = [&](uint32_t which, int s_flag, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
+                char* b = lbuf + which * 256u + l * 16;
+                *(int4*)(b) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + 64) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
+                *(int4*)(b + 128) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 192) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
+                if (l == 0) {
+                    int* sc = lsc + which * 8u;
+                    *(int4*)sc = int4{s_flag | (s_dir << 8), (int)s_i, (int)s_j, s_off}; *(int4*)(sc + 4) = int4{(int)s_tt, (int)s_nb, s_offadd, s_corner};
+                }
+            };
+            constexpr uint32_t NBOOT = SM_B / STEP;
+            for (;;) {
+                // ---- idle slots take the next pairs of the batch; a pair starts here, with its first block (boot sub-steps, as in k_quad).
+                // Pairs shorter than a block in either dimension are the solo driver's from the start.
+                while (more && __any(pair == ~0u)) {
+                    if (w_next == w_end) {
+                        uint32_t v = 0;
+                        if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
+                        w_next = (uint32_t)uni((int)v);
+                        if (w_next >= total) { more = false; w_next = w_end = 0; break; }
+                        w_end = min(w_next + bp.work_chunk, total);
+                    }
+                    const bool idle = pair == ~0u;
+                    const unsigned long long im = __ballot(idle && l == 0);   // the idle slots, in slot order, take consecutive positions
+                    const uint32_t rank = (uint32_t)__popcll(im & ((1ull << (g * SM_LW)) - 1ull));
+                    const uint32_t take = min((uint32_t)__popcll(im), w_end - w_next);
+                    const uint32_t idx = w_next + rank;
+                    w_next += take;
+                    if (idle && rank < take) {
+                        pair = idx;
+                        qlen = bp.q_len[idx]; rlen = bp.r_len[idx];
+                        flags = (qlen < (uint32_t)SM_B || rlen < (uint32_t)SM_B) ? 1u : 0u;
+                        // the state Block::align starts from (scan_block.rs:123-146), seen as four right steps of 8 columns that end
+                        // with the block at (0, 0): borders MIN = 0, no offset yet
+                        si = 0; sj = (uint32_t)-(SM_B - STEP); dir = DIR_RIGHT; prev_dir = DIR_GROW; off = 0; off_max = 0; best_max = 0;
+                        y_drop = 0; x_iter = 0; D_corner = 0; nsteps = 0; trace_top = 0; nblocks = 0; sel = 0; boot = NBOOT; bmx = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { A_d[k] = 0; A_c[k] = 0; P_d[k] = 0; P_r[k] = 0; }
+                        qp = bp.pool + bp.q_off[idx]; rp = bp.pool + bp.r_off[idx];
+                        if (TRACE) {
+                            const uint64_t t0 = bp.trace_off[idx], b0 = bp.blocks_off[idx];
+                            tr = bp.trace_arena + t0; bl = bp.blocks + b0;
+                            tcap = (uint32_t)min(bp.trace_off[idx + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[idx + 1] - b0, (uint64_t)0x7fffffffu);
+                        }
+                        if (l == 0) {   // what the record holds besides the loop's state
+                            int* rc = (int*)(slot_mem + 2 * SM_BUF_BYTES);
+                            rc[MR_PAIR] = (int)idx; rc[MR_BEST_I] = 0; rc[MR_BEST_J] = 0; rc[MR_CELLS_LO] = 0; rc[MR_CELLS_HI] = 0;
+                            rc[MR_BUDGET] = (int)(64u * ((qlen + rlen) / STEP + 64u)); rc[MR_STATUS] = 0; rc[MR_TSLOT] = (int)idx;
+                        }
+                        pf_ok = false;
+                    }
+                }
+                const bool live = pair != ~0u;
+                if (!__any(live)) break;
+
+                // ---- the step every live slot is about to take (scan_block.rs:147-246)
+                const bool right = dir == DIR_RIGHT;
+                const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (SM_B - STEP);
+                const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
+                const bool q_out = si + SM_B > qlen, r_out = sj + SM_B > rlen;
+                // a step that could break early at the matrix edge (vectors past the end of their sequence and a column at or past the end of
+                // the other; never with X-drop) is not a slot's -- except the step that ends a global alignment (`fin` below)
+                bool elig = XDROP || ri + SM_B <= lenV || rj + STEP <= lenC || (boot == 0 && q_out && r_out);
+                if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * SM_B / 8) + 64 <= tcap;   // (a step that would not fit is the solo driver's to report)
+                leave = live && (!elig || (flags & 1u));
+                if (leave && boot) flags |= 1u;   // (a first block cut short: once more from the start)
+                const bool run = live && !leave;
+                const int off_n = off_max;
+                const int off_add = sat16(off - off_n);
+                const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
+                // the state before the step: for a slot that leaves (its registers do not survive the step) and for the checkpoint
+                if (live) stage(sel ^ 1u, boot ? 2 : 1, si, sj, off_n, trace_top, nblocks, dir, off_add, corner);
+                uint2 vb, cbv;
+                {
+                    const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
+                    vb = right ? pf_qv : pf_rv; cbv = right ? pf_rc : pf_qc;
+                    if (__any(run && !pf_ok)) {   // a slot that has just taken its pair (back)
+                        if (run && !pf_ok) {
+                            const uint32_t* vp = (const uint32_t*)(Vp + ri + 8 * l);   // (images are 4-byte aligned, positions multiples of 8)
+                            vb.x = vp[0]; vb.y = vp[1];
+                            const uint32_t* cp = (const uint32_t*)(Cp + rj);
+                            cbv.x = cp[0]; cbv.y = cp[1];
+                        }
+                    }
+                    asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
+                    if (run) {                                    // for the step after this one, whichever way it goes
+                        const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);   // (first block: sj is not a position yet)
+                        const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));   // (32-bit sum: sj is "negative" during the first block)
+                        pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
+                        pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
+                        pf_ok = true;
+                    }
+                }
+                uint32_t* tw = nullptr;
+                if (TRACE) {
+                    tw = tr + trace_top + 8 * l;
+                    if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,284); the first block: four records
+                        BlockRec br;
+                        br.i = (right ? ri : rj) | 0x80000000u;   // (bit 31: words of 4 cells x 2 columns, see multi_rect)
+                        br.j = right ? rj : ri; br.h = (uint16_t)(right ? SM_B : STEP); br.w = (uint16_t)(right ? STEP : SM_B);
+                        br.trace_base = trace_top | (right ? 0x80000000u : 0u);
+                        bl[nblocks] = br;
+                    }
+                }
+                const bool fin = !XDROP && run && boot == 0 && q_out && r_out;   // the last step of a global alignment
+                const bool fin_any = !XDROP && __any(fin);
+                const uint32_t fin_col = lenC - rj;   // its last computed column (0 .. 7: columns rj .. lenC)
+                int dsel[4] = {0, 0, 0, 0};
+                MultiOut o;
+                small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw, run,
+                                                fin_any, fin ? fin_col : 8u, dsel, o);
+                if (boot) {   // the first block's maximum so far
+                    bmx = boot == NBOOT ? o.mx : max(bmx, o.mx);
+                    o.mx = bmx;
+                }
+                const bool bsub = run && boot > 1, blast = run && boot == 1;
+
+                // ---- what does the step call for? (scan_block.rs:332-558; nothing is committed yet)
+                const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
+                const int new_off_max = off_n + o.mx - ZERO;
+                const bool improve = new_off_max > best_max;
+                const uint32_t new_y = improve ? 0u : y_drop + 1;
+                bool stop = q_out && r_out;                                                                   // end of the matrix
+                if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
+                stop = stop || (!q_out && !r_out && 2 * (uint32_t)SM_B <= max_size && new_y > SM_B / STEP - 1);   // grow
+                // the first block: no decisions between its sub-steps; after the last one anything but a plain shift step (an empty improvement --
+                // the driver would grow at once --, the end of the matrix) sends the pair to the solo driver, from its start
+                const bool again = blast && (stop || !improve);
+                const bool commit = run && !stop && !bsub && !again;
+                if (!XDROP && fin_any) {
+                    // The last step of a global alignment: its columns stop at the end of the column sequence (scan_block.rs:1216-1224; the trace
+                    // index still advances over the whole rectangle), the score is the vector border's entry at the end of the vector sequence
+                    // after the last computed column (scan_block.rs:560-570). The pair is complete: results are written here.
+                    const uint32_t idx = lenV - ri;         // 0 .. 31: both ends are inside the block
+                    const uint32_t kreg = (idx >> 1) & 3u;
+                    const int dv = kreg == 0 ? dsel[0] : (kreg == 1 ? dsel[1] : (kreg == 2 ? dsel[2] : dsel[3]));
+                    const int v = __builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & ~3u) + (idx >> 3)) << 2, dv);
+                    const int sc16 = (idx & 1) ? v >> 16 : (int)(short)v;
+                    if (fin && l == 0) {
+                        const char* rcp = slot_mem + 2 * SM_BUF_BYTES;
+                        const unsigned long long cells0 = (unsigned long long)(uint32_t)mq_load(rcp + 4 * MR_CELLS_LO) | ((unsigned long long)(uint32_t)mq_load(rcp + 4 * MR_CELLS_HI) << 32);
+                        bp.score[pair] = off_n + sc16 - ZERO; bp.query_idx[pair] = qlen; bp.reference_idx[pair] = rlen;
+                        if (bp.cells) bp.cells[pair] = cells0 + (unsigned long long)nsteps * (STEP * SM_B) + (unsigned long long)(fin_col + 1u) * SM_B;
+                        if (bp.status) bp.status[pair] = (uint32_t)mq_load(rcp + 4 * MR_STATUS);
+                        if (bp.nblocks_out) bp.nblocks_out[pair] = TRACE ? nblocks + 1 : 0;
+                        if (bp.trace_words_out) bp.trace_words_out[pair] = TRACE ? trace_top + STEP * SM_B / 8 : 0;
+                        if (bp.slot_out) bp.slot_out[pair] = pair;
+                        if (TRACE) bp.slot_info[pair] = SlotInfo{pair, nblocks + 1, qlen, rlen};
+                    }
+                    if (fin) pair = ~0u;
+                }
+                if (again) flags |= 1u;
+                leave = leave || again || (run && stop && !bsub && !blast && !fin);   // rolled back: the pair's state is what was staged before this step
+                if (bsub) {
+                    sj += STEP; nsteps++; boot--;
+                    if (TRACE) { trace_top += STEP * SM_B / 8; nblocks++; }
+                }
+                if (commit) {
+                    if (improve) {
+                        if (keep_pre) sel ^= 1u;   // the state staged before this step is the checkpoint now (and yields the location of the maximum)
+                        best_max = new_off_max;
+                    }
+                    off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = blast ? DIR_GROW : dir; D_corner = blast ? 0 : o.corner_new;
+                    nsteps++; boot = 0;
+                    if (TRACE) { trace_top += STEP * SM_B / 8; nblocks++; }
+                    if (XDROP) x_iter = (off_max < best_max - x_drop) ? x_iter + 1 : 0;
+                    const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
+                    si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
+                    const int ndir = go_down ? DIR_DOWN : DIR_RIGHT;
+                    if (ndir != dir) {   // the borders change roles with the direction
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int td = A_d[k], tc = A_c[k];
+                            A_d[k] = P_d[k]; A_c[k] = P_r[k]; P_d[k] = td; P_r[k] = tc;
+                        }
+                    }
+                    dir = ndir;
+                }
+                if (__any(leave)) break;
+            }
+            // ---- every slot's state at the top of the loop to memory: the registers of the slots that took the step (the others'
+            // was staged before it)
+            const bool live = pair != ~0u;
+            if (live && !leave) stage(sel ^ 1u, boot ? 2 : 1, si, sj, 0, trace_top, nblocks, dir, 0, 0);
+            lds_sync();
+            if (live) {   // both buffers back to the arena (solo mode needs the LDS region, and reads a pair's state from the arena)
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const char* sp = lbuf + w * 256 + l * 16;
+                    char* d = slot_mem + w * SM_BUF_BYTES + l * 16;
+#pragma unroll
+                    for (int a = 0; a < 4; a++) *(int4*)(d + a * 64) = *(const int4*)(sp + a * 64);
+                    *(int*)(slot_mem + w * SM_BUF_BYTES + 256 + 4 * l) = lsc[w * 8 + l]; *(int*)(slot_mem + w * SM_BUF_BYTES + 272 + 4 * l) = lsc[w * 8 + 4 + l];
+                }
+            }
+            lds_sync();
+            if (live && l == 0) {
+                int* rc = (int*)(slot_mem + 2 * SM_BUF_BYTES);
+                rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = prev_dir; rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
+                rc[MR_Y_DROP] = (int)y_drop; rc[MR_X_ITER] = x_iter; rc[MR_D_CORNER] = D_corner; rc[MR_NSTEPS] = (int)nsteps; rc[MR_TRACE_TOP] = (int)trace_top;
+                rc[MR_NBLOCKS] = (int)nblocks; rc[MR_SEL] = (int)sel; rc[MR_FLAGS] = (int)flags; rc[MR_BOOT] = (int)boot; rc[MR_BMX] = bmx;
+            }
+            const unsigned long long lm = __ballot(leave && l == 0), vm = __ballot(live && l == 0);
+            pend_m = 0; live_m = 0;
+#pragma unroll
+            for (int s = 0; s < SM_NS; s++) { pend_m |= (uint32_t)((lm >> (s * SM_LW)) & 1ull) << s; live_m |= (uint32_t)((vm >> (s * SM_LW)) & 1ull) << s; }
+        }
+    }
+}
+
+}  // namespace ba

@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
         L.ba_batch_retried.argtypes = [vp]
         L.ba_device_memory.argtypes = [vp, vp]
         L.ba_batch_info.argtypes = [vp, vp]
+        L.ba_batch_kernel.argtypes = [vp]
         L.ba_batch_destroy.argtypes = [vp]
         L.ba_multibatch_create.restype = vp
         L.ba_multibatch_create.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, u32, vp, vp, vp, vp, vp, sz, vp, C.c_int]
@@ -446,10 +447,13 @@ class BatchAligner:
         """Pairs the last run re-ran with full-size trace slots (ba_batch_retried)."""
         return lib().ba_batch_retried(self._h)
 
+    KERNELS = ("k_align", "k_multi", "k_quad", "k_small")
+
     def info(self):
         o = np.zeros(4, np.uint64)
         lib().ba_batch_info(self._h, o.ctypes.data)
-        return dict(grid=int(o[0]), lds_bytes_per_wave=int(o[1]), trace_arena_bytes=int(o[2]), pool_bytes=int(o[3]))
+        return dict(grid=int(o[0]), lds_bytes_per_wave=int(o[1]), trace_arena_bytes=int(o[2]), pool_bytes=int(o[3]),
+                    kernel=self.KERNELS[lib().ba_batch_kernel(self._h)])
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:

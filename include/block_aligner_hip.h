@@ -237,6 +237,9 @@ int ba_batch_compact_cigars(BaBatch* batch, uint32_t* pinned_out, uint64_t pinne
 int ba_batch_surviving_cells(BaBatch* batch, uint64_t* cells);
 /* Facts about the launch: out[0] grid (resident waves), [1] LDS bytes per wave, [2] trace arena bytes, [3] padded pool bytes */
 int ba_batch_info(BaBatch* batch, uint64_t out[4]);
+/* Which fill kernel the batch's launches use: 0 the per-pair kernel (k_align), 1 four pairs per wave at 128 cells (k_multi), 2 the round-2/3
+ * small-block pipeline (k_quad + queue; profile batches), 3 sixteen pairs per wave at 32 cells (k_small). -1 for a null batch. */
+int ba_batch_kernel(BaBatch* batch);
 /* Large TRACE batches size their trace slots for the expected stack, not for the reference's worst case (Trace::new,
  * scan_block.rs:1363-1366); pairs that outgrow a slot are re-run with full-size slots inside ba_batch_run / ba_batch_wait.
  * Number of pairs the last run re-ran (results are identical either way; -1 for a null batch). */

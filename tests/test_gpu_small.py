@@ -1,0 +1,99 @@
+"""GPU parity of the small-block kernel (k_small, ba_small.hpp): batches that start at 32 cells run sixteen pairs per wave -- slots of
+four lanes x eight cells that take their pairs from the batch themselves, run the first block, plain shift steps and the last step of
+a global alignment -- and hand a pair to the same wave's solo mode (the per-pair driver) for grows, larger blocks, shrinks and X-drop
+termination. Every pair is compared with the oracle: score, end positions, computed cells, CIGAR runs (and a spread of the CIGARs is
+re-walked and re-scored without the oracle: tests/test_gpu_parity.py compare)."""
+import numpy as np
+import pytest
+
+from block_aligner_amd import scores as S
+from block_aligner_amd import synth
+from block_aligner_amd import workloads as W
+from tests.test_gpu_parity import NUC, compare
+from tests.test_gpu_pipelines import run_and_compare
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(), ("x_drop",), ("trace",), ("trace", "x_drop")]
+
+
+@pytest.fixture
+def force_small(devlib, monkeypatch):
+    monkeypatch.setenv("BA_FORCE_SMALL", "1")
+
+
+def kernel_of(hip, matrix, gaps, size, x_drop, mode_bits, pairs):
+    b = hip.BatchAligner(matrix, gaps, size, x_drop, mode_bits, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    k = b.info()["kernel"]
+    b.close()
+    return k
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("size", [(32, 32), (32, 64), (32, 256), (32, 1024)])
+def test_small_dna(hip, oracle, force_small, mode, size):
+    """Indels of 5 .. 120 bases force grows, checkpoint restores and shrinks: pairs move between slot and solo mode many times."""
+    pairs = synth.make_pairs(700, (0, 2500), (0, 250), 60, synth.DNA, seed=300 + size[1], indels=2, indel_len=(5, 120))
+    assert kernel_of(hip, NUC, (-5, -1), size, 80, 0, pairs) == "k_small"
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 80, mode)
+    assert res["cells"].max() > 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_small_ragged_and_short(hip, oracle, force_small, mode):
+    """Pairs shorter than a block, empty sequences and one-sided pairs share waves with ordinary ones."""
+    rng = np.random.default_rng(12)
+    lists = [(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A", b"A"), (b"A" * 31, b"A" * 33), (b"A" * 32, b"A" * 32), (b"ACGT" * 10, b"ACGT" * 300),
+             (b"ACGT" * 300, b"ACGT" * 7)]
+    for _ in range(300):
+        n = int(rng.integers(0, 400))
+        a = synth.rand_str(rng, n, synth.DNA)
+        b = synth.mutate(rng, a, int(rng.integers(0, 1 + n // 8)), synth.DNA) if n else a
+        lists.append((a.tobytes(), b.tobytes()))
+    pairs = synth.PairSet.from_lists(lists)
+    compare(hip, oracle, pairs, NUC, (-5, -1), (32, 128), 60, mode)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("size", [(32, 32), (32, 256)])
+def test_small_protein(hip, oracle, force_small, mode, size):
+    """The uc_bench shape (examples/uc_bench.rs:85-100): global alignments end inside their slot, the pairs that grow go solo."""
+    w = W.config4(2500, seed=5, trace="trace" in mode)
+    compare(hip, oracle, w.pairs, w.matrix, w.gaps, size, 60, mode)
+
+
+def test_small_bytes(hip, oracle, force_small):
+    pairs = synth.make_pairs(400, (0, 900), (0, 60), 5, np.frombuffer(b"abcdefghij\x01\xff", np.uint8), seed=6)
+    compare(hip, oracle, pairs, S.BYTES1, (-2, -1), (32, 128), 0, ())
+    compare(hip, oracle, pairs, S.BYTES1, (-2, -1), (32, 128), 0, ("trace",))
+
+
+@pytest.mark.parametrize("mode", [("trace",), ("trace", "x_drop")])
+def test_small_trace_regions_overflow_and_rerun(hip, oracle, force_small, monkeypatch, mode):
+    """Pair-slot trace regions cut far too small: slots and the solo driver report the overflow, the batch re-runs those pairs."""
+    monkeypatch.setenv("BA_TRACE_MARGIN_PCT", "30")
+    pairs = synth.make_pairs(600, (200, 1500), (10, 150), 40, synth.DNA, seed=41, indels=2, indel_len=(10, 100))
+    b = hip.BatchAligner(NUC, (-5, -1), (32, 256), 80, hip.TRACE | hip.CIGAR_EQ | (hip.X_DROP if "x_drop" in mode else 0), pairs.pool, pairs.q_off, pairs.q_len,
+                         pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_small"
+    b.run()
+    assert b.retried() > 0
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 80, mode)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_small_dna_at_production_threshold(hip, oracle, mode):
+    """No forcing, the release library: 9 k DNA pairs at 32..256 (threshold 8192)."""
+    assert hip.lib().ba_dev_build() == 0
+    pairs = synth.make_pairs(9000, (0, 1500), (0, 150), 40, synth.DNA, seed=812, indels=1, indel_len=(5, 60))
+    assert kernel_of(hip, NUC, (-5, -1), (32, 256), 100, 0, pairs) == "k_small"
+    run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 100, mode, True, ("dna 32..256 k_small", mode))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_small_protein_at_production_threshold(hip, oracle, mode):
+    """No forcing: 70 k protein pairs (threshold 65536), BLOSUM62, block 32..256."""
+    w = W.config4(70000, seed=92, trace="trace" in mode)
+    assert kernel_of(hip, w.matrix, w.gaps, w.size, 0, 0, w.pairs) == "k_small"
+    run_and_compare(hip, oracle, w.pairs, w.matrix, w.gaps, w.size, 60 if "x_drop" in mode else 0, mode, False, ("protein 32..256 k_small", mode))
