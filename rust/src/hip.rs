@@ -1,33 +1,35 @@
-// UNVERIFIED SOURCE: no Rust toolchain exists in the image this backend was built in (no rustc / cargo), so this file has never
-// been compiled. It is the module a maintainer drops into block-aligner's src/ next to avx2.rs (/root/reference/src/lib.rs:55-103
-// selects the SIMD layer by cargo feature). Every declaration mirrors include/block_aligner_hip.h, which IS compiled and tested
-// (tests/test_c_abi.py builds a C caller against it; tests/test_abi.py checks every declared symbol is exported).
+// UNCOMPILED SOURCE: no Rust toolchain exists in the image this backend was built in (no rustc / cargo). It is the module a maintainer
+// drops into block-aligner's src/ next to avx2.rs (the patches in this directory add the `simd_hip` feature and the module gates:
+// tests/test_rust_patches.py applies them to a copy of the reference). Every declaration mirrors include/block_aligner_hip.h, which
+// IS compiled and tested (tests/test_c_abi.py builds a C caller against it; tests/test_abi.py checks every declared symbol is exported).
 //
-// src/hip.rs -- raw FFI of libblock_aligner_hip.so + the two small traits the `simd_hip` bodies of scan_block.rs need:
-//   HipMatrix  (Matrix::HIP_KIND + a pointer to the matrix bytes in the layout of scores.rs:41-46,139-144,232-236)
-//   the batch API (HipBatch), the route the device is built for: one launch over many pairs instead of one launch per pair.
-#![cfg(feature = "simd_hip")]
+// src/hip.rs -- raw FFI of libblock_aligner_hip.so + the batch API (HipBatch), the route the device is built for: one launch over
+// many pairs instead of one launch per pair. The matrix kind and bytes come from Matrix::HIP_KIND / Matrix::hip_ptr (scores.rs.patch).
 #![allow(non_snake_case)]
 
 use std::os::raw::{c_char, c_void};
 use std::ffi::CStr;
-use crate::scores::{AAMatrix, ByteMatrix, Gaps, NucMatrix};
+use crate::scores::{Gaps, Matrix};
 use crate::cigar::{OpLen, Operation};
+use crate::scan_block::AlignResult;   // #[repr(C)] in the crate (scan_block.rs:1887-1893): crosses the ABI as it is
 
 #[repr(C)] #[derive(Copy, Clone)] pub struct SizeRange { pub min: usize, pub max: usize }
-#[repr(C)] #[derive(Copy, Clone, Debug, PartialEq, Eq)] pub struct AlignResult { pub score: i32, pub query_idx: usize, pub reference_idx: usize }
-#[repr(C)] #[derive(Copy, Clone, Debug, PartialEq, Eq)] pub struct Rectangle { pub row: usize, pub col: usize, pub width: usize, pub height: usize }
+#[repr(C)] #[derive(Copy, Clone)] pub struct CRectangle { pub row: usize, pub col: usize, pub width: usize, pub height: usize }   // (the crate's Rectangle is not repr(C))
 #[repr(C)] #[derive(Copy, Clone)] pub struct COpLen { pub op: u8, pub len: usize }   // c/block_aligner.h:17-66 (enum Operation is one byte)
 
 pub const BA_TRACE: u32 = 1; pub const BA_X_DROP: u32 = 2; pub const BA_LOCAL_START: u32 = 4;
 pub const BA_FREE_QUERY_START_GAPS: u32 = 8; pub const BA_FREE_QUERY_END_GAPS: u32 = 16; pub const BA_CIGAR_EQ: u32 = 32;
 pub const BA_KIND_AA: i32 = 0; pub const BA_KIND_NUC: i32 = 1; pub const BA_KIND_BYTES: i32 = 2;
 
-/// What a scoring matrix needs to cross the C ABI: its kind and its bytes (the reference's own in-memory layouts).
-pub trait HipMatrix { const HIP_KIND: i32; fn hip_ptr(&self) -> *const c_void; }
-impl HipMatrix for AAMatrix { const HIP_KIND: i32 = BA_KIND_AA; fn hip_ptr(&self) -> *const c_void { self as *const Self as *const c_void } }
-impl HipMatrix for NucMatrix { const HIP_KIND: i32 = BA_KIND_NUC; fn hip_ptr(&self) -> *const c_void { self as *const Self as *const c_void } }
-impl HipMatrix for ByteMatrix { const HIP_KIND: i32 = BA_KIND_BYTES; fn hip_ptr(&self) -> *const c_void { self as *const Self as *const c_void } }
+/// The matrix as the C ABI takes it. AAMatrix / NucMatrix are #[repr(C)] byte tables (scores.rs:41-46,139-144): their own memory;
+/// ByteMatrix (two private i8 fields, no repr) is passed as {match, mismatch} read through Matrix::get.
+pub(crate) struct MatrixArg { bytes: [i8; 2], ptr: *const c_void }
+impl MatrixArg {
+    pub(crate) fn of<M: Matrix>(m: &M) -> Self {
+        if M::HIP_KIND == BA_KIND_BYTES { MatrixArg { bytes: [m.get(0, 0), m.get(0, 1)], ptr: std::ptr::null() } } else { MatrixArg { bytes: [0, 0], ptr: m.hip_ptr() } }
+    }
+    pub(crate) fn ptr(&self) -> *const c_void { if self.ptr.is_null() { self.bytes.as_ptr() as *const c_void } else { self.ptr } }
+}
 
 #[link(name = "block_aligner_hip")]
 extern "C" {
@@ -40,7 +42,7 @@ extern "C" {
     pub fn block_res_generic(b: *mut c_void) -> AlignResult;
     pub fn block_cigar_generic(b: *mut c_void, query_idx: usize, reference_idx: usize, cigar: *mut c_void);
     pub fn block_cigar_eq_generic(b: *mut c_void, q: *const c_void, r: *const c_void, query_idx: usize, reference_idx: usize, cigar: *mut c_void);
-    pub fn block_trace_blocks_generic(b: *mut c_void, out: *mut Rectangle, capacity: usize) -> usize;
+    pub fn block_trace_blocks_generic(b: *mut c_void, out: *mut CRectangle, capacity: usize) -> usize;
     pub fn block_free_generic(b: *mut c_void);
     // ---- library-side Cigar (cigar.rs:42-95 as c/block_aligner.h exposes it)
     pub fn block_new_cigar(query_len: usize, reference_len: usize) -> *mut c_void;
@@ -63,6 +65,7 @@ extern "C" {
     pub fn block_get_aaprofile(p: *const c_void, i: usize, b: u8) -> i8;
     pub fn block_get_gap_extend_aaprofile(p: *const c_void) -> i8;
     pub fn block_free_aaprofile(p: *mut c_void);
+    pub fn ba_aaprofile_set_raw(p: *mut c_void, pos_aa: *const i8, gap_open_C: *const i8, gap_close_C: *const i8, gap_open_R: *const i8, positions: usize) -> i32;
     // ---- batch launcher: one persistent launch over many pairs (the default route, see HipBatch)
     pub fn ba_batch_create(kind: i32, matrix: *const c_void, gaps: Gaps, size: SizeRange, x_drop: i32, mode: u32,
                            pool: *const u8, q_off: *const u64, q_len: *const u32, r_off: *const u64, r_len: *const u32, n_pairs: usize) -> *mut c_void;
@@ -112,12 +115,13 @@ pub(crate) fn op_of(code: u8) -> Operation {   // cigar.rs:10-33 / c/block_align
 pub struct HipBatch { h: *mut c_void, n: usize, trace: bool }
 
 impl HipBatch {
-    pub fn new<M: HipMatrix>(matrix: &M, gaps: Gaps, size: std::ops::RangeInclusive<usize>, x_drop: i32, mode: u32,
+    pub fn new<M: Matrix>(matrix: &M, gaps: Gaps, size: std::ops::RangeInclusive<usize>, x_drop: i32, mode: u32,
                              pool: &[u8], q: &[(u64, u32)], r: &[(u64, u32)]) -> Result<Self, String> {
         assert_eq!(q.len(), r.len());
         let (q_off, q_len): (Vec<u64>, Vec<u32>) = q.iter().cloned().unzip();
         let (r_off, r_len): (Vec<u64>, Vec<u32>) = r.iter().cloned().unzip();
-        let h = unsafe { ba_batch_create(M::HIP_KIND, matrix.hip_ptr(), gaps, SizeRange { min: *size.start(), max: *size.end() }, x_drop, mode,
+        let marg = MatrixArg::of(matrix);
+        let h = unsafe { ba_batch_create(M::HIP_KIND, marg.ptr(), gaps, SizeRange { min: *size.start(), max: *size.end() }, x_drop, mode,
                                          pool.as_ptr(), q_off.as_ptr(), q_len.as_ptr(), r_off.as_ptr(), r_len.as_ptr(), q.len()) };
         if h.is_null() { Err(last_error()) } else { Ok(HipBatch { h, n: q.len(), trace: mode & BA_TRACE != 0 }) }
     }

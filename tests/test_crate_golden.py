@@ -1,0 +1,111 @@
+"""Golden vectors of the REAL block-aligner crate, when somebody with a Rust toolchain has produced them (this image has none):
+
+    cp rust/examples/dump_golden.rs <block-aligner>/examples/ && cd <block-aligner> && \
+    cargo run --release --features simd_avx2 --example dump_golden -- <repo>/tests/golden/crate_golden_input.tsv <repo>/tests/golden/crate_golden.tsv
+
+With tests/golden/crate_golden.tsv present, every case is compared with the oracle (CPU) and with the HIP path through the handle API
+(-m gpu): score, end indices, both CIGAR forms, Trace::blocks(). Without it those tests skip -- and say so -- while the input file
+itself is still checked: well-formed, and the oracle runs every case (the conditions the crate asserts are respected by the generator).
+"""
+import os
+
+import pytest
+
+from block_aligner_amd import scores as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+INPUT = os.path.join(HERE, "golden", "crate_golden_input.tsv")
+GOLDEN = os.path.join(HERE, "golden", "crate_golden.tsv")
+ALL_MODES = {"trace", "x_drop", "local_start", "free_query_start_gaps", "free_query_end_gaps"}
+
+
+def matrix_of(kind, name):
+    if name.startswith("simple:"):
+        _, a, b = name.split(":")
+        return {"aa": S.AAMatrix, "nuc": S.NucMatrix, "bytes": S.ByteMatrix}[kind].new_simple(int(a), int(b))
+    return S.static_matrix(name)
+
+
+def read_cases():
+    cases = []
+    with open(INPUT) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line or line.startswith("#"):
+                continue
+            cid, kind, m, go, ge, mn, mx, xd, mode, q, r = line.split("\t")
+            mode = tuple(sorted(mode.split("+"))) if mode != "-" else ()
+            cases.append(dict(id=int(cid), kind=kind, matrix=m, gaps=(int(go), int(ge)), size=(int(mn), int(mx)), x_drop=int(xd), mode=mode,
+                              q=b"" if q == "-" else q.encode(), r=b"" if r == "-" else r.encode()))
+    return cases
+
+
+def read_golden():
+    out = {}
+    with open(GOLDEN) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            cid, score, qi, ri, cigar, cigar_eq, blocks = line.split("\t")
+            rects = [] if blocks == "-" else [tuple(int(x) for x in b.split(",")) for b in blocks.split(";")]
+            out[int(cid)] = dict(score=int(score), query_idx=int(qi), reference_idx=int(ri), cigar="" if cigar == "-" else cigar,
+                                 cigar_eq="" if cigar_eq == "-" else cigar_eq, blocks=rects)
+    return out
+
+
+def test_input_file_is_well_formed_and_the_oracle_runs_every_case(oracle):
+    cases = read_cases()
+    assert len(cases) >= 300 and [c["id"] for c in cases] == list(range(len(cases)))
+    seen_modes, grew = set(), 0
+    for c in cases:
+        assert set(c["mode"]) <= ALL_MODES and not ({"local_start", "free_query_start_gaps"} <= set(c["mode"])) and not ({"x_drop", "free_query_end_gaps"} <= set(c["mode"]))
+        assert c["gaps"][0] < c["gaps"][1] < 0 and c["size"][0] <= c["size"][1]
+        if "free_query_end_gaps" in c["mode"]:
+            assert len(c["q"]) < c["size"][0]
+        res = oracle.align(matrix_of(c["kind"], c["matrix"]), c["q"], c["r"], c["gaps"], c["size"], c["x_drop"], c["mode"])
+        seen_modes.add(c["mode"])
+        grew += res["end_block_size"] > c["size"][0] or res["cells"] > (len(c["q"]) + len(c["r"]) + 2 * c["size"][0]) * c["size"][0]
+    assert len(seen_modes) >= 12 and grew >= 60   # the file does reach past the reference's own fixed-size known answers
+
+
+needs_golden = pytest.mark.skipif(not os.path.exists(GOLDEN), reason="tests/golden/crate_golden.tsv not present: produce it with rust/examples/dump_golden.rs "
+                                                                     "(needs cargo; see this file's docstring)")
+
+
+@needs_golden
+def test_oracle_equals_the_crate(oracle):
+    golden = read_golden()
+    cases = read_cases()
+    assert set(golden) == {c["id"] for c in cases}
+    for c in cases:
+        g = golden[c["id"]]
+        m = matrix_of(c["kind"], c["matrix"])
+        res = oracle.align(m, c["q"], c["r"], c["gaps"], c["size"], c["x_drop"], c["mode"])
+        assert (res["score"], res["query_idx"], res["reference_idx"]) == (g["score"], g["query_idx"], g["reference_idx"]), c["id"]
+        if "trace" in c["mode"]:
+            assert res["cigar"] == g["cigar"], c["id"]
+            assert oracle.align(m, c["q"], c["r"], c["gaps"], c["size"], c["x_drop"], c["mode"], cigar_eq=True)["cigar"] == g["cigar_eq"], c["id"]
+            assert oracle.align_blocks(m, c["q"], c["r"], c["gaps"], c["size"], c["x_drop"], c["mode"]) == g["blocks"], c["id"]
+
+
+@needs_golden
+@pytest.mark.gpu
+def test_hip_equals_the_crate(hip):
+    golden = read_golden()
+    for c in read_cases():
+        g = golden[c["id"]]
+        m = matrix_of(c["kind"], c["matrix"])
+        mc = type(m)
+        blk = hip.Block(len(c["q"]), len(c["r"]), c["size"][1], **{k: True for k in c["mode"]})
+        qp = hip.PaddedBytes.from_bytes(c["q"], c["size"][1], mc); rp = hip.PaddedBytes.from_bytes(c["r"], c["size"][1], mc)
+        blk.align(qp, rp, m, c["gaps"], c["size"], c["x_drop"])
+        res = blk.res()
+        assert (res.score, res.query_idx, res.reference_idx) == (g["score"], g["query_idx"], g["reference_idx"]), c["id"]
+        if "trace" in c["mode"]:
+            cg = hip.Cigar(len(c["q"]), len(c["r"]))
+            blk.trace().cigar(res.query_idx, res.reference_idx, cg)
+            assert str(cg) == g["cigar"], c["id"]
+            blk.trace().cigar_eq(qp, rp, res.query_idx, res.reference_idx, cg)
+            assert str(cg) == g["cigar_eq"], c["id"]
+            assert blk.trace().blocks() == g["blocks"], c["id"]
