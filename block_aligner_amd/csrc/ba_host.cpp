@@ -258,6 +258,7 @@ struct BaBatch {
     uint32_t mq_drain = 0;      // k_multi: pairs at the end of the batch that are run one at a time (BatchParams::mq_drain)
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
     uint32_t walk_wave_n = 0;   // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (plan_walks)
+    uint32_t sm_excl_n = 0;     // k_small: the batch's longest pairs, run one to a wave (plan_exclusive)
     bool small = false;         // small-block batch: sixteen pairs per wave while their block is 32 cells, everything else by the same wave (ba_small.hpp)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
@@ -299,6 +300,7 @@ struct BaBatch {
         bp.work_counter = counter.as<uint32_t>();
         bp.work_chunk = work_chunk;
         bp.mq_drain = mq_drain;
+        bp.sm_excl_n = small ? sm_excl_n : 0;
         bp.prof = prof.as<unsigned long long>();
         return bp;
     }
@@ -508,7 +510,10 @@ static void pipe_regions(const BaBatch* b, const uint32_t* ql, const uint32_t* r
                          std::vector<uint64_t>& boff) {
     toff.resize(n + 1); boff.resize(n + 1);
     const uint64_t mx = b->max_size, mn = b->min_size;
-    uint64_t t = 0, r = 0;
+    // (k_small: the arena starts with the waves' sinks -- 64 lanes x 16 words each, where the slots without a step put their trace stores;
+    // sized for any launch geometry: 4 workgroups of 8 waves per CU on up to 512 CUs)
+    uint64_t t = b->small ? 512ull * 32 * 64 * 16 + 64 : 0, r = 0;
+    t = (t + 15) & ~15ull;
     for (size_t p = 0; p < n; p++) {
         const uint64_t len2 = (uint64_t)ql[p] + rl[p] + 2;
         const uint64_t full = (mx / 16) * (len2 + 2 * mx) * 2 + 64;
@@ -700,6 +705,7 @@ static int upload_images(BaBatch* b, const Packed& P, size_t n) {
 
 static int upload_dev_of(BaBatch* b);
 static void plan_walks(BaBatch* b, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rl);
+static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rl);
 // `get(p, which, &ptr, &len)` yields pair p's query (0) / reference (1); for kind PROFILE the reference comes from
 // `getp(p)` instead.
 template <class GetSeq, class GetProfile = NoProfiles>
@@ -783,6 +789,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (!b->multi && !b->small)
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
     if (b->pipe) b->adaptive = true;
+    plan_exclusive(b.get(), ql, rl);
     b->cig_total = trace ? cig_total : 0;
 
     lap("launch geometry");
@@ -866,6 +873,7 @@ static int batch_reload(BaBatch* b, size_t n, bool already_converted, GetSeq get
     HIP_TRY(hipMemset(b->status.p, 0, n * 4));
     b->n = (uint32_t)n; b->h_q_off = P.qo; b->h_r_off = P.ro; b->h_order = P.order; b->pool_bytes = P.total;
     plan_walks(b, P.ql, P.rl);
+    plan_exclusive(b, P.ql, P.rl);
     b->cig_total = (b->mode & BA_TRACE) ? P.cig_total : 0;
     b->ran = false;
     return upload_dev_of(b);
@@ -888,6 +896,24 @@ static void plan_walks(BaBatch* b, const std::vector<uint32_t>& ql, const std::v
     size_t cnt = 0;
     while (cnt < n && cnt < kmax && ql[cnt] + rl[cnt] >= from) cnt++;   // (device order: longest first)
     b->walk_wave_n = (uint32_t)cnt;
+}
+// k_small: sixteen pairs to a wave make every pair sixteen times as long in flight (and a neighbour's solo episode stops a slot), so a pair
+// many times the average length would end the launch alone. The leading pairs of the batch order (longest first) whose own chain of steps
+// in a slot would take more than about half of what the whole batch takes -- |q| + |r| above half the batch's residues per slot -- run one
+// to a wave instead, on all lanes, before the wave starts its slots; at most one for every second wave.
+static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const std::vector<uint32_t>& rl) {
+    b->sm_excl_n = 0;
+    if (!b->small || dev_env("BA_NO_EXCL")) return;
+    const size_t n = ql.size();
+    uint64_t total = 0;
+    for (size_t p = 0; p < n; p++) total += (uint64_t)ql[p] + rl[p];
+    const uint64_t slots = (uint64_t)b->grid * ba::WAVES_PER_WG * ba::SM_SLOTS;
+    uint64_t thr = std::max<uint64_t>(total / std::max<uint64_t>(slots, 1) / 2, 1024);
+    if (const char* e = dev_env("BA_EXCL_LEN2")) thr = (uint64_t)std::max(0, atoi(e));
+    const size_t cap = (size_t)b->grid * ba::WAVES_PER_WG / 2;
+    size_t cnt = 0;
+    while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
+    b->sm_excl_n = (uint32_t)cnt;
 }
 static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves x 64 walking lanes each)
     hipDeviceProp_t prop;

@@ -103,6 +103,7 @@ struct BatchParams {
                                  // flight) but one at a time by waves whose slots have emptied, and run on all lanes to their end: a finer ragged end
     uint32_t walk_wave_n;        // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (walk_wave), the others one to a lane
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
+    uint32_t sm_excl_n;          // k_small: the first sm_excl_n pairs of the batch order (its longest) run one to a wave on all lanes, from start to end (work_counter[2])
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;
 };

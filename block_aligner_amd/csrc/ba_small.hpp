@@ -23,7 +23,7 @@
 namespace ba {
 
 constexpr int SM_B = 32, SM_LW = 4, SM_NS = 16;
-enum { MR_FLAGS = MR_WORDS, MR_BOOT, MR_BMX, SM_MR_WORDS };   // flags: bit 0 = run the pair from its start in solo mode
+enum { MR_FLAGS = MR_WORDS, MR_BOOT, MR_BMX, SM_MR_WORDS };   // flags: bit 0 = run the pair from its start in solo mode, bit 1 = ... and to its end
 static_assert(SM_MR_WORDS <= 32 && SM_B == (int)SM_B_HOST && SM_NS == (int)SM_SLOTS, "k_small record");
 
 template <int N>
@@ -46,12 +46,8 @@ __device__ __forceinline__ int quad_all_max(int v) {
         : "+v"(v));
     return v;
 }
-// lane l <- src[l - 1] & mask[l] inside the quad (mask = 0 in quad lane 0: nothing above it)
-__device__ __forceinline__ int quad_shr1_and(int src, int mask) {
-    int t;
-    asm volatile("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(src), "v"(mask));
-    return t;
-}
+// lane l <- src[l - 1] inside the quad (quad lane 0 keeps its own value: the caller replaces it)
+__device__ __forceinline__ int quad_shr1(int src) { return __builtin_amdgcn_update_dpp(src, src, 0x90, 0xf, 0xf, false); }
 // lane l <- l == 3 ? last[l] : src[l + 1] inside the quad, for the eight registers of the orthogonal border pair at once (one mask set-up)
 __device__ __forceinline__ void quad_shl1_keep8(int (&d)[4], int (&r)[4], const int (&sd)[4], const int (&sr)[4], const int (&ld)[4], const int (&lr)[4], unsigned long long last_mask) {
     asm volatile(
@@ -71,32 +67,39 @@ __device__ __forceinline__ void quad_shl1_keep8(int (&d)[4], int (&r)[4], const 
 }
 
 struct SmallConsts {
-    int G[4];            // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
-    int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g (quad lane 0: 0 -- its candidate is replaced by -32768, see small_rect)
-    int vtop[4];         // per cell: max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column)
-    int nz;              // 0 in quad lane 0, -1 elsewhere
+    int G[4];            // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k (wave-uniform)
+    int laneKG;          // l * 8g
+    int g8;              // 8g (wave-uniform): (l - 1) * 8g = laneKG - g8
+    // Per cell: max(zero-shift-in artefact of the reference's in-vector scan (avx2.rs:315-338), the MIN = 0 carry above the column). For a
+    // lane's first six cells (registers 0 .. 2) that is G[k] in every lane -- cell c of a 16-cell vector sees a virtual zero at distance
+    // (c & 7) + 1 = 2k + 1 + h, never farther than the carry from above the column --; only the last register (vector cells 6, 7 / 14, 15:
+    // the artefact's 12g, its absence) differs from lane to lane: one per-lane register instead of four.
+    int vtop3;
 };
 
 // One 8-column shift step for the sixteen slots of a wave (multi_rect for quads). first_cell: this lane holds cell (0, 0) of a pair's
 // first block (scan_block.rs:1130-1132). fin_any / fin_col / dsel: a global alignment's last step is among the slots: D of column fin_col.
+// The orthogonal border pair is not live across the columns: its values of before the step are read back from the buffer the step's state
+// was staged in (pstage: this lane's 16 bytes of P_d, P_r 64 bytes behind) when the step shifts it -- eight registers fewer in the columns,
+// which is what keeps the loop of steps free of scratch reloads (a reload waits for every memory operation in flight, the step's trace
+// stores included: with 9 of them in the loop the TRACE kernels ran 1.6 x slower than the score-only ones).
 template <int KIND, bool TRACE, bool FIN>
 __device__ __forceinline__ void small_rect(const char* table, const FillConsts& fc, const SmallConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
-                                           int (&Pd)[4], int (&Pr)[4], uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, bool first_cell,
-                                           uint32_t* __restrict__ tout, bool store, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o) {
+                                           int (&Pd)[4], int (&Pr)[4], const char* pstage, uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, bool first_cell,
+                                           uint32_t* __restrict__ tout, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o) {
     const int offa = splat(off_add);
-    int d[4], c[4], pd[4], pr[4];
+    int d[4], c[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // just_offset (scan_block.rs:1003-1012)
-        d[k] = adds(Ad[k], offa); c[k] = adds(Ac[k], offa); pd[k] = adds(Pd[k], offa); pr[k] = adds(Pr[k], offa);
+        d[k] = adds(Ad[k], offa); c[k] = adds(Ac[k], offa);
     }
-    o.corner_new = quad_bcast<0>(pd[3]) >> 16;   // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based
     ScoreKey<KIND> key[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t w = k < 2 ? vb.x : vb.y;
         key[k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
     }
-    int dmax[4] = {0, 0, 0, 0}, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dmax[4] = {0, 0, 0, 0}, tacc[2] = {0, 0};
     int nvD[4] = {0, 0, 0, 0}, nvR[4] = {0, 0, 0, 0};   // the last cells of the 8 new columns: the orthogonal border's new entries (quad lane 3)
     int holdD = 0, holdR = 0;
 #pragma unroll
@@ -106,8 +109,8 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
 #pragma unroll
         for (int k = 0; k < 4; k++) sc[k] = fetch_score<KIND>(table, key[k], cb);
         // D00: the previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
-        int prev = quad_shr1_and(d[3], mc.nz);
-        if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
+        int prev = quad_shr1(d[3]);
+        prev = l == 0 ? (j == 0 ? (int)((uint32_t)corner << 16) : 0) : prev;
         int d00[4];
         d00[0] = __builtin_amdgcn_alignbit(d[0], prev, 16);
 #pragma unroll
@@ -128,45 +131,54 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
         for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(splat_hi(r[k - 1]), mc.G[0]));
         const int pm = quad_prefix_max((int)as_s(r[3]).y - mc.laneKG);
         // R of the lane above's last cell; quad lane 0 has no lane above: a candidate that never wins
-        int cin = __builtin_amdgcn_update_dpp(pm, pm, 0x90, 0xf, 0xf, false) + mc.lanem1KG;
+        int cin = __builtin_amdgcn_update_dpp(pm, pm, 0x90, 0xf, 0xf, false) + mc.laneKG - mc.g8;
         cin = l == 0 ? -32768 : cin;
         const int cs = splat_lo(cin);
         int dn[4];
-        uint32_t sC[4], sR[4], sCo[4], sRo[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), mc.vtop[k]);
-            dn[k] = vmax(d11[k], r[k]);
-            if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect); packed below, two registers at a time
-                sC[k] = (uint32_t)subs(cn[k], dn[k]); sR[k] = (uint32_t)subs(r[k], dn[k]); sCo[k] = (uint32_t)subs(copen[k], cn[k]); sRo[k] = (uint32_t)subs(x[k], r[k]);
+        for (int p2 = 0; p2 < 2; p2++) {   // two registers at a time: their trace flags are packed before the next two are touched (fewer values alive)
+            uint32_t sC[2], sR[2], sCo[2], sRo[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int k = 2 * p2 + kk;
+                r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), k < 3 ? mc.G[k] : mc.vtop3);
+                dn[k] = vmax(d11[k], r[k]);
+                if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect)
+                    sC[kk] = (uint32_t)subs(cn[k], dn[k]); sR[kk] = (uint32_t)subs(r[k], dn[k]); sCo[kk] = (uint32_t)subs(copen[k], cn[k]); sRo[kk] = (uint32_t)subs(x[k], r[k]);
+                }
+                dmax[k] = vmax(dmax[k], dn[k]);
+                d[k] = dn[k]; c[k] = cn[k];
             }
-            dmax[k] = vmax(dmax[k], dn[k]);
-            d[k] = dn[k]; c[k] = cn[k];
+            if (TRACE) {   // trace words: see multi_rect (4 consecutive cells x 2 columns per word, a lane's eight words contiguous)
+                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[1], (int)sC[0], 0x07050301), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[1], (int)sR[0], 0x07050301);
+                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[1], (int)sCo[0], 0x07050301), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[1], (int)sRo[0], 0x07050301);
+                const uint32_t hi2 = bfi(0x80808080u, pRo, pCo >> 1), lo2 = bfi(0x80808080u, pR, pC >> 1);
+                const uint32_t nib = bfi(0xC0C0C0C0u, hi2, lo2 >> 2);   // bits 7..4 of every byte
+                if (j & 1) tacc[p2] = (int)bfi(0xF0F0F0F0u, nib, (uint32_t)tacc[p2]);
+                else tacc[p2] = (int)(nib >> 4);
+            }
         }
         if (FIN && fin_any) {   // (wave-uniform branch)
 #pragma unroll
             for (int k = 0; k < 4; k++) dsel[k] = fin_col == (uint32_t)j ? dn[k] : dsel[k];
         }
-        if (TRACE) {   // trace words: see multi_rect (4 consecutive cells x 2 columns per word, a lane's eight words contiguous)
-#pragma unroll
-            for (int p2 = 0; p2 < 2; p2++) {
-                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[2 * p2 + 1], (int)sC[2 * p2], 0x07050301), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[2 * p2 + 1], (int)sR[2 * p2], 0x07050301);
-                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[2 * p2 + 1], (int)sCo[2 * p2], 0x07050301), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[2 * p2 + 1], (int)sRo[2 * p2], 0x07050301);
-                const uint32_t hi2 = bfi(0x80808080u, pRo, pCo >> 1), lo2 = bfi(0x80808080u, pR, pC >> 1);
-                const uint32_t nib = bfi(0xC0C0C0C0u, hi2, lo2 >> 2);   // bits 7..4 of every byte
-                if (j & 1) tacc[2 * (j >> 1) + p2] = (int)bfi(0xF0F0F0F0u, nib, (uint32_t)tacc[2 * (j >> 1) + p2]);
-                else tacc[2 * (j >> 1) + p2] = (int)(nib >> 4);
-            }
-        }
+        if (TRACE && (j & 1)) *(int2*)(tout + 2 * (j >> 1)) = int2{tacc[0], tacc[1]};   // (a column pair's two words: the accumulators do not live on; unpredicated: a slot without a step writes to the wave's sink)
         // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
         if (j & 1) { nvD[j >> 1] = __builtin_amdgcn_perm(dn[3], holdD, 0x07060302); nvR[j >> 1] = __builtin_amdgcn_perm(r[3], holdR, 0x07060302); }
         else { holdD = dn[3]; holdR = r[3]; }
+#ifdef SM_COLUMN_BARRIER
+        __builtin_amdgcn_sched_barrier(0);   // (columns are not interleaved by the scheduler: shorter live ranges)
+#endif
     }
-    if (TRACE) {
-        if (store) { *(int4*)tout = int4{tacc[0], tacc[1], tacc[2], tacc[3]}; *(int4*)(tout + 4) = int4{tacc[4], tacc[5], tacc[6], tacc[7]}; }
+    // shift_and_offset (scan_block.rs:1040-1061): 8 entries = one lane; the border as it was before the step comes back from its staged copy
+    int pd[4], pr[4];
+    {
+        const int4 sd = *(const int4*)pstage, sr = *(const int4*)(pstage + 64);
+        pd[0] = adds(sd.x, offa); pd[1] = adds(sd.y, offa); pd[2] = adds(sd.z, offa); pd[3] = adds(sd.w, offa);
+        pr[0] = adds(sr.x, offa); pr[1] = adds(sr.y, offa); pr[2] = adds(sr.z, offa); pr[3] = adds(sr.w, offa);
     }
-    // shift_and_offset (scan_block.rs:1040-1061): 8 entries = one lane
-    quad_shl1_keep8(Pd, Pr, pd, pr, nvD, nvR, 0x8888888888888888ull);
+    o.corner_new = quad_bcast<0>(pd[3]) >> 16;   // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based
+    quad_shl1_keep8(Pd, Pr, pd, pr, nvD, nvR, 0x8888888888888888ull);   // (Pd, Pr: outputs -- the border pair after the step)
 #pragma unroll
     for (int k = 0; k < 4; k++) { Ad[k] = d[k]; Ac[k] = c[k]; }
     {   // max of the first 8 entries of both borders (quad lane 0), to every lane of the slot (scan_block.rs:1020-1022)
@@ -219,8 +231,23 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
     uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
     uint32_t w_next = 0, w_end = 0;
     bool more = true;
+    // The batch's longest pairs (the first sm_excl_n of the batch order: ba_host.cpp) are not for slots: sixteen pairs to a wave make each
+    // of them sixteen times as long in flight -- and every solo episode of a neighbour stops the other fifteen --, so a pair many times the
+    // average length would end the launch alone (400 k protein pairs 22 .. 8881: 10.7 ms with the 77 longest, 5.3 without). Each wave takes
+    // at most a few of them, one at a time, before it starts its slots, and runs them from start to end on all its lanes.
+    const uint32_t excl_n = bp.sm_excl_n;
+    bool excl_more = excl_n > 0;
 
     for (;;) {
+        if (excl_more && !live_m && !pend_m) {
+            uint32_t e = 0;
+            if (is_lane(0)) e = atomicAdd(bp.work_counter + 2, 1u);
+            e = (uint32_t)uni((int)e);
+            if (e < excl_n) {
+                if (is_lane(0)) { int* rc = (int*)(wave_mem + 2 * SM_BUF_BYTES); rc[MR_PAIR] = (int)e; rc[MR_FLAGS] = 3; }
+                pend_m = 1u;
+            } else excl_more = false;
+        }
         // ================= solo mode: the pairs whose step was rolled back (or that a slot cannot take), one at a time on all 64 lanes
         while (pend_m) {
             int solo = __builtin_ctz(pend_m);
@@ -248,6 +275,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
 #define BA_W(v, k) __builtin_amdgcn_readlane(v, k)
             uint32_t s_pair = (uint32_t)BA_W(rv, MR_PAIR);
             bool fresh = (BA_W(rv, MR_FLAGS) & 1) != 0;
+            const bool to_end = (BA_W(rv, MR_FLAGS) & 2) != 0;
             if (!fresh) {
                 const uint32_t s_sel = (uint32_t)BA_W(rv, MR_SEL);
                 const char* live_b = smem_s + (s_sel ^ 1u) * SM_BUF_BYTES; const char* ck_b = smem_s + s_sel * SM_BUF_BYTES;
@@ -267,7 +295,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     st.status = (uint32_t)BA_W(rv, MR_STATUS);
                     const bool ck_pre = flag != 0;
                     st.ck_i = (uint32_t)BA_W(cv, 1); st.ck_j = (uint32_t)BA_W(cv, 2); st.ck_off = BA_W(cv, 3);
-                    st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * SM_B / 8 : 0u); st.ck_nb = (uint32_t)BA_W(cv, 5) + (flag ? 1u : 0u);
+                    st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * SM_B / 8 : 0u);
+                    st.ck_nb = (uint32_t)BA_W(cv, 5) - (TRACE ? (uint32_t)bp.blocks_off[s_pair] : 0u) + (flag ? 1u : 0u);   // (staged as an absolute record position)
                     const int ck_dir = (BA_W(cv, 0) >> 8) & 0xff, ck_offadd = BA_W(cv, 6), ck_corner = BA_W(cv, 7);
                     {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 3), into the canonical order D_col, C_col, D_row, R_row
                         int reg[16], ckr[16];
@@ -290,13 +319,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             // The per-pair driver needs every scalar register: what the wave keeps across it is parked in the lanes of one VGPR
             int keepv = 0;
             park<0>(keepv, (int)live_m); park<1>(keepv, (int)pend_m); park<2>(keepv, (int)w_next); park<3>(keepv, (int)w_end);
-            park<4>(keepv, (more ? 1 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair);
+            park<4>(keepv, (more ? 1 : 0) | (excl_more ? 2 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair);
             // (a pair in solo mode keeps the wave's other fifteen slots waiting: its dependent chain goes first among the SIMD's waves)
             __builtin_amdgcn_s_setprio(MQ_SOLO_PRIO);
-            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, true, !fresh);
+            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh);
             __builtin_amdgcn_s_setprio(0);
             live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
-            more = unpark<4>(keepv) & 1; solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv);
+            more = unpark<4>(keepv) & 1; excl_more = unpark<4>(keepv) & 2; solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv);
             char* const smem_s2 = (char*)coldp_big() + (uint64_t)fill_wave_of() * SM_WAVE_BYTES + (uint32_t)solo * SM_SLOT_BYTES;
             char* const rec2 = smem_s2 + 2 * SM_BUF_BYTES;
             pend_m &= ~(1u << solo);
@@ -316,7 +345,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 }
                 if (is_lane(0)) {
                     char* b0 = smem_s2;
-                    *(int4*)(b0 + 256) = int4{0 | (DIR_RIGHT << 8), (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + 272) = int4{(int)st.ck_tt, (int)st.ck_nb, 0, 0};
+                    *(int4*)(b0 + 256) = int4{0 | (DIR_RIGHT << 8), (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + 272) = int4{(int)st.ck_tt, (int)(st.ck_nb + (TRACE ? (uint32_t)bp.blocks_off[s_pair] : 0u)), 0, 0};
                     int* rc = (int*)rec2;
                     rc[MR_PAIR] = (int)s_pair; rc[MR_BEST_I] = (int)st.best_i; rc[MR_BEST_J] = (int)st.best_j; rc[MR_CELLS_LO] = (int)(uint32_t)st.cells; rc[MR_CELLS_HI] = (int)(uint32_t)(st.cells >> 32);
                     rc[MR_BUDGET] = (int)st.step_budget; rc[MR_STATUS] = (int)st.status; rc[MR_TSLOT] = (int)s_pair; rc[MR_SI] = (int)st.si; rc[MR_SJ] = (int)st.sj; rc[MR_DIR] = st.dir;
@@ -328,6 +357,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 live_m |= 1u << solo;
             } else live_m &= ~(1u << solo);
         }
+        if (excl_more) continue;
         if (!live_m && !more) break;
 
         // ================= the slots: registers from memory, steps until a slot needs solo mode (or the batch is done), registers to memory
@@ -338,52 +368,67 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             FillConsts fq;   // only the three gap constants (wave-uniform)
             fq.go2 = splat(bp.gap_open); fq.ge2 = splat(gx); fq.ome2 = splat(clamp16(bp.gap_open - gx));
             SmallConsts mc;  // eight cells per lane
-            mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : 0; mc.nz = l ? -1 : 0;
+            mc.laneKG = l * 8 * gx; mc.g8 = 8 * gx;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+            for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+            {
                 int t[2];
                 for (int h = 0; h < 2; h++) {
-                    const int cell = 8 * l + 2 * k + h, k16 = cell & 15;
+                    const int cell = 8 * l + 6 + h, k16 = cell & 15;
                     const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
                     const int art = mult ? max(-32768, mult * gx) : -32768;
                     t[h] = max(art, max(-32768, (cell + 1) * gx));
                 }
-                mc.vtop[k] = pk(t[0], t[1]);
+                mc.vtop3 = pk(t[0], t[1]);
             }
             // ---- slot state (row-uniform, replicated over the slot's lanes)
             const bool live0 = (live_m >> g) & 1u;
             const char* rec = slot_mem + 2 * SM_BUF_BYTES;
 #define BA_R(k) (live0 ? mq_load(rec + 4 * (k)) : 0)
             uint32_t pair = live0 ? (uint32_t)mq_load(rec + 4 * MR_PAIR) : ~0u;
-            uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ), y_drop = (uint32_t)BA_R(MR_Y_DROP), nsteps = (uint32_t)BA_R(MR_NSTEPS);
-            uint32_t trace_top = (uint32_t)BA_R(MR_TRACE_TOP), nblocks = (uint32_t)BA_R(MR_NBLOCKS), sel = (uint32_t)BA_R(MR_SEL);
-            uint32_t flags = (uint32_t)BA_R(MR_FLAGS), boot = (uint32_t)BA_R(MR_BOOT);
-            int dir = BA_R(MR_DIR), prev_dir = BA_R(MR_PREV_DIR), off = BA_R(MR_OFF), off_max = BA_R(MR_OFF_MAX), best_max = BA_R(MR_BEST_MAX);
-            int x_iter = BA_R(MR_X_ITER), D_corner = BA_R(MR_D_CORNER), bmx = BA_R(MR_BMX);
-#undef BA_R
+            // (few registers: every one that lives across the columns of a step counts -- see small_rect. The small counters share one:
+            // bits = boot sub-steps left [2:0] | "from the start, solo" [3] | prev_dir [5:4] | x_drop_iter [7:6]; ymix = the first block's
+            // maximum so far while boot > 0, y_drop_iter after it; the steps taken since the record was written follow from si + sj)
+            uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ);
+            uint32_t trace_top = (uint32_t)BA_R(MR_TRACE_TOP), sel = (uint32_t)BA_R(MR_SEL);
+            uint32_t bits = ((uint32_t)BA_R(MR_BOOT) & 7u) | (((uint32_t)BA_R(MR_FLAGS) & 1u) << 3) | (((uint32_t)BA_R(MR_PREV_DIR) & 3u) << 4) | (((uint32_t)BA_R(MR_X_ITER) & 3u) << 6);
+            int ymix = (bits & 7u) ? BA_R(MR_BMX) : BA_R(MR_Y_DROP);
+            int dir = BA_R(MR_DIR), off = BA_R(MR_OFF), off_max = BA_R(MR_OFF_MAX), best_max = BA_R(MR_BEST_MAX);
+            int D_corner = BA_R(MR_D_CORNER);
             uint32_t qlen = live0 ? bp.q_len[pair] : 0u, rlen = live0 ? bp.r_len[pair] : 0u;
             const uint8_t* qp = bp.pool + (live0 ? bp.q_off[pair] : 0ull); const uint8_t* rp = bp.pool + (live0 ? bp.r_off[pair] : 0ull);
-            uint32_t* tr = bp.trace_arena; BlockRec* bl = bp.blocks; uint32_t tcap = 0, bcap = 0;
+            // TRACE: the pair's trace region (units of 16 words: regions are cut at multiples of 16), the next rectangle record (absolute), and
+            // the number of steps region and record list still have room for
+            uint32_t tr16 = 0, bpos = 0; int room = 0;
+            auto room_of = [](uint32_t tcap, uint32_t bcap, uint32_t tt, uint32_t nb) -> int {
+                const uint32_t a = tcap >= tt + 64u ? (tcap - 64u - tt) / (STEP * SM_B / 8) : 0u, b = bcap > nb ? bcap - nb : 0u;
+                return (int)min(min(a, b), 0x7fffffffu);
+            };
             if (TRACE && live0) {
                 const uint64_t t0 = bp.trace_off[pair], b0 = bp.blocks_off[pair];
-                tr = bp.trace_arena + t0; bl = bp.blocks + b0;
-                tcap = (uint32_t)min(bp.trace_off[pair + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[pair + 1] - b0, (uint64_t)0x7fffffffu);
+                const uint32_t nb = (uint32_t)BA_R(MR_NBLOCKS);
+                tr16 = (uint32_t)(t0 >> 4); bpos = (uint32_t)b0 + nb;
+                room = room_of((uint32_t)min(bp.trace_off[pair + 1] - t0, (uint64_t)0x7fffffffu), (uint32_t)min(bp.blocks_off[pair + 1] - b0, (uint64_t)0x7fffffffu), trace_top, nb);
             }
-            int A_d[4], A_c[4], P_d[4], P_r[4];   // borders: (A) along the vector axis of the step at `dir`, (P) orthogonal
+#undef BA_R
+            // While the slots run, the two buffers of every slot live in this wave's LDS region (the solo borders' space): the checkpoint
+            // (buffer `sel`) comes from the arena now and goes back after the loop. Of the other one -- the state at the top of the step in
+            // flight -- the border pair along the step's vector axis (A) is in registers and staged before every step; the orthogonal pair (P)
+            // lives ONLY there: a step reads it when it shifts it and writes the new one behind its driver decisions.
+            char* const lbuf = base + (uint32_t)g * 512u;                        // this slot's buffers: + which * 256
+            int* const lsc = (int*)(base + SM_LDS_SCALARS) + (uint32_t)g * 16u;   // their scalars: + which * 8
+            int A_d[4], A_c[4];
+            lds_sync();
             {
                 const char* b = slot_mem + (sel ^ 1u) * SM_BUF_BYTES + l * 16;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    A_d[k] = live0 ? mq_load(b + 4 * k) : 0; A_c[k] = live0 ? mq_load(b + 64 + 4 * k) : 0;
-                    P_d[k] = live0 ? mq_load(b + 128 + 4 * k) : 0; P_r[k] = live0 ? mq_load(b + 192 + 4 * k) : 0;
+                for (int k = 0; k < 4; k++) { A_d[k] = live0 ? mq_load(b + 4 * k) : 0; A_c[k] = live0 ? mq_load(b + 64 + 4 * k) : 0; }
+                if (live0) {
+                    char* d = lbuf + (sel ^ 1u) * 256u + l * 16;
+                    *(int4*)(d + 128) = int4{mq_load(b + 128), mq_load(b + 132), mq_load(b + 136), mq_load(b + 140)};
+                    *(int4*)(d + 192) = int4{mq_load(b + 192), mq_load(b + 196), mq_load(b + 200), mq_load(b + 204)};
                 }
             }
-            // While the slots run, the two buffers of every slot live in this wave's LDS region (the solo borders' space): the checkpoint
-            // (buffer `sel`) comes from the arena now and goes back after the loop; the other one is rewritten before every step.
-            char* const lbuf = base + (uint32_t)g * 512u;                        // this slot's buffers: + which * 256
-            int* const lsc = (int*)(base + SM_LDS_SCALARS) + (uint32_t)g * 16u;   // their scalars: + which * 8
-            lds_sync();
             if (live0) {
                 const char* cb = slot_mem + sel * SM_BUF_BYTES;
                 char* d = lbuf + sel * 256u + l * 16;
@@ -398,11 +443,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             // sequence bytes of the next step, fetched one step ahead for both possible directions
             uint2 pf_qv = {0, 0}, pf_rv = {0, 0}, pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
             bool leave = false;
-            // the slot's registers and the scalars of the step at the top into the buffer `which` (see ba_multi.hpp)
-            auto stage = [&](uint32_t which, int s_flag, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
+            // the slot's A registers and the scalars of the step at the top into the buffer `which` (see ba_multi.hpp; rectangle records as
+            // absolute positions here)
+            auto stageA = [&](uint32_t which, int s_flag, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
                 char* b = lbuf + which * 256u + l * 16;
                 *(int4*)(b) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + 64) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
-                *(int4*)(b + 128) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 192) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
                 if (l == 0) {
                     int* sc = lsc + which * 8u;
                     *(int4*)sc = int4{s_flag | (s_dir << 8), (int)s_i, (int)s_j, s_off}; *(int4*)(sc + 4) = int4{(int)s_tt, (int)s_nb, s_offadd, s_corner};
@@ -416,7 +461,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     if (w_next == w_end) {
                         uint32_t v = 0;
                         if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
-                        w_next = (uint32_t)uni((int)v);
+                        w_next = (uint32_t)uni((int)v) + excl_n;   // (the first excl_n pairs of the batch order are taken one to a wave, above)
                         if (w_next >= total) { more = false; w_next = w_end = 0; break; }
                         w_end = min(w_next + bp.work_chunk, total);
                     }
@@ -429,23 +474,25 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     if (idle && rank < take) {
                         pair = idx;
                         qlen = bp.q_len[idx]; rlen = bp.r_len[idx];
-                        flags = (qlen < (uint32_t)SM_B || rlen < (uint32_t)SM_B) ? 1u : 0u;
+                        bits = NBOOT | ((qlen < (uint32_t)SM_B || rlen < (uint32_t)SM_B) ? 8u : 0u) | ((uint32_t)DIR_GROW << 4);
                         // the state Block::align starts from (scan_block.rs:123-146), seen as four right steps of 8 columns that end
                         // with the block at (0, 0): borders MIN = 0, no offset yet
-                        si = 0; sj = (uint32_t)-(SM_B - STEP); dir = DIR_RIGHT; prev_dir = DIR_GROW; off = 0; off_max = 0; best_max = 0;
-                        y_drop = 0; x_iter = 0; D_corner = 0; nsteps = 0; trace_top = 0; nblocks = 0; sel = 0; boot = NBOOT; bmx = 0;
+                        si = 0; sj = (uint32_t)-(SM_B - STEP); dir = DIR_RIGHT; off = 0; off_max = 0; best_max = 0;
+                        ymix = 0; D_corner = 0; trace_top = 0; sel = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) { A_d[k] = 0; A_c[k] = 0; P_d[k] = 0; P_r[k] = 0; }
+                        for (int k = 0; k < 4; k++) { A_d[k] = 0; A_c[k] = 0; }
+                        *(int4*)(lbuf + 256u + 128u + l * 16) = int4{0, 0, 0, 0}; *(int4*)(lbuf + 256u + 192u + l * 16) = int4{0, 0, 0, 0};   // P of buffer 1 (sel = 0)
                         qp = bp.pool + bp.q_off[idx]; rp = bp.pool + bp.r_off[idx];
                         if (TRACE) {
                             const uint64_t t0 = bp.trace_off[idx], b0 = bp.blocks_off[idx];
-                            tr = bp.trace_arena + t0; bl = bp.blocks + b0;
-                            tcap = (uint32_t)min(bp.trace_off[idx + 1] - t0, (uint64_t)0x7fffffffu); bcap = (uint32_t)min(bp.blocks_off[idx + 1] - b0, (uint64_t)0x7fffffffu);
+                            tr16 = (uint32_t)(t0 >> 4); bpos = (uint32_t)b0;
+                            room = room_of((uint32_t)min(bp.trace_off[idx + 1] - t0, (uint64_t)0x7fffffffu), (uint32_t)min(bp.blocks_off[idx + 1] - b0, (uint64_t)0x7fffffffu), 0u, 0u);
                         }
                         if (l == 0) {   // what the record holds besides the loop's state
                             int* rc = (int*)(slot_mem + 2 * SM_BUF_BYTES);
                             rc[MR_PAIR] = (int)idx; rc[MR_BEST_I] = 0; rc[MR_BEST_J] = 0; rc[MR_CELLS_LO] = 0; rc[MR_CELLS_HI] = 0;
                             rc[MR_BUDGET] = (int)(64u * ((qlen + rlen) / STEP + 64u)); rc[MR_STATUS] = 0; rc[MR_TSLOT] = (int)idx;
+                            rc[MR_SI] = 0; rc[MR_SJ] = -(SM_B - STEP); rc[MR_NSTEPS] = 0;   // (the position the steps are counted from)
                         }
                         pf_ok = false;
                     }
@@ -455,21 +502,22 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
 
                 // ---- the step every live slot is about to take (scan_block.rs:147-246)
                 const bool right = dir == DIR_RIGHT;
+                const uint32_t boot = bits & 7u; const int prev_dir = (int)((bits >> 4) & 3u), x_iter = (int)((bits >> 6) & 3u);
                 const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (SM_B - STEP);
                 const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
                 const bool q_out = si + SM_B > qlen, r_out = sj + SM_B > rlen;
                 // a step that could break early at the matrix edge (vectors past the end of their sequence and a column at or past the end of
                 // the other; never with X-drop) is not a slot's -- except the step that ends a global alignment (`fin` below)
                 bool elig = XDROP || ri + SM_B <= lenV || rj + STEP <= lenC || (boot == 0 && q_out && r_out);
-                if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * SM_B / 8) + 64 <= tcap;   // (a step that would not fit is the solo driver's to report)
-                leave = live && (!elig || (flags & 1u));
-                if (leave && boot) flags |= 1u;   // (a first block cut short: once more from the start)
+                if (TRACE) elig = elig && room > 0;   // (a step that would not fit is the solo driver's to report)
+                leave = live && (!elig || (bits & 8u));
+                if (leave && boot) bits |= 8u;   // (a first block cut short: once more from the start)
                 const bool run = live && !leave;
                 const int off_n = off_max;
                 const int off_add = sat16(off - off_n);
                 const int corner = (prev_dir != dir && prev_dir != DIR_GROW) ? sat16(D_corner + off_add) : 0;
                 // the state before the step: for a slot that leaves (its registers do not survive the step) and for the checkpoint
-                if (live) stage(sel ^ 1u, boot ? 2 : 1, si, sj, off_n, trace_top, nblocks, dir, off_add, corner);
+                if (live) stageA(sel ^ 1u, boot ? 2 : 1, si, sj, off_n, trace_top, bpos, dir, off_add, corner);
                 uint2 vb, cbv;
                 {
                     const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
@@ -482,36 +530,41 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                             cbv.x = cp[0]; cbv.y = cp[1];
                         }
                     }
-                    asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
-                    if (run) {                                    // for the step after this one, whichever way it goes
-                        const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);   // (first block: sj is not a position yet)
-                        const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));   // (32-bit sum: sj is "negative" during the first block)
-                        pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
-                        pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
-                        pf_ok = true;
-                    }
                 }
                 uint32_t* tw = nullptr;
                 if (TRACE) {
-                    tw = tr + trace_top + 8 * l;
+                    // (a slot without a step writes to the wave's sink: the first 64 x 16 words of the arena's sink area, ba_host.cpp; selected by
+                    // 32-bit pieces: no 64-bit pointer pair lives across the step)
+                    const uint32_t t16 = run ? tr16 : fill_wave * 64u + (uint32_t)lane, tt = run ? trace_top : 0u;
+                    tw = bp.trace_arena + ((uint64_t)t16 << 4) + tt + 8 * l;
                     if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,284); the first block: four records
                         BlockRec br;
                         br.i = (right ? ri : rj) | 0x80000000u;   // (bit 31: words of 4 cells x 2 columns, see multi_rect)
                         br.j = right ? rj : ri; br.h = (uint16_t)(right ? SM_B : STEP); br.w = (uint16_t)(right ? STEP : SM_B);
                         br.trace_base = trace_top | (right ? 0x80000000u : 0u);
-                        bl[nblocks] = br;
+                        bp.blocks[bpos] = br;
                     }
                 }
                 const bool fin = !XDROP && run && boot == 0 && q_out && r_out;   // the last step of a global alignment
                 const bool fin_any = !XDROP && __any(fin);
                 const uint32_t fin_col = lenC - rj;   // its last computed column (0 .. 7: columns rj .. lenC)
                 int dsel[4] = {0, 0, 0, 0};
+                int Pn_d[4], Pn_r[4];   // the orthogonal border pair after the step
                 MultiOut o;
-                small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw, run,
+                small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, Pn_d, Pn_r, lbuf + (sel ^ 1u) * 256u + 128u + l * 16, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw,
                                                 fin_any, fin ? fin_col : 8u, dsel, o);
+                // sequence bytes of the step after this one, whichever way it goes: issued behind the columns (the eight registers are not live
+                // across them), consumed at the top of the next step -- consecutive steps read consecutive bytes, mostly out of the L1
+                if (run) {
+                    const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);   // (first block: sj is not a position yet)
+                    const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));   // (32-bit sum: sj is "negative" during the first block)
+                    pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
+                    pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
+                    pf_ok = true;
+                }
                 if (boot) {   // the first block's maximum so far
-                    bmx = boot == NBOOT ? o.mx : max(bmx, o.mx);
-                    o.mx = bmx;
+                    ymix = boot == NBOOT ? o.mx : max(ymix, o.mx);
+                    o.mx = ymix;
                 }
                 const bool bsub = run && boot > 1, blast = run && boot == 1;
 
@@ -519,7 +572,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
                 const int new_off_max = off_n + o.mx - ZERO;
                 const bool improve = new_off_max > best_max;
-                const uint32_t new_y = improve ? 0u : y_drop + 1;
+                const uint32_t new_y = improve ? 0u : (uint32_t)ymix + 1;   // (during the first block ymix is not a count: its last sub-step goes on only if it improves)
                 bool stop = q_out && r_out;                                                                   // end of the matrix
                 if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
                 stop = stop || (!q_out && !r_out && 2 * (uint32_t)SM_B <= max_size && new_y > SM_B / STEP - 1);   // grow
@@ -539,49 +592,55 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     if (fin && l == 0) {
                         const char* rcp = slot_mem + 2 * SM_BUF_BYTES;
                         const unsigned long long cells0 = (unsigned long long)(uint32_t)mq_load(rcp + 4 * MR_CELLS_LO) | ((unsigned long long)(uint32_t)mq_load(rcp + 4 * MR_CELLS_HI) << 32);
+                        const uint32_t nb1 = TRACE ? bpos - (uint32_t)bp.blocks_off[pair] + 1u : 0u;
                         bp.score[pair] = off_n + sc16 - ZERO; bp.query_idx[pair] = qlen; bp.reference_idx[pair] = rlen;
+                        const uint32_t nsteps = (uint32_t)mq_load(rcp + 4 * MR_NSTEPS) + ((si + sj) - ((uint32_t)mq_load(rcp + 4 * MR_SI) + (uint32_t)mq_load(rcp + 4 * MR_SJ))) / STEP;
                         if (bp.cells) bp.cells[pair] = cells0 + (unsigned long long)nsteps * (STEP * SM_B) + (unsigned long long)(fin_col + 1u) * SM_B;
                         if (bp.status) bp.status[pair] = (uint32_t)mq_load(rcp + 4 * MR_STATUS);
-                        if (bp.nblocks_out) bp.nblocks_out[pair] = TRACE ? nblocks + 1 : 0;
+                        if (bp.nblocks_out) bp.nblocks_out[pair] = nb1;
                         if (bp.trace_words_out) bp.trace_words_out[pair] = TRACE ? trace_top + STEP * SM_B / 8 : 0;
                         if (bp.slot_out) bp.slot_out[pair] = pair;
-                        if (TRACE) bp.slot_info[pair] = SlotInfo{pair, nblocks + 1, qlen, rlen};
+                        if (TRACE) bp.slot_info[pair] = SlotInfo{pair, nb1, qlen, rlen};
                     }
                     if (fin) pair = ~0u;
                 }
-                if (again) flags |= 1u;
+                if (again) bits |= 8u;
                 leave = leave || again || (run && stop && !bsub && !blast && !fin);   // rolled back: the pair's state is what was staged before this step
                 if (bsub) {
-                    sj += STEP; nsteps++; boot--;
-                    if (TRACE) { trace_top += STEP * SM_B / 8; nblocks++; }
+                    sj += STEP; bits -= 1u;
+                    if (TRACE) { trace_top += STEP * SM_B / 8; bpos++; room--; }
                 }
+                bool swap = false;
                 if (commit) {
                     if (improve) {
                         if (keep_pre) sel ^= 1u;   // the state staged before this step is the checkpoint now (and yields the location of the maximum)
                         best_max = new_off_max;
                     }
-                    off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = blast ? DIR_GROW : dir; D_corner = blast ? 0 : o.corner_new;
-                    nsteps++; boot = 0;
-                    if (TRACE) { trace_top += STEP * SM_B / 8; nblocks++; }
-                    if (XDROP) x_iter = (off_max < best_max - x_drop) ? x_iter + 1 : 0;
+                    off = off_n; off_max = new_off_max; ymix = (int)new_y; D_corner = blast ? 0 : o.corner_new;
+                    if (TRACE) { trace_top += STEP * SM_B / 8; bpos++; room--; }
+                    const uint32_t nx = (XDROP && off_max < best_max - x_drop) ? (uint32_t)x_iter + 1u : 0u;
+                    bits = ((uint32_t)(blast ? DIR_GROW : dir) << 4) | (nx << 6);   // boot = 0, no restart flag
                     const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
                     si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
                     const int ndir = go_down ? DIR_DOWN : DIR_RIGHT;
-                    if (ndir != dir) {   // the borders change roles with the direction
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int td = A_d[k], tc = A_c[k];
-                            A_d[k] = P_d[k]; A_c[k] = P_r[k]; P_d[k] = td; P_r[k] = tc;
-                        }
-                    }
+                    swap = ndir != dir;   // the borders change roles with the direction
                     dir = ndir;
+                }
+                if (commit || bsub) {   // the orthogonal pair of the next step: to its place in the buffer the next step is staged in
+                    int4 npd, npr;
+                    npd.x = swap ? A_d[0] : Pn_d[0]; npd.y = swap ? A_d[1] : Pn_d[1]; npd.z = swap ? A_d[2] : Pn_d[2]; npd.w = swap ? A_d[3] : Pn_d[3];
+                    npr.x = swap ? A_c[0] : Pn_r[0]; npr.y = swap ? A_c[1] : Pn_r[1]; npr.z = swap ? A_c[2] : Pn_r[2]; npr.w = swap ? A_c[3] : Pn_r[3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { A_d[k] = swap ? Pn_d[k] : A_d[k]; A_c[k] = swap ? Pn_r[k] : A_c[k]; }
+                    char* b = lbuf + (sel ^ 1u) * 256u + l * 16;
+                    *(int4*)(b + 128) = npd; *(int4*)(b + 192) = npr;
                 }
                 if (__any(leave)) break;
             }
-            // ---- every slot's state at the top of the loop to memory: the registers of the slots that took the step (the others'
-            // was staged before it)
+            // ---- every slot's state at the top of the loop to memory: the A registers of the slots that took the step (the others' were
+            // staged before it; P is in the buffer already)
             const bool live = pair != ~0u;
-            if (live && !leave) stage(sel ^ 1u, boot ? 2 : 1, si, sj, 0, trace_top, nblocks, dir, 0, 0);
+            if (live && !leave) stageA(sel ^ 1u, (bits & 7u) ? 2 : 1, si, sj, 0, trace_top, bpos, dir, 0, 0);
             lds_sync();
             if (live) {   // both buffers back to the arena (solo mode needs the LDS region, and reads a pair's state from the arena)
 #pragma unroll
@@ -596,9 +655,12 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             lds_sync();
             if (live && l == 0) {
                 int* rc = (int*)(slot_mem + 2 * SM_BUF_BYTES);
-                rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = prev_dir; rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
-                rc[MR_Y_DROP] = (int)y_drop; rc[MR_X_ITER] = x_iter; rc[MR_D_CORNER] = D_corner; rc[MR_NSTEPS] = (int)nsteps; rc[MR_TRACE_TOP] = (int)trace_top;
-                rc[MR_NBLOCKS] = (int)nblocks; rc[MR_SEL] = (int)sel; rc[MR_FLAGS] = (int)flags; rc[MR_BOOT] = (int)boot; rc[MR_BMX] = bmx;
+                const char* rcp = (const char*)rc;
+                rc[MR_NSTEPS] = (int)((uint32_t)mq_load(rcp + 4 * MR_NSTEPS) + ((si + sj) - ((uint32_t)mq_load(rcp + 4 * MR_SI) + (uint32_t)mq_load(rcp + 4 * MR_SJ))) / STEP);
+                rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = (int)((bits >> 4) & 3u); rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
+                rc[MR_Y_DROP] = (bits & 7u) ? 0 : ymix; rc[MR_X_ITER] = (int)((bits >> 6) & 3u); rc[MR_D_CORNER] = D_corner; rc[MR_TRACE_TOP] = (int)trace_top;
+                rc[MR_NBLOCKS] = TRACE ? (int)(bpos - (uint32_t)bp.blocks_off[pair]) : 0; rc[MR_SEL] = (int)sel; rc[MR_FLAGS] = (int)((bits >> 3) & 1u); rc[MR_BOOT] = (int)(bits & 7u);
+                rc[MR_BMX] = (bits & 7u) ? ymix : 0;
             }
             const unsigned long long lm = __ballot(leave && l == 0), vm = __ballot(live && l == 0);
             pend_m = 0; live_m = 0;
