@@ -530,6 +530,18 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                             cbv.x = cp[0]; cbv.y = cp[1];
                         }
                     }
+#ifndef SM_PREFETCH_LATE
+                    asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
+                    // sequence bytes of the step after this one, whichever way it goes: in flight across the columns, so that the wait for them at
+                    // the top of the next step does not wait for this step's trace stores (issued behind them: the memory counter is in order)
+                    if (run) {
+                        const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);   // (first block: sj is not a position yet)
+                        const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));   // (32-bit sum: sj is "negative" during the first block)
+                        pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
+                        pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
+                        pf_ok = true;
+                    }
+#endif
                 }
                 uint32_t* tw = nullptr;
                 if (TRACE) {
@@ -553,15 +565,17 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 MultiOut o;
                 small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, Pn_d, Pn_r, lbuf + (sel ^ 1u) * 256u + 128u + l * 16, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw,
                                                 fin_any, fin ? fin_col : 8u, dsel, o);
-                // sequence bytes of the step after this one, whichever way it goes: issued behind the columns (the eight registers are not live
-                // across them), consumed at the top of the next step -- consecutive steps read consecutive bytes, mostly out of the L1
+#ifdef SM_PREFETCH_LATE
+                // (variant: the prefetch issued behind the columns -- its registers are not live across them, but the wait for it at the top of
+                // the next step then also waits for this step's trace stores: the memory counter is in order)
                 if (run) {
-                    const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);   // (first block: sj is not a position yet)
-                    const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));   // (32-bit sum: sj is "negative" during the first block)
+                    const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);
+                    const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));
                     pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
                     pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
                     pf_ok = true;
                 }
+#endif
                 if (boot) {   // the first block's maximum so far
                     ymix = boot == NBOOT ? o.mx : max(ymix, o.mx);
                     o.mx = ymix;

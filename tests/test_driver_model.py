@@ -1,0 +1,118 @@
+"""oracle == tests/driver_model.py (a second, independent transcription of scan_block.rs / avx2.rs: see its docstring) on random pairs
+with forced grows, checkpoint restores, shrinks and X-drop termination after growth, at (16, 64), (32, 256), (128, 1024) and fixed sizes,
+all mode bits, three matrix kinds: score, end indices, computed cells, both CIGAR forms from the end position, Trace::blocks().
+What this pins and what it does not: two readings of the Rust source by the same builder agree cell for cell; the crate itself is pinned
+by the reference-held known answers (tests/golden/reference_kats.json) and -- once somebody runs rust/examples/dump_golden.rs -- by
+tests/test_crate_golden.py."""
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+from block_aligner_amd import scores as S
+from block_aligner_amd import synth
+
+MODES = [(), ("x_drop",), ("trace",), ("trace", "x_drop"), ("trace", "local_start"), ("trace", "x_drop", "local_start"),
+         ("trace", "free_query_start_gaps"), ("trace", "x_drop", "free_query_start_gaps"), ("trace", "free_query_end_gaps"),
+         ("trace", "local_start", "free_query_end_gaps"), ("local_start",), ("free_query_end_gaps",)]
+BYTE_ALPHA = np.frombuffer(b"abcdefghij", np.uint8)
+KINDS = {"nuc": (synth.DNA, lambda: S.NucMatrix.new_simple(2, -3), (-5, -1)), "aa": (synth.AMINO, lambda: S.static_matrix("BLOSUM62"), (-11, -1)),
+         "bytes": (BYTE_ALPHA, lambda: S.BYTES1, (-2, -1))}
+
+
+def make_case(rng, kind, size, mode):
+    alpha = KINDS[kind][0]
+    n = int(rng.integers(0, 50)) if rng.random() < 0.1 else int(rng.integers(40, 1800 if size[1] >= 1024 else 700))
+    r = synth.rand_str(rng, n, alpha)
+    q = synth.mutate(rng, r, int(rng.integers(0, 1 + n // 6)), alpha) if n else r
+    if n > 120 and rng.random() < 0.7:   # a long insertion or deletion: grow, checkpoint restore, shrink
+        at = int(rng.integers(20, len(q) - 20)); ln = int(rng.integers(8, min(300, 3 * size[1])))
+        q = np.concatenate([q[:at], synth.rand_str(rng, ln, alpha), q[at:]]) if rng.random() < 0.5 else np.concatenate([q[:at], q[at + ln:]])
+    if rng.random() < 0.5:               # unrelated tails: X-drop termination after growth
+        q = np.concatenate([q, synth.rand_str(rng, int(rng.integers(0, 200)), alpha)])
+        r = np.concatenate([r, synth.rand_str(rng, int(rng.integers(0, 200)), alpha)])
+    if "free_query_end_gaps" in mode:    # (its precondition: min block size > query length, scan_block.rs:864)
+        k = int(rng.integers(0, max(size[0], 16)))
+        at = int(rng.integers(0, max(1, len(q) - k)))
+        q = q[at: at + k]
+    return q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()
+
+
+def run_chunk(args):
+    """One worker: `count` cases from `seed`; returns (cases run, cases that grew, list of mismatches)."""
+    seed, count, kind, sizes = args
+    from oracle.oracle_py import Oracle
+    from tests.driver_model import Model
+    oracle = Oracle("avx2")
+    matrix, gaps = KINDS[kind][1](), KINDS[kind][2]
+    rng = np.random.default_rng(seed)
+    bad, grew, ran = [], 0, 0
+    for c in range(count):
+        size = sizes[c % len(sizes)]
+        mode = MODES[int(rng.integers(0, len(MODES)))]
+        if kind == "bytes" and "x_drop" in mode:
+            mode = tuple(m for m in mode if m != "x_drop")   # (documented as inaccurate by the reference, scores.rs:235-239)
+        q, r = make_case(rng, kind, size, mode)
+        xd = int(rng.integers(10, 120)) if "x_drop" in mode else 0
+        try:
+            ref = oracle.align(matrix, q, r, gaps, size, xd, mode)
+        except RuntimeError:
+            continue   # (an end position in the padding: Trace::cigar asserts -- the crate would panic too)
+        m = Model(**{k: True for k in mode})
+        got = m.align(q, r, matrix, gaps, size, xd)
+        ran += 1
+        grew += m.end_block_size > max(size[0], 16) or len(m.blocks()) > (len(q) + len(r)) // 8 + 6
+        what = []
+        for k in ("score", "query_idx", "reference_idx", "cells"):
+            if got[k] != ref[k]:
+                what.append((k, got[k], ref[k]))
+        if m.end_block_size != ref["end_block_size"]:
+            what.append(("end_block_size", m.end_block_size, ref["end_block_size"]))
+        if "trace" in mode and not what:
+            if m.cigar(got["query_idx"], got["reference_idx"]) != ref["cigar"]:
+                what.append(("cigar",))
+            if m.cigar(got["query_idx"], got["reference_idx"], eq=True) != oracle.align(matrix, q, r, gaps, size, xd, mode, cigar_eq=True)["cigar"]:
+                what.append(("cigar_eq",))
+            if m.blocks() != oracle.align_blocks(matrix, q, r, gaps, size, xd, mode):
+                what.append(("blocks",))
+        if what:
+            bad.append((seed, c, kind, size, mode, len(q), len(r), what))
+    return ran, grew, bad
+
+
+@pytest.mark.parametrize("kind,sizes,total", [("nuc", [(16, 64), (32, 256), (16, 16), (32, 32)], 1200), ("nuc", [(128, 1024), (64, 2048)], 160),
+                                               ("aa", [(16, 64), (32, 256), (32, 64)], 700), ("bytes", [(16, 64), (32, 128)], 240)])
+def test_oracle_equals_the_independent_model(kind, sizes, total):
+    workers = 8
+    per = total // workers
+    with mp.get_context("fork").Pool(workers) as pool:
+        out = pool.map(run_chunk, [(9000 + 17 * w + len(sizes) * 1000 + total, per, kind, sizes) for w in range(workers)])
+    ran = sum(o[0] for o in out); grew = sum(o[1] for o in out); bad = [b for o in out for b in o[2]]
+    assert not bad, bad[:5]
+    assert ran >= total * 9 // 10 and grew >= ran // 4, (ran, grew)
+
+
+def test_model_passes_the_reference_known_answers(kats):
+    """The model against the reference-held vectors themselves (the alignment KATs of scan_block.rs:1908-2230 that use two sequences)."""
+    from tests.common import kat_matrix
+    from tests.driver_model import Model
+    from tests.driver_model import prefix_scan
+    for k in kats["lane"]:   # avx2.rs:469-489
+        assert list(prefix_scan(np.array(k["input"], np.int64), k["gap"])) == k["expect"], k["name"]
+    n = 0
+    for k in kats["align"] + kats["inferred"]:
+        if k["kind"] == "profile":
+            continue
+        m = Model(**{x: True for x in k["mode"]})
+        got = m.align(k["q"].encode(), k["r"].encode(), kat_matrix(k), tuple(k["gaps"]), tuple(k["size"]), k.get("x_drop", 0))
+        e = k["expect"]
+        assert got["score"] == e["score"], (k["name"], got, e)
+        for f in ("query_idx", "reference_idx"):
+            if f in e:
+                assert got[f] == e[f], (k["name"], f, got, e)
+        if "cigar" in e:
+            assert m.cigar(got["query_idx"], got["reference_idx"]) == e["cigar"], k["name"]
+        if "cigar_eq" in e:
+            assert m.cigar(got["query_idx"], got["reference_idx"], eq=True) == e["cigar_eq"], k["name"]
+        n += 1
+    assert n >= 30
