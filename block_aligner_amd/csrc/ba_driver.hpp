@@ -1198,7 +1198,7 @@ struct Aligner {
     // in ck_reg: see import_slot), leave again -- returning the state, exited = 1 -- once the next step is a plain shift step at MQ_B
     // cells (allow_quad), after taking the step at the top here whatever it is (forced_in: the slot rolled it back)
     __device__ __forceinline__ RunOut run(uint32_t pair_in, uint32_t slot_in, bool batch_traceback, const PairCont* resume = nullptr, const int mmode_in = MM_NONE,
-                                          const RunOut min = RunOut{}, const bool allow_quad = false, const bool forced_in = false) {
+                                          const RunOut min = RunOut{}, const bool allow_quad = false, const bool forced_in = false, const bool walk_now = false) {
         RunOut mout{}; bool forced = MULTI && forced_in;
         const int mmode = MULTI ? mmode_in : (int)MM_NONE;
         BA_TSTAMP(tq0);
@@ -1598,6 +1598,21 @@ struct Aligner {
 #ifdef BA_TIMING
         prof[16] += steps;
 #endif
+        if (TRACE && XDROP && chain && coldp()->prof) {
+            // The speculative (untraced) rectangles left on the stack: cells that needed neither trace flags nor location bookkeeping. Their
+            // sum goes to a counter of the launch (bench.py's ops_required); they sit among the last records of the stack (the chain of grows
+            // that closed the alignment and the shift steps between them). Records read past the L1: this wave's own stores.
+            uint32_t sc = 0;
+            const uint32_t nscan = min(nblocks, 512u);
+            for (uint32_t k = (uint32_t)lane_id(); k < nscan; k += 64u) {
+                const uint32_t* rp = (const uint32_t*)(blocks + (nblocks - 1u - k));
+                const uint32_t hw = __hip_atomic_load(rp + 2, BA_RLX_AGENT), tb = __hip_atomic_load(rp + 3, BA_RLX_AGENT);
+                if (tb & 0x40000000u) sc += (hw & 0xffffu) * (hw >> 16);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sc += (uint32_t)__shfl_xor((int)sc, d, 64);
+            if (is_lane(0) && sc) atomicAdd(coldp()->prof + 60, (unsigned long long)sc);
+        }
         const uint32_t pair = (uint32_t)unpark<7>(parked), slot = (uint32_t)unpark<8>(parked);
         int score; uint32_t ri, rj;
         if (XDROP || FQE) { score = best_max; ri = (uint32_t)unpark<5>(parked); rj = (uint32_t)unpark<6>(parked); }
@@ -1619,7 +1634,8 @@ struct Aligner {
             return mout;
         }
         // pair-slot batches: pairs shorter than inline_len2 leave their paths to k_walk (one pair per lane) instead of this wave's lane 0
-        const bool walk_later = TRACE && coldp()->trace_off && qlen + rlen < coldp()->inline_len2;
+        // (walk_now: k_small's longest pairs, run one to a wave at the start of the launch -- their walks, the batch's longest, overlap with the fill)
+        const bool walk_later = TRACE && coldp()->trace_off && qlen + rlen < coldp()->inline_len2 && !(MULTI && walk_now);
         if (TRACE && coldp()->cig_ops && !status && !walk_later) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back

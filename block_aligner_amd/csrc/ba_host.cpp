@@ -109,6 +109,10 @@ constexpr int BA_KIND_PROFILE_ = ba::KIND_PROFILE;   // batches whose "reference
 #else
 #define dev_env(name) ((const char*)nullptr)
 #endif
+#ifndef BA_BUILD_ID
+#define BA_BUILD_ID "unknown"
+#endif
+extern "C" const char* ba_build_id(void) { return BA_BUILD_ID; }   // tools/kernel_hash.py over the kernel sources at build time
 extern "C" int ba_dev_build(void) {
 #ifdef BA_DEV
     return 1;
@@ -893,8 +897,16 @@ static void plan_walks(BaBatch* b, const std::vector<uint32_t>& ql, const std::v
     uint32_t longest = 0;
     for (size_t p = 0; p < n; p++) longest = std::max(longest, ql[p] + rl[p]);
     const uint32_t from = std::max(longest / frac, 512u);
+    // The walkers take the leading walk_wave_n pairs of the batch order. That order is longest first only when pack_pairs sorted it (it keeps
+    // the caller's order when that is already sorted -- or when told to): then count the leading run; otherwise no pair is singled out rather
+    // than an arbitrary prefix (round-3 advisor finding: an unsorted order stopped the prefix test at its first short pair).
+    bool sorted = true;
+    for (size_t p = 1; p < n && sorted; p++) sorted = (uint64_t)ql[p] + rl[p] <= (uint64_t)ql[p - 1] + rl[p - 1] + 64;   // (cost order: ties and near-ties in any order)
     size_t cnt = 0;
-    while (cnt < n && cnt < kmax && ql[cnt] + rl[cnt] >= from) cnt++;   // (device order: longest first)
+    if (sorted) while (cnt < n && cnt < kmax && ql[cnt] + rl[cnt] >= from) cnt++;
+    // equal-length batches (every pair qualifies): whole-wave walks are for a FEW long paths beside many lane walks, not for a prefix of a
+    // uniform batch
+    if (cnt == std::min<size_t>(n, kmax) && n > kmax) cnt = 0;
     b->walk_wave_n = (uint32_t)cnt;
 }
 // k_small: sixteen pairs to a wave make every pair sixteen times as long in flight (and a neighbour's solo episode stops a slot), so a pair
@@ -984,7 +996,9 @@ static int batch_launch(BaBatch* b) {
     } else if (b->small) {
         // k_small takes every pair from start to end (slots at 32 cells, everything else by the same wave in solo mode); TRACE: a pair-slot
         // batch -- the fill only stacks, k_walk (its form for slot rectangles) walks all paths afterwards
-        BatchParams p1 = bp; p1.cig_ops = nullptr; p1.inline_len2 = ~0u;
+        // (the pairs run one to a wave at the start of the launch -- the batch's longest -- walk their paths at once, with the whole wave:
+        // the longest walk of the batch overlaps with the fill instead of ending the launch)
+        BatchParams p1 = bp; p1.inline_len2 = ~0u;
         HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
         if ((b->mode & BA_TRACE) && bp.cig_ops) {
             HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
@@ -1213,6 +1227,19 @@ int ba_batch_compact_cigars(BaBatch* b, uint32_t* pinned_out, uint64_t pinned_ca
     // (a device-to-host copy issued while another batch's persistent launch fills the machine waits for that launch: copies of this size
     // are done by copy kernels). Otherwise: into a device buffer.
     uint32_t* out = pinned_out; uint64_t cap = pinned_capacity;
+    if (out) {
+        // a kernel writes through this pointer: it must be host memory the device can reach (ba_host_alloc / hipHostMalloc / hipHostRegister)
+        // and hold pinned_capacity runs -- an ordinary malloc or numpy buffer here would be a GPU page fault that takes the process down
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, out) != hipSuccess) { (void)hipGetLastError(); return fail("ba_batch_compact_cigars: pinned_out is not page-locked host memory (use ba_host_alloc)"); }
+        if (at.type != hipMemoryTypeHost) return fail("ba_batch_compact_cigars: pinned_out must be page-locked HOST memory (use ba_host_alloc)");
+        void* base = nullptr; size_t range = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &range, (hipDeviceptr_t)at.devicePointer) == hipSuccess && base) {
+            const size_t used = (size_t)((const char*)at.devicePointer - (const char*)base);
+            if (range < used || (range - used) / 4 < cap) return fail("ba_batch_compact_cigars: pinned_out holds %zu runs, pinned_capacity says %llu", (range - used) / 4, (unsigned long long)cap);
+        } else (void)hipGetLastError();
+        out = (uint32_t*)at.devicePointer;   // (the address the device uses for this allocation; the same value for ba_host_alloc memory)
+    }
     if (!out) {
         if (!b->compact.p) {
             // capacity: a third of the worst case (every cell of a pair's path its own run) covers any real alignment; if it ever does not,
@@ -1272,6 +1299,16 @@ int ba_batch_prof(BaBatch* b, uint64_t out[128]) {   // development: phase timer
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {
     if (!b) return fail("null batch");
     out[0] = (uint64_t)b->grid * ba::WAVES_PER_WG; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
+    return 0;
+}
+// Cells of the speculative, untraced rectangles of the last run (X-drop + TRACE batches: the chain of grows that closes an alignment,
+// ba_driver.hpp run()): part of the computed cells, filled without trace flags and location bookkeeping (14 instead of 20 int16
+// operations per cell). Pairs re-run for a trace overflow are not in it.
+int ba_batch_spec_cells(BaBatch* b, uint64_t* cells) {
+    if (!b || !cells) return fail("null argument");
+    if (!b->ran) return fail("ba_batch_run has not been called");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(cells, (const char*)b->prof.p + 60 * 8, 8, hipMemcpyDeviceToHost));
     return 0;
 }
 int ba_batch_kernel(BaBatch* b) { return !b ? -1 : (b->small ? 3 : (b->quad ? 2 : (b->multi ? 1 : 0))); }

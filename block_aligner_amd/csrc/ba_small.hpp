@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             park<4>(keepv, (more ? 1 : 0) | (excl_more ? 2 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair);
             // (a pair in solo mode keeps the wave's other fifteen slots waiting: its dependent chain goes first among the SIMD's waves)
             __builtin_amdgcn_s_setprio(MQ_SOLO_PRIO);
-            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh);
+            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh, to_end);
             __builtin_amdgcn_s_setprio(0);
             live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
             more = unpark<4>(keepv) & 1; excl_more = unpark<4>(keepv) & 2; solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv);
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                             cbv.x = cp[0]; cbv.y = cp[1];
                         }
                     }
-#ifndef SM_PREFETCH_LATE
+#ifdef SM_PREFETCH_EARLY
                     asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
                     // sequence bytes of the step after this one, whichever way it goes: in flight across the columns, so that the wait for them at
                     // the top of the next step does not wait for this step's trace stores (issued behind them: the memory counter is in order)
@@ -565,9 +565,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 MultiOut o;
                 small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, Pn_d, Pn_r, lbuf + (sel ^ 1u) * 256u + 128u + l * 16, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw,
                                                 fin_any, fin ? fin_col : 8u, dsel, o);
-#ifdef SM_PREFETCH_LATE
-                // (variant: the prefetch issued behind the columns -- its registers are not live across them, but the wait for it at the top of
-                // the next step then also waits for this step's trace stores: the memory counter is in order)
+#ifndef SM_PREFETCH_EARLY
+                // sequence bytes of the step after this one, whichever way it goes: issued behind the columns (the eight registers are not live
+                // across them; consecutive steps read consecutive bytes, mostly out of the L1). The alternative -- issued at the top, in flight
+                // across the columns (-DSM_PREFETCH_EARLY) -- costs ~60 more instructions per step for the same time (same-box A/B: C2 -3.5 %).
                 if (run) {
                     const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);
                     const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));

@@ -129,6 +129,8 @@ def lib() -> C.CDLL:
         L.ba_device_memory.argtypes = [vp, vp]
         L.ba_batch_info.argtypes = [vp, vp]
         L.ba_batch_kernel.argtypes = [vp]
+        L.ba_batch_spec_cells.argtypes = [vp, vp]
+        L.ba_build_id.restype = C.c_char_p
         L.ba_batch_destroy.argtypes = [vp]
         L.ba_multibatch_create.restype = vp
         L.ba_multibatch_create.argtypes = [C.c_int, vp, GapsC, SizeRangeC, i32, u32, vp, vp, vp, vp, vp, sz, vp, C.c_int]
@@ -143,13 +145,32 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_pinned = {}   # base address -> (bytes, owning library) of the live ba_host_alloc buffers
+
+
 def pinned_array(n: int, dtype=np.uint32) -> np.ndarray:
-    """A numpy array over page-locked host memory (ba_host_alloc): pass it as `out=` to BatchAligner.cigars. Lives until the process ends."""
+    """A numpy array over page-locked host memory (ba_host_alloc): pass it as `out=` to BatchAligner.compact_cigars / cigars. Free it with
+    free_pinned(array) when done (nothing else frees it); arrays from anywhere else are refused where the device writes through them."""
     nbytes = int(n) * np.dtype(dtype).itemsize
     p = lib().ba_host_alloc(nbytes)
     if not p:
         raise RuntimeError(last_error())
+    _pinned[p] = (nbytes, lib())
     return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p)).view(dtype)
+
+
+def is_pinned(a: np.ndarray) -> bool:
+    """True if `a` lies inside a live pinned_array() buffer."""
+    addr = a.ctypes.data
+    return any(base <= addr and addr + a.nbytes <= base + nb for base, (nb, _) in _pinned.items())
+
+
+def free_pinned(a: np.ndarray) -> None:
+    """ba_host_free for an array made by pinned_array (the array must not be used afterwards)."""
+    ent = _pinned.pop(a.ctypes.data, None)
+    if ent is None:
+        raise ValueError("not the start of a pinned_array() buffer")
+    ent[1].ba_host_free(a.ctypes.data)
 
 
 def last_error() -> str:
@@ -406,6 +427,8 @@ class BatchAligner:
     def compact_cigars(self, pinned_out=None) -> None:
         """Between launch() and wait(): gather the CIGAR runs on the device behind the kernels -- straight into `pinned_out` (an array
         from pinned_array(); pass the same array as cigars(out=...)) or into a device buffer (cigars() is then one copy)."""
+        if pinned_out is not None and not is_pinned(pinned_out):
+            raise ValueError("compact_cigars writes through this buffer from the device: it must come from pinned_array()")
         if lib().ba_batch_compact_cigars(self._h, pinned_out.ctypes.data if pinned_out is not None else None, pinned_out.size if pinned_out is not None else 0):
             raise RuntimeError(last_error())
 
@@ -448,6 +471,13 @@ class BatchAligner:
         return lib().ba_batch_retried(self._h)
 
     KERNELS = ("k_align", "k_multi", "k_quad", "k_small")
+
+    def spec_cells(self) -> int:
+        """Cells of the last run's speculative, untraced rectangles (X-drop + TRACE): a part of results()["cells"]."""
+        o = C.c_uint64()
+        if lib().ba_batch_spec_cells(self._h, C.byref(o)):
+            raise RuntimeError(last_error())
+        return int(o.value)
 
     def info(self):
         o = np.zeros(4, np.uint64)

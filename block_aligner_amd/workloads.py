@@ -37,7 +37,8 @@ class Workload:
 
     @property
     def ops_per_cell(self) -> int:
-        return OPS_PER_CELL[self.mode]
+        base = tuple(m for m in self.mode if m in ("trace", "x_drop"))
+        return OPS_PER_CELL[base] + (1 if "local_start" in self.mode else 0)   # (+ the max with the relative zero, scan_block.rs:1134-1136)
 
     def full_matrix_cells(self) -> int:
         ql = self.pairs.q_len.astype(np.int64)
@@ -98,9 +99,39 @@ def config5(n: int = 5000, seed: int = 5) -> Workload:
                     pairs, None, (0, -1), (32, 256), 0, ("trace",), cigar_eq=False, profiles=profiles)
 
 
+def config_local(n: int = 50000, seed: int = 31) -> Workload:
+    """Seed extension with LOCAL_START (Block::<true, true, true>, scan_block.rs:825-846): 1 kbp DNA pairs whose first 100..300 bases are
+    unrelated, X-drop 50, block 32..256, traceback -- the alignment starts wherever the path's score first leaves zero."""
+    rng = np.random.default_rng(seed)
+    base = synth.make_pairs(n, 1000, 100, 50, synth.DNA, seed=seed)
+    lists = []
+    for p in range(n):
+        hq = synth.rand_str(rng, int(rng.integers(100, 300)), synth.DNA).astype(np.uint8).tobytes()
+        hr = synth.rand_str(rng, int(rng.integers(100, 300)), synth.DNA).astype(np.uint8).tobytes()
+        lists.append((hq + base.query(p), hr + base.reference(p)))
+    return Workload("LOCAL_START: %d x ~1.2 kbp DNA with unrelated heads, X-drop 50, block 32..256, traceback" % n, synth.PairSet.from_lists(lists),
+                    S.NucMatrix.new_simple(2, -3), (-5, -1), (32, 256), 50, ("local_start", "trace", "x_drop"))
+
+
+def config_free_end(n: int = 50000, seed: int = 32) -> Workload:
+    """FREE_QUERY_END_GAPS (scan_block.rs:825-846; precondition: min block size > query length): 40..120-base queries -- the start of
+    a 300..1500-base reference, mutated -- global in the reference's start, free gaps after the query's end; block 128..512, traceback."""
+    rng = np.random.default_rng(seed)
+    lists = []
+    for _ in range(n):
+        r = synth.rand_str(rng, int(rng.integers(300, 1500)), synth.DNA)
+        k = int(rng.integers(40, 121))
+        q = synth.mutate(rng, r[:k], int(rng.integers(0, 1 + k // 8)), synth.DNA)[:127]
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    return Workload("FREE_QUERY_END_GAPS: %d x 40..120-base queries on 300..1500-base references, global start, block 128..512, traceback" % n,
+                    synth.PairSet.from_lists(lists), S.NucMatrix.new_simple(2, -3), (-5, -1), (128, 512), 0, ("free_query_end_gaps", "trace"))
+
+
 def make_batch(H, w: Workload):
     """The HIP batch object for a workload (block_aligner_amd.hip.BatchAligner / ProfileBatchAligner)."""
     mode = (H.TRACE if "trace" in w.mode else 0) | (H.X_DROP if "x_drop" in w.mode else 0)
+    mode |= (H.LOCAL_START if "local_start" in w.mode else 0) | (H.FREE_QUERY_START_GAPS if "free_query_start_gaps" in w.mode else 0)
+    mode |= H.FREE_QUERY_END_GAPS if "free_query_end_gaps" in w.mode else 0
     if w.profiles:
         return H.ProfileBatchAligner(w.profiles, w.size, w.x_drop, mode, w.pairs.pool, w.pairs.q_off, w.pairs.q_len)
     if "trace" in w.mode and w.cigar_eq:

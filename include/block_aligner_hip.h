@@ -119,6 +119,12 @@ BA_DECLARE_BLOCK_FNS(aa_trace_xdrop, block_cigar_aa_trace_xdrop, block_cigar_eq_
 
 /* thread-local message for the last failing Part 2 call */
 const char* ba_last_error(void);
+/* 1 for the development build of the library (lib/libblock_aligner_hip_dev.so: reads the BA_* switches, tests and tools only), 0 for the
+ * release library, which reads no environment variables. */
+int ba_dev_build(void);
+/* Hash of the kernel sources this library was built from (tools/kernel_hash.py at build time): equal for the release and the
+ * development library of one build. */
+const char* ba_build_id(void);
 /* Page-locked host memory for result buffers (device-to-host copies into it run at PCIe speed; into pageable memory at a fraction). */
 void* ba_host_alloc(uint64_t bytes);
 void ba_host_free(void* p);
@@ -240,6 +246,10 @@ int ba_batch_info(BaBatch* batch, uint64_t out[4]);
 /* Which fill kernel the batch's launches use: 0 the per-pair kernel (k_align), 1 four pairs per wave at 128 cells (k_multi), 2 the round-2/3
  * small-block pipeline (k_quad + queue; profile batches), 3 sixteen pairs per wave at 32 cells (k_small). -1 for a null batch. */
 int ba_batch_kernel(BaBatch* batch);
+/* X-drop + BA_TRACE batches: cells of the last run's speculative, untraced rectangles (the chain of grows that closes an X-drop alignment
+ * can lie on no path: filled without trace flags and location bookkeeping) -- a part of the computed cells that needed 14 instead of 20
+ * int16 operations per cell (bench.py: roofline.ops_required). */
+int ba_batch_spec_cells(BaBatch* batch, uint64_t* cells);
 /* Large TRACE batches size their trace slots for the expected stack, not for the reference's worst case (Trace::new,
  * scan_block.rs:1363-1366); pairs that outgrow a slot are re-run with full-size slots inside ba_batch_run / ba_batch_wait.
  * Number of pairs the last run re-ran (results are identical either way; -1 for a null batch). */

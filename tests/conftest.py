@@ -53,8 +53,10 @@ def devlib(hip):
         import __graft_entry__
         __graft_entry__.build()
     release = hip.LIB_PATH
+    release_id = hip.lib().ba_build_id()
     hip.use_library(hip.DEV_LIB_PATH)
     assert hip.lib().ba_dev_build() == 1
+    assert hip.lib().ba_build_id() == release_id, "libblock_aligner_hip_dev.so is from another build than the release library: make -C block_aligner_amd/csrc"
     yield hip
     import gc
     gc.collect()          # objects of the test are freed by the library that made them

@@ -5,7 +5,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["ba_params.h", "ba_device.hpp", "ba_driver.hpp", "ba_quad.hpp", "ba_multi.hpp", "ba_kernels.hip", "ba_host.cpp", "Makefile"]
+FILES = ["ba_params.h", "ba_device.hpp", "ba_driver.hpp", "ba_quad.hpp", "ba_multi.hpp", "ba_small.hpp", "ba_kernels.hip", "ba_host.cpp", "Makefile"]
 
 
 def kernel_hash() -> str:
