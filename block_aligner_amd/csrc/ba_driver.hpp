@@ -1603,7 +1603,7 @@ struct Aligner {
             // sum goes to a counter of the launch (bench.py's ops_required); they sit among the last records of the stack (the chain of grows
             // that closed the alignment and the shift steps between them). Records read past the L1: this wave's own stores.
             uint32_t sc = 0;
-            const uint32_t nscan = min(nblocks, 512u);
+            const uint32_t nscan = nblocks < 512u ? nblocks : 512u;   // (`min` is this function's state parameter)
             for (uint32_t k = (uint32_t)lane_id(); k < nscan; k += 64u) {
                 const uint32_t* rp = (const uint32_t*)(blocks + (nblocks - 1u - k));
                 const uint32_t hw = __hip_atomic_load(rp + 2, BA_RLX_AGENT), tb = __hip_atomic_load(rp + 3, BA_RLX_AGENT);

@@ -767,10 +767,16 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // (1 kbp DNA, round 3 -- the per-pair kernel walks with whole waves now: 2.5 k pairs 0.78 / 1.89 ms without / with traceback against
     // 1.34 / 2.96 through the pipeline, 4 k 0.82 / 1.96 against 1.40 / 3.07, 8 k 1.37 / 3.18 against 1.44 / 3.31, 10 k 3.59 against 3.33)
     const size_t quad_from = kind == BA_KIND_AA ? 65536u : 8192u;
+    const bool trace_mode = mode & BA_TRACE;
     b->quad = !special_of(mode) && pc != BA_PCLASS_BIG && min_size == 32 && !dev_env("BA_NO_QUAD") && (dev_env("BA_FORCE_QUAD") || n >= quad_from);
     // Round 4: sequence kinds take k_small instead (ba_small.hpp) -- sixteen pairs per wave at 32 cells, eight cells per lane, and the grow /
     // shrink / X-drop end game of a pair by the same wave in solo mode: no queue, no launch beside. Block classes up to 1024 cells.
-    b->small = !profile && !special_of(mode) && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= quad_from && !dev_env("BA_FORCE_QUAD")));
+    // From the batch sizes at which sixteen pairs per wave still fill the machine (same-box sweeps, tools/dev/small_sweep.sh; GCUPS k_small /
+    // round-3 pipeline / per-pair kernel): 1 kbp DNA X-drop 40 k pairs 941 / 963 / 580, 80 k 1356 / 1154 / 622; with traceback 40 k 512 / 580 /
+    // 348, 80 k 791 / 742 / 393; protein pairs 30 k 388 / 303 / 369, 70 k 792 / 651 / 519; with traceback 70 k 258 / 283 / 210, 150 k 487 / 441 /
+    // 216. Below them the round-3 rules apply.
+    const size_t small_from = kind == BA_KIND_AA ? (trace_mode ? 98304u : 32768u) : (trace_mode ? 57344u : 49152u);
+    b->small = !profile && !special_of(mode) && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
     if (b->small) b->quad = false;
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
