@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--tail", type=int, default=500)
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE list of --pairs pairs, cut into cost-balanced slices, one per rank "
                                                         "(default: weak scaling, --pairs pairs per rank)")
+    ap.add_argument("--multibatch", action="store_true", help="ONE process, the library's own multi-GPU launcher (ba_multibatch_*: one list of pairs cut into "
+                                                            "cost-balanced slices, one per device) instead of one process per GPU under torch.distributed.run")
     ap.add_argument("--no-trace", action="store_true", help="score-only variant (not the headline workload)")
     ap.add_argument("--cpu-baseline-pairs", type=int, default=0, help="0 = size the sample for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,6 +124,7 @@ def secondary_line(np, H, W, o, w, cores):
     b = W.make_batch(H, w)
     ms = min(b.run() for _ in range(3))
     res = b.results()
+    kernel = b.info()["kernel"]
     if res["status"].any():
         raise RuntimeError(f"bench.py: {w.name}: pairs failed on the device")
     cells = int(res["cells"].sum())
@@ -152,7 +155,7 @@ def secondary_line(np, H, W, o, w, cores):
                 self_check(np, w, res, runs, off, range(0, checked, max(1, checked // 256)))
     b.close()
     gc = cells / (ms * 1e-3) / 1e9
-    return {"config": w.name, "gcups": round(gc, 1), "valu_frac": round(gc * 1e9 * w.ops_per_cell / 1e12 / VALU_PEAK_INT16_TOPS, 4),
+    return {"config": w.name, "kernel": kernel, "gcups": round(gc, 1), "valu_frac": round(gc * 1e9 * w.ops_per_cell / 1e12 / VALU_PEAK_INT16_TOPS, 4),
             "ops_per_cell": w.ops_per_cell, "kernel_ms": round(ms, 3), "pairs": n, "m_pairs_per_s": round(n / (ms * 1e-3) / 1e6, 3),
             "full_matrix_equiv_gcups": round(w.full_matrix_cells() / (ms * 1e-3) / 1e9, 1), "parity_checked_pairs": checked, "retried": retried}
 
@@ -186,14 +189,90 @@ def measure_e2e(np, H, W, w, sets=4):
         cells += int(res["cells"].sum())
         cur, nxt = nxt, cur
     dt = _t.perf_counter() - t0
+    cig_mb = round(int(off[-1]) * 4 / 1e6, 1)
+    del runs
     for b in bs:
         b.close()
-    return {"gcups": round(cells / dt / 1e9, 1), "sets": sets, "pairs_per_set": len(p), "seconds": round(dt, 3), "cigar_mb_per_set": round(int(off[-1]) * 4 / 1e6, 1),
+    for buf in bufs:
+        H.free_pinned(buf)
+    return {"gcups": round(cells / dt / 1e9, 1), "sets": sets, "pairs_per_set": len(p), "seconds": round(dt, 3), "cigar_mb_per_set": cig_mb,
             "what": "host pool -> device (reload) -> align -> scores + CIGAR runs in host memory, two batch objects alternating; PCIe and host packing included"}
+
+
+def run_multibatch(a):
+    """--multibatch: one process drives --gpus devices through the library's own launcher (ba_multibatch_*: ba_host.cpp ba_shard_slices cuts
+    ONE pair list into contiguous cost-balanced slices, one batch per device, each built by its own host thread and launched on its own
+    stream; results come back in the caller's order; no collective on the data path). Weak scaling by default (--pairs per device),
+    --strong for one list of --pairs pairs. Same timed region and the same JSON line as the torchrun form."""
+    import numpy as np
+    from block_aligner_amd import workloads as W
+    t0 = time.time()
+    trace = not a.no_trace
+    n_total = a.pairs if a.strong else a.pairs * a.gpus
+    w = W.config3(n_total, a.len, a.edits, a.tail, seed=1234, trace=trace, workers=a.gen_workers or min(32, usable_cpus()))
+    t_gen = time.time() - t0
+    import torch
+    from block_aligner_amd import hip as H
+    if H.device_count() < a.gpus:
+        raise RuntimeError(f"bench.py --multibatch --gpus {a.gpus}: only {H.device_count()} HIP devices visible (there is no CPU fallback)")
+    size = (H.percent_len(a.len, 0.01), H.percent_len(a.len, 0.1))
+    mode = H.X_DROP | ((H.TRACE | H.CIGAR_EQ) if trace else 0)
+    p = w.pairs
+    t0 = time.time()
+    mb = H.MultiBatchAligner(w.matrix, w.gaps, size, w.x_drop, mode, p.pool, p.q_off, p.q_len, p.r_off, p.r_len, list(range(a.gpus)))
+    t_setup = time.time() - t0
+
+    def sync_all():
+        for d in range(a.gpus):
+            torch.cuda.synchronize(d)
+
+    for _ in range(a.warmup):
+        mb.run()
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms = [mb.run() for _ in range(a.steps)]      # (each run launches every device's slice, then waits for all of them)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    res = mb.results()
+    if res["status"].any():
+        raise RuntimeError(f"{int((res['status'] != 0).sum())} pairs failed on the device")
+    cells = int(res["cells"].sum())
+    gcups = cells * a.steps / elapsed / 1e9
+    k_ms = float(np.mean(kernel_ms))                     # the slowest device's kernel time per step (HIP events on its stream)
+    ops = w.ops_per_cell
+    tops = cells / (k_ms * 1e-3) * ops / 1e12
+    parts = [int(x) for x in mb.parts()]
+    rescored = 0
+    if trace:
+        runs, off = mb.cigars(res["cigar_len"])
+        rescored = self_check(np, w, res, runs, off, range(0, n_total, max(1, n_total // 256)))
+    mb.close()
+    out = {
+        "metric": "GCUPS (DP cells/s) on 10 kbp DNA X-drop batch; bit-exact score+CIGAR vs AVX2",
+        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
+        "vs_baseline": None, "dtype": "i16 (saturating lane scores) + i32 block offsets", "data": "synthetic",
+        "config": {"workload": f"config 3: {a.pairs} pairs{' in total' if a.strong else '/GPU'} x {a.len} bp random DNA, {a.edits} edits, +{a.tail} bp random tails, "
+                               f"NucMatrix(2,-3), gaps(-5,-1), X-drop {w.x_drop}, block {size[0]}..{size[1]}, " + ("traceback to =/X CIGAR" if trace else "score only"),
+                   "launcher": "ba_multibatch_* (one process, one host thread and one stream per device)", "pairs_total": n_total, "slice_bounds": parts,
+                   "block": list(size), "trace": trace, "parallelism": f"{a.gpus} x independent shard", "gen_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
+                   "cells_per_step": cells},
+        "pairs_per_s": round(n_total * a.steps / elapsed, 1), "computed_cells": cells, "cigars_rescored": rescored,
+        "roofline": {"bound": "valu-int16", "achieved": round(tops, 3), "peak": round(VALU_PEAK_INT16_TOPS * a.gpus, 1), "unit": "Tint16-op/s",
+                     "frac": round(tops / (VALU_PEAK_INT16_TOPS * a.gpus), 5), "traffic": None, "kernel_ms": round(k_ms, 3),
+                     "note": "all devices together; kernel_ms = the slowest device's slice per step"},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
 
 
 def main():
     a = parse()
+    if a.multibatch:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            print("bench.py --multibatch is the one-process form: run it without torch.distributed.run", file=sys.stderr)
+            sys.exit(2)
+        return run_multibatch(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -291,10 +370,19 @@ def main():
             profile_ref = {"file": None, "note": f"profile record unreadable: {e}"}
         ops = w.ops_per_cell
         tops = gcups_kernel * 1e9 * ops / 1e12
+        # what the launch had to compute: the speculative, untraced rectangles (the chain of grows that closes an X-drop alignment: on no
+        # path) need the X-drop recurrence only (14 ops per cell), every other cell the full count. `achieved` / `frac` above price EVERY
+        # cell at the full count -- reference-equivalent work; ops_required is the issued-useful view, valu_overhead the instructions the
+        # launch executed per required operation (SQ_INSTS_VALU from the profile record of these sources x 128 int16 lanes-halves)
+        spec_cells = batch.spec_cells() if trace else 0
+        ops_required = (cells_rank - spec_cells) * ops + spec_cells * W.OPS_PER_CELL[("x_drop",)]
         roofline = {"bound": "valu-int16", "achieved": round(tops, 3), "peak": round(VALU_PEAK_INT16_TOPS, 1), "unit": "Tint16-op/s",
                     "frac": round(tops / VALU_PEAK_INT16_TOPS, 5), "traffic": traffic, "profile": profile_ref,
-                    "kernel": "ba::k_multi<8, NUC, trace=%d, xdrop=1>" % int(trace), "kernel_ms": round(k_ms, 3),
+                    "kernel": "ba::%s<class %d, NUC, trace=%d, xdrop=1>" % (info["kernel"], size[1] // 128, int(trace)), "kernel_ms": round(k_ms, 3),
                     "algorithmic_ops_per_cell": ops, "kernel_gcups": round(gcups_kernel, 1),
+                    "speculative_untraced_cells": spec_cells, "ops_required": ops_required,
+                    "frac_of_required": round(ops_required / (k_ms * 1e-3) / 1e12 / VALU_PEAK_INT16_TOPS, 5),
+                    "valu_overhead": (round(profile_ref["sq_insts_valu"] * 128 / ops_required, 3) if profile_ref and profile_ref.get("sq_insts_valu") else None),
                     "hbm": {"achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
                             "algorithmic_bytes_per_cell": BYTES_PER_CELL[trace]},
                     "note": "integer max-plus recurrence: bound by packed-int16 VALU issue (4 cycles per wave64 instruction, "
@@ -354,6 +442,9 @@ def main():
                 c4.mode = ("trace",); c4.name += ", traceback"
                 secondary.append(secondary_line(np, H, W, o, c4, cores))
                 secondary.append(secondary_line(np, H, W, o, W.config5(80000), cores))
+                # the special alignment modes (scan_block.rs:89: LOCAL_START, FREE_QUERY_END_GAPS), on the per-pair kernel
+                secondary.append(secondary_line(np, H, W, o, W.config_local(50000), cores))
+                secondary.append(secondary_line(np, H, W, o, W.config_free_end(50000), cores))
                 # ... and the same configurations at the batch sizes of the reference's own harnesses (BASELINE.json: 10 k pairs,
                 # examples/nanopore_bench.rs:73-95; 7 k protein pairs, examples/uc_bench.rs:79-104; 11 k PSSMs, examples/pssm_bench.rs:94-100):
                 # a few pairs per wave, bound by the longest pair's chain of steps rather than by the machine

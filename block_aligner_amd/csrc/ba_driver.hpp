@@ -1553,7 +1553,9 @@ struct Aligner {
 
             const uint32_t next_size = block_size * 2;
             if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
-                if (TRACE && KIND != KIND_PROFILE && !SPECIAL && !kBig && !chain && !no_spec && !(h_flags & 0x400u)) {
+                // (X-drop only: a global alignment's path starts at its end cell, so every chain of untraced grows would be rolled back at the
+                // end of the matrix at the latest -- the protein set's growers did all their large-block work twice)
+                if (TRACE && XDROP && KIND != KIND_PROFILE && !SPECIAL && !kBig && !chain && !no_spec && !(h_flags & 0x400u)) {
                     // Speculative grows. A grow that does not raise the best score is followed at once by the next grow, and the
                     // sequence that closes an X-drop alignment (128 -> 1024 in config 3: 29 % of its cells) never does: its rectangles
                     // can be on no path. From here on grow steps reserve their trace space but compute neither trace flags nor

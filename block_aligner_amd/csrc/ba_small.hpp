@@ -322,6 +322,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             park<4>(keepv, (more ? 1 : 0) | (excl_more ? 2 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair);
             // (a pair in solo mode keeps the wave's other fifteen slots waiting: its dependent chain goes first among the SIMD's waves)
             __builtin_amdgcn_s_setprio(MQ_SOLO_PRIO);
+            // (a pair run from start to end here -- one of the batch's longest -- walks its path at once, with the whole wave: the batch's longest
+            // walks overlap with the fill. Tried instead: the first waves to run out of work take these walks from a counter -- they all run out
+            // at about the same time, so the walks only lengthen the launch: protein set with traceback 11.1 -> 13.3 ms)
             st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh, to_end);
             __builtin_amdgcn_s_setprio(0);
             live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
@@ -547,8 +550,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 if (TRACE) {
                     // (a slot without a step writes to the wave's sink: the first 64 x 16 words of the arena's sink area, ba_host.cpp; selected by
                     // 32-bit pieces: no 64-bit pointer pair lives across the step)
+#ifdef SM_X_SINK   // (development: every trace store to the sink -- what do the stores' addresses cost?)
+                    const uint32_t t16 = fill_wave * 64u + (uint32_t)lane, tt = 0u;
+#else
                     const uint32_t t16 = run ? tr16 : fill_wave * 64u + (uint32_t)lane, tt = run ? trace_top : 0u;
+#endif
                     tw = bp.trace_arena + ((uint64_t)t16 << 4) + tt + 8 * l;
+#ifndef SM_X_NOREC
                     if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204,284); the first block: four records
                         BlockRec br;
                         br.i = (right ? ri : rj) | 0x80000000u;   // (bit 31: words of 4 cells x 2 columns, see multi_rect)
@@ -556,6 +564,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                         br.trace_base = trace_top | (right ? 0x80000000u : 0u);
                         bp.blocks[bpos] = br;
                     }
+#endif
                 }
                 const bool fin = !XDROP && run && boot == 0 && q_out && r_out;   // the last step of a global alignment
                 const bool fin_any = !XDROP && __any(fin);

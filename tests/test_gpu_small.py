@@ -10,7 +10,7 @@ from block_aligner_amd import scores as S
 from block_aligner_amd import synth
 from block_aligner_amd import workloads as W
 from tests.test_gpu_parity import NUC, compare
-from tests.test_gpu_pipelines import run_and_compare
+from tests.test_gpu_pipelines import mode_bits, run_and_compare
 
 pytestmark = pytest.mark.gpu
 
@@ -84,16 +84,16 @@ def test_small_trace_regions_overflow_and_rerun(hip, oracle, force_small, monkey
 
 @pytest.mark.parametrize("mode", MODES)
 def test_small_dna_at_production_threshold(hip, oracle, mode):
-    """No forcing, the release library: 9 k DNA pairs at 32..256 (threshold 8192)."""
+    """No forcing, the release library: 60 k DNA pairs at 32..256 (the library takes k_small from 49152 pairs, 57344 with traceback)."""
     assert hip.lib().ba_dev_build() == 0
-    pairs = synth.make_pairs(9000, (0, 1500), (0, 150), 40, synth.DNA, seed=812, indels=1, indel_len=(5, 60))
-    assert kernel_of(hip, NUC, (-5, -1), (32, 256), 100, 0, pairs) == "k_small"
+    pairs = synth.make_pairs(60000, (0, 1500), (0, 150), 40, synth.DNA, seed=812, indels=1, indel_len=(5, 60))
+    assert kernel_of(hip, NUC, (-5, -1), (32, 256), 100, mode_bits(hip, mode, True), pairs) == "k_small"
     run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 100, mode, True, ("dna 32..256 k_small", mode))
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_small_protein_at_production_threshold(hip, oracle, mode):
-    """No forcing: 70 k protein pairs (threshold 65536), BLOSUM62, block 32..256."""
-    w = W.config4(70000, seed=92, trace="trace" in mode)
-    assert kernel_of(hip, w.matrix, w.gaps, w.size, 0, 0, w.pairs) == "k_small"
+    """No forcing: 100 k protein pairs (the library takes k_small from 32768 pairs, 98304 with traceback), BLOSUM62, block 32..256."""
+    w = W.config4(100000, seed=92, trace="trace" in mode)
+    assert kernel_of(hip, w.matrix, w.gaps, w.size, 60 if "x_drop" in mode else 0, mode_bits(hip, mode, False), w.pairs) == "k_small"
     run_and_compare(hip, oracle, w.pairs, w.matrix, w.gaps, w.size, 60 if "x_drop" in mode else 0, mode, False, ("protein 32..256 k_small", mode))
