@@ -643,7 +643,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
-        if (b->multi) spw = 10;   // four pairs being filled + pending walks
+        if (b->multi) spw = 8;   // four pairs being filled + pending walks (round 4: 8 instead of 10 -- 105 instead of 131 GB at config 3 for -0.7 %, same box: 179.8 against 178.6 ms)
         if (const char* env = dev_env("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         if (b->multi && spw < 6) return fail("device memory: the multi-pair kernel needs six trace slots per wave");   // (batch_build falls back to the per-pair kernel)

@@ -541,26 +541,29 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 stop = stop || (!q_out && !r_out && 2 * MQ_B <= max_size && new_y > MQ_B / STEP - 1);        // grow
                 const bool commit = run && !stop;
                 leave = leave || (run && stop);   // rolled back: the pair's state is what was staged before this step
-                if (commit) {
-                    if (improve) {
-                        if (keep_pre) sel ^= 1u;   // the state staged before this step is the checkpoint now (and yields the location of the maximum)
-                        best_max = new_off_max;
-                    }
-                    off = off_n; off_max = new_off_max; y_drop = new_y; prev_dir = dir; D_corner = o.corner_new;
-                    nsteps++;
-                    if (TRACE) { trace_top += STEP * MQ_B / 8; nblocks++; }
-                    if (XDROP) x_iter = (off_max < best_max - x_drop) ? x_iter + 1 : 0;
+                {
+                    // Straight-line selects, no branch (round 4): as nested conditionals the compiler copied the sixteen border registers three
+                    // times per step (before the commit branch, inside it, and for the exchange: ~64 moves of 1156 instructions).
+                    const bool imp = commit && improve;
+                    if (keep_pre) sel ^= imp ? 1u : 0u;   // the state staged before this step is the checkpoint now (and yields the location of the maximum)
+                    best_max = imp ? new_off_max : best_max;
+                    off = commit ? off_n : off; off_max = commit ? new_off_max : off_max; y_drop = commit ? new_y : y_drop;
+                    prev_dir = commit ? dir : prev_dir; D_corner = commit ? o.corner_new : D_corner;
+                    nsteps += commit ? 1u : 0u;
+                    if (TRACE) { trace_top += commit ? (uint32_t)(STEP * MQ_B / 8) : 0u; nblocks += commit ? 1u : 0u; }
+                    if (XDROP) x_iter = commit ? ((new_off_max < best_max - x_drop) ? x_iter + 1 : 0) : x_iter;
                     const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
-                    si += go_down ? (uint32_t)STEP : 0u; sj += go_down ? 0u : (uint32_t)STEP;
+                    si += (commit && go_down) ? (uint32_t)STEP : 0u; sj += (commit && !go_down) ? (uint32_t)STEP : 0u;
                     const int ndir = go_down ? DIR_DOWN : DIR_RIGHT;
-                    if (ndir != dir) {   // the borders change roles with the direction
+                    // the borders change roles with the direction (whatever a slot that does not commit holds is not read again: its state is
+                    // what was staged before the step)
+                    const bool swap = ndir != dir;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int td = A_d[k], tc = A_c[k];
-                            A_d[k] = P_d[k]; A_c[k] = P_r[k]; P_d[k] = td; P_r[k] = tc;
-                        }
+                    for (int k = 0; k < 4; k++) {
+                        const int td = A_d[k], tc = A_c[k];
+                        A_d[k] = swap ? P_d[k] : td; A_c[k] = swap ? P_r[k] : tc; P_d[k] = swap ? td : P_d[k]; P_r[k] = swap ? tc : P_r[k];
                     }
-                    dir = ndir;
+                    dir = commit ? ndir : dir;
                 }
 #ifdef BA_TIMING
                 n_quad++;
