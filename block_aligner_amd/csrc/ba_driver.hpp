@@ -1153,13 +1153,13 @@ struct Aligner {
     __device__ __forceinline__ static int ckpt_load(const short* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }
     __device__ __forceinline__ static short ckpt_load16(const short* p) { return __hip_atomic_load(p, BA_RLX_AGENT); }   // (past the L1: the wave reads back its own stores)
 
-    // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done). The wait only
-    // gives up when the traceback side as a whole has stopped making progress: no task claimed for ~2 s, scaled by the
-    // batch's longest pair (a walk over a multi-Mbp pair alone takes seconds).
+    // Wait until this wave's next trace slot has been walked (its previous tenant's traceback is done). The wait never gives up
+    // (round 4: no pair comes back failed for a slow traceback side): whenever nobody has claimed a hand-off for a few milliseconds the
+    // wave walks the ring's head entry itself and looks again -- the entries ahead of its own slots are either unclaimed (it walks
+    // them) or claimed by a resident wave that is walking them.
     // tb_lds: this wave's LDS region (free between pairs): see traceback_help_one.
-    __device__ __forceinline__ bool acquire_slot(uint32_t slot, const BatchParams& bp, unsigned char* tb_lds) {
+    __device__ __forceinline__ void acquire_slot(uint32_t slot, const BatchParams& bp, unsigned char* tb_lds) {
         uint32_t seen = 0, idle = 0;
-        const uint32_t limit = (1u << 20) * (1u + (uint32_t)(coldp()->blocks_stride >> 15));
         for (;;) {
             uint32_t f = 0, head = 0;
             if (is_lane(0)) {
@@ -1168,13 +1168,12 @@ struct Aligner {
             }
             if (uni((int)f)) {
                 if (is_lane(0)) __hip_atomic_store(coldp()->slot_free + slot, 0u, BA_RLX_AGENT);
-                return true;
+                return;
             }
             head = (uint32_t)uni((int)head);
             if (head != seen) { seen = head; idle = 0; }
-            else if (++idle > limit) return false;
             // nobody has taken a traceback for a few milliseconds: walk one here (a launch whose traceback waves are not resident)
-            else if ((idle & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, tb_lds)) idle = 0;
+            else if ((++idle & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, tb_lds)) idle = 0;
             __builtin_amdgcn_s_sleep(64);
         }
     }
@@ -1871,19 +1870,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
             if (TRACE && bp.trace_off) slot = pair;   // pair-slot batches: the pair's own region (never shared, never waited for)
             Aligner<PMAX, KIND, TRACE, XDROP, SPECIAL> al(bp, L, fc);
             BA_TSTAMP(tw0);
-            const bool got_slot = !batch_traceback || al.acquire_slot(slot, bp, (unsigned char*)base);
+            if (batch_traceback) al.acquire_slot(slot, bp, (unsigned char*)base);
             BA_TSTAMP(tw1);
 #ifdef BA_TIMING
             if (bp.prof && is_lane(0)) atomicAdd(bp.prof + 17, tw1 - tw0);
 #endif
-            if (!got_slot) {
-                // the traceback waves are not making progress: report instead of hanging. The pair still has to
-                // produce its queue entry so the consumers' task count stays exact.
-                al.status = ST_SLOT_TIMEOUT;
-                if (is_lane(0)) { bp.score[pair] = 0; bp.query_idx[pair] = 0; bp.reference_idx[pair] = 0; }
-                al.hand_off(slot, pair, 0, 0, true);
-                continue;
-            }
             al.trace = bp.trace_arena + (uint64_t)slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)slot * bp.blocks_stride;
             if (TRACE && bp.trace_off) { al.trace = bp.trace_arena + bp.trace_off[pair]; al.blocks = bp.blocks + bp.blocks_off[pair]; }

@@ -197,8 +197,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     const int gx = bp.gap_extend;
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
-#ifdef BA_TIMING
+#if defined(BA_TIMING) || defined(BA_DEV)
     if (bp.prof && blockIdx.x == 0 && wave == 1 && is_lane(0)) atomicMax(bp.prof + 43, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+#ifdef BA_TIMING
     unsigned long long t_solo = 0, t_quad = 0, t_wait = 0, n_solo = 0, n_quad = 0;
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
@@ -273,9 +275,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 s_slot = fill_wave * bp.slots_per_wave;
                 if (batch_traceback) {
                     BA_TSTAMP(tw_a);
-                    uint32_t seen = 0, idle_n = 0; bool got = false;
-                    const uint32_t limit = (1u << 20) * (1u + (uint32_t)(bp.blocks_stride >> 15));
-                    for (;;) {
+                    uint32_t seen = 0, idle_n = 0;
+                    for (;;) {   // (never gives up: see Aligner::acquire_slot)
                         uint32_t f = 0, head = 0;
                         if ((uint32_t)lane < bp.slots_per_wave) f = __hip_atomic_load(bp.slot_free + s_slot + lane, BA_RLX_AGENT);
                         if (is_lane(0)) head = __hip_atomic_load(bp.tb_ctrl + 32, BA_RLX_AGENT);
@@ -283,25 +284,18 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                         if (fm) {
                             s_slot += (uint32_t)__builtin_ctzll(fm);
                             if (is_lane(0)) __hip_atomic_store(bp.slot_free + s_slot, 0u, BA_RLX_AGENT);
-                            got = true; break;
+                            break;
                         }
                         head = (uint32_t)uni((int)head);
                         if (head != seen) { seen = head; idle_n = 0; }
-                        else if (++idle_n > limit) break;
                         // nobody has taken a traceback for a few milliseconds: walk one here (see traceback_help_one; the wave's LDS region
                         // is free: the slots' buffers are in the arena while the wave is in solo mode)
-                        else if ((idle_n & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base)) idle_n = 0;
+                        else if ((++idle_n & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base)) idle_n = 0;
                         __builtin_amdgcn_s_sleep(64);
                     }
 #ifdef BA_TIMING
                     t_wait += __builtin_amdgcn_s_memtime() - tw_a;
 #endif
-                    if (!got) {   // the traceback side has stopped making progress: report instead of hanging
-                        al.status = ST_SLOT_TIMEOUT;
-                        if (is_lane(0)) { bp.score[s_pair] = 0; bp.query_idx[s_pair] = 0; bp.reference_idx[s_pair] = 0; }
-                        al.hand_off(s_slot, s_pair, 0, 0, true);
-                        continue;
-                    }
                 } else if (TRACE) {
                     // (no hand-off: the pair's traceback is walked by this wave before the slot is reused; the four slots of the wave
                     // still need a trace slot each while their pairs are live)
@@ -601,6 +595,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     if (bp.prof && is_lane(0)) {
         atomicMax(bp.prof + 40, (unsigned long long)__builtin_amdgcn_s_memrealtime());
         atomicAdd(bp.prof + 50, t_solo); atomicAdd(bp.prof + 51, t_quad); atomicAdd(bp.prof + 52, t_wait); atomicAdd(bp.prof + 53, n_solo); atomicAdd(bp.prof + 54, n_quad); atomicAdd(bp.prof + 55, 1ull);
+    }
+#endif
+#ifdef BA_DEV
+    if (bp.prof && is_lane(0)) {   // development (tools/dev/ragged_end.py): when did this fill wave run out of pairs? 4 ms buckets after the launch's start
+        const unsigned long long t0 = __hip_atomic_load(bp.prof + 43, BA_RLX_AGENT), t = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long k = t0 && t > t0 ? (t - t0) / 400000ull : 0ull;
+        atomicAdd(bp.prof + 64 + (k < 63ull ? k : 63ull), 1ull);
     }
 #endif
     // a fill wave joins the traceback side with one lane once the batch has no pairs left for it (see k_align)

@@ -276,7 +276,8 @@ void ba_multibatch_destroy(BaMultiBatch* batch);
 int ba_shard_slices(const uint32_t* q_len, const uint32_t* r_len, uintptr_t n_pairs, int parts, uint64_t* bounds);
 
 enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16,
-       BA_ST_SLOT_TIMEOUT = 32, BA_ST_MODE = 64 /* FREE_QUERY_END_GAPS reached a down step: the reference panics there */ };
+       BA_ST_SLOT_TIMEOUT = 32 /* never reported since round 4 (a fill wave that waits for a trace slot walks pending tracebacks itself); kept for ABI stability */,
+       BA_ST_MODE = 64 /* FREE_QUERY_END_GAPS reached a down step: the reference panics there */ };
 
 /* One-shot convenience over create/run/results/cigars/destroy. */
 int block_batch_align(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,

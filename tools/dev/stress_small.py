@@ -1,0 +1,40 @@
+"""k_small at production batch sizes over random parameters, every pair against the oracle (GPU box):
+python tools/dev/stress_small.py [seed0] [count]   (BA_FORCE_SMALL=1 is set here: any batch that starts at 32 cells takes k_small)"""
+import os, sys
+os.environ["BA_FORCE_SMALL"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from block_aligner_amd import hip as H, scores as S, synth
+from oracle.oracle_py import Oracle
+from tests.test_gpu_pipelines import run_and_compare
+o = Oracle("avx2")
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+bad = 0
+for seed in range(seed0, seed0 + count):
+    rng = np.random.default_rng(seed)
+    hi = 32 << int(rng.integers(0, 6))
+    lo_len, hi_len = int(rng.integers(0, 300)), int(rng.integers(300, 1800))
+    edits = (int(rng.integers(0, 30)), int(rng.integers(40, 250)))
+    tails = int(rng.integers(0, 200))
+    x_drop = int(rng.integers(15, 150))
+    mode = [(), ("x_drop",), ("trace",), ("trace", "x_drop")][int(rng.integers(0, 4))]
+    kind = int(rng.integers(0, 3))
+    ext = -int(rng.integers(1, 4)); opn = ext - int(rng.integers(2, 12))
+    if kind == 0:
+        alpha, matrix = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5)))
+    elif kind == 1:
+        alpha, matrix = synth.AMINO, S.BLOSUM62
+    else:
+        alpha, matrix = np.frombuffer(b"abcdefgh", np.uint8), S.BYTES1
+        mode = tuple(m for m in mode if m != "x_drop"); opn, ext = -2, -1
+    n = int(rng.integers(3000, 40000))
+    pairs = synth.make_pairs(n, (lo_len, hi_len), edits, tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 150))
+    what = (seed, n, kind, (32, hi), (opn, ext), x_drop, mode)
+    try:
+        run_and_compare(H, o, pairs, matrix, (opn, ext), (32, hi), x_drop if "x_drop" in mode else 0, mode, kind == 0, what)
+        print("ok", what, flush=True)
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print("FAIL", what, repr(e)[:300], flush=True)
+print("done, failures:", bad)
