@@ -253,7 +253,7 @@ struct BaBatch {
     uint32_t retried = 0;       // pairs the last run had to re-run with full-size slots
     uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace_words, trace, blocks, ckpt, big, counter,
-           tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev;
+           tb_queue, tb_ctrl, slot_free, slot_info, prof, params_dev, donate;
     std::vector<uint32_t> h_order;   // device order -> caller's pair index (empty: identical); see Packed::order
     uint32_t tb_stride = 0, n_fill_waves = 0, slots_per_wave = 1, tb_qsize = 1, tb_reserve = 0;
     std::vector<uint64_t> h_q_off, h_r_off;   // padded offsets (host copy, for the per-handle traceback)
@@ -286,7 +286,7 @@ struct BaBatch {
         bp.q_off = q_off.as<uint64_t>(); bp.q_len = q_len.as<uint32_t>();
         bp.r_off = r_off.as<uint64_t>(); bp.r_len = r_len.as<uint32_t>();
         bp.n = n; bp.gap_open = gap_open; bp.gap_extend = gap_extend;
-        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (dev_env("BA_NO_FAST") ? 0x100u : 0u) | (dev_env("BA_SKIP_WALK") ? 0x200u : 0u) | ((handle_mode || dev_env("BA_NO_SPEC")) ? 0x400u : 0u) | (dev_env("BA_NO_TB_WAVES") ? 0x800u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
+        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (dev_env("BA_NO_FAST") ? 0x100u : 0u) | (dev_env("BA_SKIP_WALK") ? 0x200u : 0u) | ((handle_mode || dev_env("BA_NO_SPEC")) ? 0x400u : 0u) | (dev_env("BA_NO_TB_WAVES") ? 0x800u : 0u) | (dev_env("BA_NO_REFILL") ? 0x1000u : 0u) | (dev_env("BA_NO_STEAL") ? 0x2000u : 0u) | (dev_env("BA_X4") ? 0x4000u : 0u) | (dev_env("BA_X8") ? 0x8000u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
         bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !dev_env("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch
@@ -304,6 +304,8 @@ struct BaBatch {
         bp.work_counter = counter.as<uint32_t>();
         bp.work_chunk = work_chunk;
         bp.mq_drain = mq_drain;
+        bp.mq_waves = grid * ba::WAVES_PER_WG;
+        bp.mq_donate = (multi && (mode & BA_TRACE) && donate.p && !dev_env("BA_NO_DONATE")) ? donate.as<uint32_t>() : nullptr;   // (the score-only kernels are compiled without the end-of-batch code)
         bp.sm_excl_n = small ? sm_excl_n : 0;
         bp.prof = prof.as<unsigned long long>();
         return bp;
@@ -659,7 +661,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
         if (const char* env = dev_env("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
     }
-    b->mq_drain = b->multi ? b->n_fill_waves : 0;
+    // (round 4: a quarter of the fill waves instead of all of them -- since waves that run out of pairs take over other waves' slots at the
+    // end of the batch, fewer pairs need to be kept out of the slots: config 3 178.9 -> 176.7 ms, 25 k pairs 60.5 -> 58.0 ms; 0: the same)
+    b->mq_drain = b->multi ? ((dev_env("BA_NO_DONATE") || !trace) ? b->n_fill_waves : b->n_fill_waves / 4) : 0;
     if (const char* env = dev_env("BA_MQ_DRAIN")) b->mq_drain = (uint32_t)std::max(0, atoi(env));
     if (b->multi && b->slots_per_wave < 4) b->slots_per_wave = 4;   // (without the hand-off ring: one trace slot per slot of the wave)
     b->slots = b->n_fill_waves * b->slots_per_wave;
@@ -683,6 +687,7 @@ static int batch_alloc_scratch(BaBatch* b) {
                                               : (b->multi ? (size_t)b->grid * ba::WAVES_PER_WG * ba::MQ_WAVE_BYTES : (b->small ? (size_t)b->grid * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES : 0)));
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
+    if (b->multi) BA_ALLOC(donate, ((size_t)b->grid * ba::WAVES_PER_WG + 64) * 4);   // (+ two counters in their own cache lines)
 #undef BA_ALLOC
     return 0;
 }
@@ -951,6 +956,7 @@ static int batch_launch(BaBatch* b) {
         HIP_TRY(hipMemsetAsync(b->prof.p, 0, 2048, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
         HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
+        if (b->multi && b->donate.p) HIP_TRY(hipMemsetAsync(b->donate.p, 0, ((size_t)b->grid * ba::WAVES_PER_WG + 64) * 4, b->stream));
     }
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));

@@ -41,7 +41,8 @@ __device__ __forceinline__ int splat_lo(int x) { const s16x2 t = as_s(x); return
 struct MultiConsts {
     int G[4];             // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
     int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g, except row lane 0 which holds -32768 (no lane above: a candidate that never wins)
-    int vtop[4];          // per cell: max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column)
+    int vtop3;            // per cell: max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column) -- for the lane's
+                          // first six cells that is G[k] in every lane (artefact ((cell & 7) + 1) g >= carry (cell + 1) g), only register 3 differs per lane
 };
 
 struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
@@ -101,7 +102,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
         uint32_t sC[4], sR[4], sCo[4], sRo[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), mc.vtop[k]);
+            r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), k < 3 ? mc.G[k] : mc.vtop3);
             dn[k] = vmax(d11[k], r[k]);
             if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect); packed below, two registers at a time
                 sC[k] = (uint32_t)subs(cn[k], dn[k]); sR[k] = (uint32_t)subs(r[k], dn[k]); sCo[k] = (uint32_t)subs(copen[k], cn[k]); sRo[k] = (uint32_t)subs(x[k], r[k]);
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     const int gx = bp.gap_extend;
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
-#if defined(BA_TIMING) || defined(BA_DEV)
+#if defined(BA_TIMING) || defined(BA_ENDHIST)
     if (bp.prof && blockIdx.x == 0 && wave == 1 && is_lane(0)) atomicMax(bp.prof + 43, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
 #ifdef BA_TIMING
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         if (!(bp.flags & 0x800u))   // (development switch: as if the traceback waves were never resident)
         traceback_consumer<(int)TB_LANE_BYTES_L2, 8, 3>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 64u, true, 1);   // (8 cells per call: the window of a slot's rectangle is 16 rows x 8 columns; 4: -0.8 %, 12: -2 %. Three records fetched ahead: +0.8 % over two)   // (records in this wave's own region)
-#ifdef BA_TIMING
+#if defined(BA_TIMING) || defined(BA_ENDHIST)
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 42, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
         return;
@@ -224,6 +225,46 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
     uint32_t w_next = 0, w_end = 0;
     bool more = true, drain = false;
+    // The end of the batch (round 4): a wave whose slots are filled for the last time (the pool is closed for them) takes its live slots solo,
+    // one after the other -- and offers the ones it is not working on to waves that have nothing left (mq_donate[its id], bit s; a slot's
+    // state in the arena is a complete resumable record). `don` (bits 8 / 9 of the wave's own word): bit 0 this wave has been counted in mq_donate[waves] (it will offer nothing
+    // more), bit 1 its word holds offers; donor_id: the wave whose slot `solo` is (a slot taken over), else this wave.
+    // (neither is kept in a register across the loop of steps: the id is derived again, the bits live in the wave's own word, bits 8 / 9)
+#define don_final (bp.mq_donate + gridDim.x * WAVES_PER_WG)   /* fill waves that will offer nothing more */
+#define don_offers (don_final + 32)                            /* (its own cache line) offers outstanding */
+    // a slot's memory in the arena: `id` = blockIdx * 8 + wave of the wave that owns it
+    auto slot_mem_of = [&](uint32_t id, uint32_t s_i) {
+        const uint32_t db = id / WAVES_PER_WG;
+        const uint32_t dcb = batch_traceback ? (db + stride - 1) / stride + (db % stride == 0 ? 1u : 0u) : 0u;
+        return (char*)bp.big + (uint64_t)(id - dcb) * MQ_WAVE_BYTES + s_i * MQ_SLOT_BYTES;
+    };
+    // one pass over the waves' words (mq_donate[waves + 32]: offers outstanding, a hint that saves the pass): take one offered slot
+    auto claim_offer = [&](uint32_t my_id, uint32_t& id_out, int& s_out) {
+        uint32_t avail = 0;
+        if (is_lane(0)) avail = __hip_atomic_load(don_offers, BA_RLX_AGENT);
+        if ((int)uni((int)avail) <= 0) return false;
+        const uint32_t n_ids = gridDim.x * WAVES_PER_WG;
+        for (uint32_t k0 = 0; k0 < n_ids; k0 += 64) {
+            const uint32_t idx = ((my_id & ~63u) + k0 + (uint32_t)lane) % n_ids;   // (every word at least once, starting near this wave's own; the number of waves need not be a multiple of 64)
+            const uint32_t v = __hip_atomic_load(bp.mq_donate + idx, BA_RLX_AGENT) & 15u;
+            unsigned long long m = __ballot(v != 0u);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v, src), id = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
+                const int s_i = __builtin_ctz(vv);
+                uint32_t old = 0;
+                if (is_lane(0)) {
+                    old = __hip_atomic_fetch_and(bp.mq_donate + id, ~(1u << s_i), BA_RLX_AGENT);
+                    if ((old >> s_i) & 1u) __hip_atomic_fetch_sub(don_offers, 1u, BA_RLX_AGENT);
+                }
+                old = (uint32_t)uni((int)old);
+                if ((old >> s_i) & 1u) { id_out = id; s_out = s_i; return true; }
+                m &= m - 1;   // (taken meanwhile; the word's other offers are seen by the next pass)
+            }
+        }
+        return false;
+    };
+    auto my_id_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); return b * WAVES_PER_WG + w; };
 
     for (;;) {
         // ================= solo mode: one pair at a time on all 64 lanes, the slots' state in memory. Whose turn? a slot whose step
@@ -231,7 +272,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
         // step would idle lanes -- a live slot, to its end.
         for (;;) {
             int solo = -1; bool fresh = false, to_end = false;
-            uint32_t new_pair = 0;
+            uint32_t new_pair = 0, donor_id = ~0u;
             if (pend_m) solo = __builtin_ctz(pend_m);
             else if (more && (drain ? live_m == 0u : live_m != 15u)) {
                 if (w_next == w_end) {
@@ -244,7 +285,69 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 new_pair = w_next++; solo = __builtin_ctz(~live_m & 15u); fresh = true;
                 to_end = drain;                                      // (the batch is running out: this pair is not for a slot)
                 if (new_pair + bp.mq_drain >= bp.n) drain = true;    // from the next pair on
-            } else if (live_m && live_m != 15u) { solo = __builtin_ctz(live_m); to_end = true; }
+            } else if (live_m && live_m != 15u) {
+                solo = __builtin_ctz(live_m); to_end = true;
+                if (TRACE && bp.mq_donate) {   // (the score-only kernels are compiled without the end-of-batch code: see DESIGN.md)
+                    const uint32_t my_id = my_id_of();
+                    uint32_t don = 0;
+                    if (is_lane(0)) don = __hip_atomic_load(bp.mq_donate + my_id, BA_RLX_AGENT);
+                    don = (uint32_t)uni((int)don) >> 8;
+                    if (!(don & 1u)) {   // (here: the batch has run out, or this wave takes the pairs that are left one at a time -- either way the batch fills none of its slots again)
+                        // an empty slot is first filled with a slot that another wave offers: the wave stays at four pairs per step
+                        uint32_t id = 0; int s_o = 0;
+                        if (!(bp.flags & 0x1000u) && claim_offer(my_id, id, s_o)) {   // (0x1000 / 0x2000: development switches)
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            const int e = __builtin_ctz(~live_m & 15u);
+                            const char* src = slot_mem_of(id, (uint32_t)s_o);
+                            char* dst = wave_mem + (uint32_t)e * MQ_SLOT_BYTES;
+#pragma unroll
+                            for (int k = 0; k < (int)(MQ_SLOT_BYTES / 256u); k++) *(int*)(dst + 256 * k + 4 * lane) = mq_load(src + 256 * k + 4 * lane);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the copy is in the L2 before this wave reads it back)
+                            live_m |= 1u << e;
+                            continue;
+                        }
+                        // nothing on offer: this wave's own slots are, except the one it works on now (solo, to its end)
+                        const uint32_t others = live_m & ~(1u << solo);
+                        if (others) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the slots' records and trace words, before the offer
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                        if (is_lane(0)) {
+                            __hip_atomic_store(bp.mq_donate + my_id, others | 0x100u | (others ? 0x200u : 0u), BA_RLX_AGENT);
+                            if (others) __hip_atomic_fetch_add(don_offers, (uint32_t)__builtin_popcount(others), BA_RLX_AGENT);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the offer before the count: a wave that sees every wave counted has seen every offer)
+                        if (is_lane(0)) __hip_atomic_fetch_add(don_final, 1u, BA_RLX_AGENT);
+                    } else if (don & 2u) {   // its own offer back, unless somebody has taken it
+                        uint32_t old = 0;
+                        if (is_lane(0)) {
+                            old = __hip_atomic_fetch_and(bp.mq_donate + my_id, ~(1u << solo), BA_RLX_AGENT);
+                            if ((old >> solo) & 1u) __hip_atomic_fetch_sub(don_offers, 1u, BA_RLX_AGENT);
+                        }
+                        old = (uint32_t)uni((int)old);
+                        if (!((old >> solo) & 1u)) { live_m &= ~(1u << solo); continue; }
+                    }
+                }
+            } else if (TRACE && bp.mq_donate && !live_m && !more) {
+                // nothing left here: take over a slot that another wave offers and run it solo to its end; leave when no wave can offer any more
+                const uint32_t my_id = my_id_of();
+                if (is_lane(0) && !(__hip_atomic_fetch_or(bp.mq_donate + my_id, 0x100u, BA_RLX_AGENT) & 0x100u)) __hip_atomic_fetch_add(don_final, 1u, BA_RLX_AGENT);
+                const uint32_t n_fill = gridDim.x * WAVES_PER_WG - (batch_traceback ? (gridDim.x + stride - 1) / stride : 0u);
+                bool got = false;
+                uint32_t nap = 1;
+                for (;;) {
+                    uint32_t nf = 0;
+                    if (is_lane(0)) nf = __hip_atomic_load(don_final, BA_RLX_AGENT);
+                    nf = (uint32_t)uni((int)nf);
+                    got = !(bp.flags & 0x2000u) && claim_offer(my_id, donor_id, solo);
+                    if (got || nf >= n_fill) break;
+                    for (uint32_t z = 0; z < nap; z++) __builtin_amdgcn_s_sleep(127);   // (thousands of waves poll two words: 3 .. 50 us apart)
+                    nap = nap < 16u ? nap * 2u : 16u;
+                }
+                if (!got) { donor_id = ~0u; break; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                to_end = true;
+            }
             else break;
 
             BA_TSTAMP(ts_a);
@@ -267,7 +370,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             Aligner<PMAX, KIND, TRACE, XDROP, false, true> al(bp, L, fc);
             PairState st{};
             uint32_t s_pair, s_slot;
-            char* const smem_s = wave_mem + (uint32_t)solo * MQ_SLOT_BYTES;
+            char* smem_s = wave_mem + (uint32_t)solo * MQ_SLOT_BYTES;
+            if (donor_id != ~0u) smem_s = slot_mem_of(donor_id, (uint32_t)solo);   // (a slot taken over: the other wave's region of the arena)
             char* const rec = smem_s + 2 * MQ_BUF_BYTES;
             if (fresh) {
                 s_pair = new_pair;
@@ -409,16 +513,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             MultiConsts mc;  // eight cells per lane
             mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : -32768;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+            for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+            {
                 int t[2];
                 for (int h = 0; h < 2; h++) {
-                    const int cell = 8 * l + 2 * k + h, k16 = cell & 15;
+                    const int cell = 8 * l + 6 + h, k16 = cell & 15;
                     const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
                     const int art = mult ? max(-32768, mult * gx) : -32768;
                     t[h] = max(art, max(-32768, (cell + 1) * gx));
                 }
-                mc.vtop[k] = pk(t[0], t[1]);
+                mc.vtop3 = pk(t[0], t[1]);
             }
             const uint64_t tcap64 = bp.trace_stride, bcap64 = bp.blocks_stride;
             const uint32_t tcap = (uint32_t)(tcap64 < 0x7fffffffull ? tcap64 : 0x7fffffffull), bcap = (uint32_t)(bcap64 < 0x7fffffffull ? bcap64 : 0x7fffffffull);
@@ -427,13 +531,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             const char* rec = slot_mem + 2 * MQ_BUF_BYTES;
 #define BA_R(k) (live ? mq_load(rec + 4 * (k)) : 0)
             const uint32_t pair = (uint32_t)BA_R(MR_PAIR), tslot = (uint32_t)BA_R(MR_TSLOT);
-            uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ), y_drop = (uint32_t)BA_R(MR_Y_DROP), nsteps = (uint32_t)BA_R(MR_NSTEPS);
+            uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ), y_drop = (uint32_t)BA_R(MR_Y_DROP);
             uint32_t trace_top = (uint32_t)BA_R(MR_TRACE_TOP), nblocks = (uint32_t)BA_R(MR_NBLOCKS), sel = (uint32_t)BA_R(MR_SEL);
             int dir = BA_R(MR_DIR), prev_dir = BA_R(MR_PREV_DIR), off = BA_R(MR_OFF), off_max = BA_R(MR_OFF_MAX), best_max = BA_R(MR_BEST_MAX);
             int x_iter = BA_R(MR_X_ITER), D_corner = BA_R(MR_D_CORNER);
 #undef BA_R
-            const uint32_t qlen = live ? bp.q_len[pair] : 0u, rlen = live ? bp.r_len[pair] : 0u;
-            const uint8_t* qp = bp.pool + (live ? bp.q_off[pair] : 0ull); const uint8_t* rp = bp.pool + (live ? bp.r_off[pair] : 0ull);
             int A_d[4], A_c[4], P_d[4], P_r[4];   // borders: (A) along the vector axis of the step at `dir`, (P) orthogonal
             {
                 const char* b = slot_mem + (sel ^ 1u) * MQ_BUF_BYTES + l * 16;
@@ -446,8 +548,18 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             // While the slots run, the two buffers of every slot live in this wave's LDS region (the solo borders' space): the checkpoint
             // (buffer `sel`) comes from the arena now and goes back after the loop; the other one is rewritten before every step.
             char* const lbuf = base + (uint32_t)g * 2048u;                       // this slot's buffers: + which * 1024
-            int* const lsc = (int*)(base + MQ_LDS_SCALARS) + (uint32_t)g * 18u;   // their scalars: + which * 9
+            int* const lsc = (int*)(base + MQ_LDS_SCALARS) + (uint32_t)g * MQ_LSC_INTS;   // their scalars: + which * 9; + 20: eight constants of the slot's pair
             lds_sync();
+            // (score-only kernels have the registers: there the values stay where they were -- 119.8 against 125.5 ms at config 3 without traceback)
+            const unsigned long long qa_r = TRACE ? 0ull : (unsigned long long)(bp.pool + (live ? bp.q_off[pair] : 0ull)), ra_r = TRACE ? 0ull : (unsigned long long)(bp.pool + (live ? bp.r_off[pair] : 0ull));
+            const uint32_t qlen_r = (!TRACE && live) ? bp.q_len[pair] : 0u, rlen_r = (!TRACE && live) ? bp.r_len[pair] : 0u;
+            if (TRACE && l == 0) {
+                // what a step needs of its pair only at its start -- the two sequence images and their lengths, the trace slot -- is read from
+                // LDS in every step instead of living in seven registers through the columns
+                const unsigned long long qa = (unsigned long long)(bp.pool + (live ? bp.q_off[pair] : 0ull)), ra = (unsigned long long)(bp.pool + (live ? bp.r_off[pair] : 0ull));
+                *(int4*)(lsc + 20) = int4{(int)(uint32_t)qa, (int)(uint32_t)(qa >> 32), (int)(uint32_t)ra, (int)(uint32_t)(ra >> 32)};
+                *(int4*)(lsc + 24) = int4{live ? (int)bp.q_len[pair] : 0, live ? (int)bp.r_len[pair] : 0, (int)tslot, 0};
+            }
             if (live) {
                 const char* cb = slot_mem + sel * MQ_BUF_BYTES;
                 char* d = lbuf + sel * 1024u + l * 16;
@@ -475,6 +587,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             do {
                 // ---- the step every live slot is about to take (scan_block.rs:147-246)
                 const bool right = dir == DIR_RIGHT;
+                int4 cA = {0, 0, 0, 0}, cB = {0, 0, 0, 0};
+                if (TRACE) { cA = *(const int4*)(lsc + 20); cB = *(const int4*)(lsc + 24); }
+                const uint8_t* const qp = TRACE ? (const uint8_t*)((unsigned long long)(uint32_t)cA.x | ((unsigned long long)(uint32_t)cA.y << 32)) : (const uint8_t*)qa_r;
+                const uint8_t* const rp = TRACE ? (const uint8_t*)((unsigned long long)(uint32_t)cA.z | ((unsigned long long)(uint32_t)cA.w << 32)) : (const uint8_t*)ra_r;
+                const uint32_t qlen = TRACE ? (uint32_t)cB.x : qlen_r, rlen = TRACE ? (uint32_t)cB.y : rlen_r;
                 const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (MQ_B - STEP);
                 const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
                 const bool q_out = si + MQ_B > qlen, r_out = sj + MQ_B > rlen;
@@ -490,13 +607,22 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
 #ifndef MQ_X_NOSTAGE
                 if (live) stage(sel ^ 1u, si, sj, off_n, trace_top, nblocks, dir, off_add, corner);
 #endif
+                // (the lane's number inside its row: from the hardware's lane count in every step, not from a kernel-wide value -- the allocator
+                // kept that one, widened to 64 bits, in scratch memory and reloaded it before the prefetch and before the trace stores, each
+                // time behind every outstanding memory operation)
+                // (should the allocator keep the column code's per-lane constants in scratch memory after all: reloaded here, before the prefetch
+                // is issued, a reload waits for nothing but the previous step's stores)
+                asm volatile("" : "+v"(mc.laneKG), "+v"(mc.lanem1KG), "+v"(mc.vtop3));
+                uint32_t l8;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l8));
+                l8 = (l8 & 15u) * 8u;
                 uint2 vb, cbv;
                 {
                     const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
                     vb = right ? pf_qv : pf_rv; cbv = right ? pf_rc : pf_qc;
                     if (__any(run && !pf_ok)) {   // a slot that has just taken its pair (back)
                         if (run && !pf_ok) {
-                            const uint32_t* vp = (const uint32_t*)(Vp + ri + 8 * l);   // (images are 4-byte aligned, positions multiples of 8)
+                            const uint32_t* vp = (const uint32_t*)(Vp + (ri + l8));   // (images are 4-byte aligned, positions multiples of 8)
                             vb.x = vp[0]; vb.y = vp[1];
                             const uint32_t* cp = (const uint32_t*)(Cp + rj);
                             cbv.x = cp[0]; cbv.y = cp[1];
@@ -504,7 +630,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     }
                     asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
                     if (run) {                                    // for the step after this one, whichever way it goes
-                        const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + sj + 8 * l);
+                        const uint32_t* a = (const uint32_t*)(qp + (si + l8)); const uint32_t* b = (const uint32_t*)(rp + (sj + l8));
                         const uint32_t* cq = (const uint32_t*)(qp + si + MQ_B); const uint32_t* cr = (const uint32_t*)(rp + sj + MQ_B);
                         pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
                         pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
@@ -513,13 +639,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 }
                 uint32_t* tw = nullptr;
                 if (TRACE) {
-                    tw = bp.trace_arena + (uint64_t)tslot * bp.trace_stride + trace_top + 8 * l;
+                    // (the slot's base address is derived again in every step -- two multiply-adds -- instead of living in a register pair across
+                    // the loop: with the pair the allocator spilled it and reloaded it before the stores, behind every outstanding memory operation)
+                    uint32_t ts = (uint32_t)cB.z; asm volatile("" : "+v"(ts));
+                    tw = bp.trace_arena + (uint64_t)ts * bp.trace_stride + (trace_top + l8);
                     if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
                         BlockRec br;
                         br.i = (right ? ri : rj) | 0x80000000u;   // (bit 31: words of 4 cells x 2 columns, see multi_rect)
                         br.j = right ? rj : ri; br.h = (uint16_t)(right ? MQ_B : STEP); br.w = (uint16_t)(right ? STEP : MQ_B);
                         br.trace_base = trace_top | (right ? 0x80000000u : 0u);
-                        bp.blocks[(uint64_t)tslot * bp.blocks_stride + nblocks] = br;
+                        bp.blocks[(uint64_t)(uint32_t)cB.z * bp.blocks_stride + nblocks] = br;
                     }
                 }
                 MultiOut o;
@@ -543,7 +672,6 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     best_max = imp ? new_off_max : best_max;
                     off = commit ? off_n : off; off_max = commit ? new_off_max : off_max; y_drop = commit ? new_y : y_drop;
                     prev_dir = commit ? dir : prev_dir; D_corner = commit ? o.corner_new : D_corner;
-                    nsteps += commit ? 1u : 0u;
                     if (TRACE) { trace_top += commit ? (uint32_t)(STEP * MQ_B / 8) : 0u; nblocks += commit ? 1u : 0u; }
                     if (XDROP) x_iter = commit ? ((new_off_max < best_max - x_drop) ? x_iter + 1 : 0) : x_iter;
                     const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
@@ -580,6 +708,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             lds_sync();
             if (live && l == 0) {
                 int* rc = (int*)(slot_mem + 2 * MQ_BUF_BYTES);
+                // (the steps taken here are not counted in a register: every one moved the block by STEP in one direction)
+                const uint32_t nsteps = (uint32_t)mq_load((const char*)(rc + MR_NSTEPS)) + ((si + sj) - (uint32_t)mq_load((const char*)(rc + MR_SI)) - (uint32_t)mq_load((const char*)(rc + MR_SJ))) / (uint32_t)STEP;
                 rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = prev_dir; rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
                 rc[MR_Y_DROP] = (int)y_drop; rc[MR_X_ITER] = x_iter; rc[MR_D_CORNER] = D_corner; rc[MR_NSTEPS] = (int)nsteps; rc[MR_TRACE_TOP] = (int)trace_top;
                 rc[MR_NBLOCKS] = (int)nblocks; rc[MR_SEL] = (int)sel;
@@ -597,11 +727,12 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
         atomicAdd(bp.prof + 50, t_solo); atomicAdd(bp.prof + 51, t_quad); atomicAdd(bp.prof + 52, t_wait); atomicAdd(bp.prof + 53, n_solo); atomicAdd(bp.prof + 54, n_quad); atomicAdd(bp.prof + 55, 1ull);
     }
 #endif
-#ifdef BA_DEV
+#ifdef BA_ENDHIST
     if (bp.prof && is_lane(0)) {   // development (tools/dev/ragged_end.py): when did this fill wave run out of pairs? 4 ms buckets after the launch's start
         const unsigned long long t0 = __hip_atomic_load(bp.prof + 43, BA_RLX_AGENT), t = __builtin_amdgcn_s_memrealtime();
         const unsigned long long k = t0 && t > t0 ? (t - t0) / 400000ull : 0ull;
         atomicAdd(bp.prof + 64 + (k < 63ull ? k : 63ull), 1ull);
+        atomicMax(bp.prof + 40, t);
     }
 #endif
     // a fill wave joins the traceback side with one lane once the batch has no pairs left for it (see k_align)
@@ -615,10 +746,12 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
 #else
         traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, MQ_HELPER_LANES, false);
 #endif
-#ifdef BA_TIMING
+#if defined(BA_TIMING) || defined(BA_ENDHIST)
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     }
 }
 
+#undef don_final
+#undef don_offers
 }  // namespace ba

@@ -101,6 +101,9 @@ struct BatchParams {
     uint32_t ckpt_wave0;         // this launch's first wave in the checkpoint arena (two per-pair kernels of one batch run side by side)
     uint32_t mq_drain;           // k_multi: the last mq_drain pairs of the batch are not taken into slots (four pairs per wave, each four times as long in
                                  // flight) but one at a time by waves whose slots have emptied, and run on all lanes to their end: a finer ragged end
+    uint32_t* mq_donate;         // k_multi: one word per wave of the launch (blockIdx * 8 + wave), bit s = slot s of that wave is offered to waves that have run out
+                                 // of work (end of the batch), followed by two counters: [waves] fill waves that will offer nothing more, [waves + 32] offers outstanding; null = no donation
+    uint32_t mq_waves;           // k_multi: waves of the launch (workgroups x 8): the number of words in mq_donate
     uint32_t walk_wave_n;        // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (walk_wave), the others one to a lane
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
     uint32_t sm_excl_n;          // k_small: the first sm_excl_n pairs of the batch order (its longest) run one to a wave on all lanes, from start to end (work_counter[2])
@@ -119,7 +122,7 @@ constexpr uint32_t MQ_B_HOST = 128;   // k_multi: block size of a slot (ba_drive
 constexpr uint32_t MQ_BUF_BYTES = 4 * 256 + 64, MQ_SLOT_BYTES = 2 * MQ_BUF_BYTES + 128, MQ_WAVE_BYTES = 4 * MQ_SLOT_BYTES;
 // k_multi: while the slots run, the same buffers live in the wave's LDS region (the solo borders' space, which the slots do not need):
 // 4 slots x 2 buffers x 1 KB of borders, then 8 x 9 scalars
-constexpr uint32_t MQ_LDS_SCALARS = 8192, MQ_LDS_BYTES = 8192 + 8 * 36 + 32;
+constexpr uint32_t MQ_LDS_SCALARS = 8192, MQ_LSC_INTS = 28, MQ_LDS_BYTES = 8192 + 4 * MQ_LSC_INTS * 4;   // per slot: 2 x 9 scalars, 2 free, 8 constants of the slot's pair (sequence addresses and lengths, trace slot)
 // k_small (ba_small.hpp): sixteen pairs per wave while the block is 32 cells -- slots of 4 lanes x 8 cells. Per wave and slot in the `big`
 // arena: two state buffers (4 border arrays x 4 lanes x 16 bytes + 8 scalars) and a 128-byte record; while the slots run the buffers live in
 // the wave's LDS region (16 slots x 2 buffers x 256 bytes of borders, then 16 x 2 x 8 scalars)
@@ -133,7 +136,7 @@ BA_HD constexpr uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size 
 BA_HD constexpr uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_array_bytes_h(max_size) + 128; }
 BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }
 BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
-BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > 8512u ? lds_wave_bytes_h(max_size) : 8512u; }   // k_multi (MQ_LDS_BYTES)
+BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > MQ_LDS_BYTES ? lds_wave_bytes_h(max_size) : MQ_LDS_BYTES; }   // k_multi
 BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * mq_wave_bytes_h(max_size); }
 BA_HD constexpr uint32_t sm_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > SM_LDS_BYTES ? lds_wave_bytes_h(max_size) : SM_LDS_BYTES; }   // k_small
 BA_HD constexpr uint32_t sm_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * sm_wave_bytes_h(max_size); }
@@ -143,7 +146,7 @@ constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;
 constexpr uint32_t TB_LANE_BYTES_L2 = 100;   // k_multi's traceback waves (16 trace words per window): their records sit in the wave's own LDS region   // table first, then the records (a helper fill wave uses one)
 constexpr uint32_t TB_LDS_BYTES_L2 = 6656;   // k_walk over a k_small batch: the move table + 64 records of TB_LANE_BYTES_L2
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= TB_LDS_BYTES_L2, "k_walk LDS (slot rectangles)");
-static_assert(MQ_LDS_BYTES <= 8512u && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= 8512u, "k_multi LDS");
+static_assert(MQ_LDS_BYTES % 16 == 0 && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= MQ_LDS_BYTES, "k_multi LDS");
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES <= lds_wave_bytes_h(128), "traceback LDS regions");
 
 }  // namespace ba
