@@ -722,18 +722,20 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int g = fc.gap_extend;
-    const int laneKG = lane * 8 * g, lanem1KG = lane ? (lane - 1) * 8 * g : -32768;
-    int G[4], vart[4];
+    int laneKG = lane * 8 * g, lanem1KG = lane ? (lane - 1) * 8 * g : -32768;
+    int G[4], vart3;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        G[k] = pk(max(-32768, (2 * k + 1) * g), max(-32768, (2 * k + 2) * g));
+    for (int k = 0; k < 4; k++) G[k] = pk(max(-32768, (2 * k + 1) * g), max(-32768, (2 * k + 2) * g));
+    {
+        // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338; see k_align): for a lane's first six cells -- cell & 7 =
+        // 2k + h, multiplier 2k + h + 1 -- they are the wave-uniform G[k]; only the last register differs from lane to lane
         int t[2];
-        for (int h = 0; h < 2; h++) {   // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338; see k_align)
-            const int k16 = (8 * lane + 2 * k + h) & 15;
+        for (int h = 0; h < 2; h++) {
+            const int k16 = (8 * lane + 6 + h) & 15;
             const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
             t[h] = mult ? max(-32768, mult * g) : -32768;
         }
-        vart[k] = pk(t[0], t[1]);
+        vart3 = pk(t[0], t[1]);
     }
     const int offa = splat(off_add);
     int d[NC8][4], c[NC8][4], dmax[NC8][4], jlast[NC8][4], tacc[NC8][4];
@@ -785,6 +787,11 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
     // branch in between -- one basic block, which is what lets the scheduler interleave the chunks)
     auto iteration = [&](uint32_t t, auto guard_c) {
         constexpr bool GUARD = decltype(guard_c)::value;
+        // (the three per-lane constants of the scan are kept out of the allocator's list of cheap things to park in scratch memory: as
+        // loop invariants they were, in some builds, reloaded in the middle of an iteration, behind every outstanding memory operation --
+        // config 3 176 against 184 ms depending on unrelated code elsewhere in the kernel. The same marks in fast_rect / place_rect:
+        // no gain there, and the score-only kernels lose 2.5 %)
+        asm volatile("" : "+v"(laneKG), "+v"(lanem1KG), "+v"(vart3));
         if (((t + 1) & 7) == 0) { cbase = (int)(t + 1) - 8; cvec = load_cols(cbase); }   // (t + 1 - c8 >= cbase for every chunk: NC8 <= 4)
         int d_last = 0, r_last = 0;
 #pragma unroll
@@ -836,7 +843,7 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
             const s16x2 cs = as_s(cin);
             const int csp = as_i(s16x2{cs.x, cs.x});
 #pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = vmax(vmax(r[k], adds(csp, G[k])), vart[k]);
+            for (int k = 0; k < 4; k++) r[k] = vmax(vmax(r[k], adds(csp, G[k])), k < 3 ? G[k] : vart3);
             if (NC8 > 1 && c8 < NC8 - 1) carry_cap[c8] = (int)(short)(__builtin_amdgcn_readlane(r[3], 63) >> 16);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
