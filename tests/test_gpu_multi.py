@@ -62,6 +62,19 @@ def test_multi_config3_shape_with_traceback_waves(hip, oracle, force_multi, monk
     assert (res["query_idx"] > 2000).all()
 
 
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
+@pytest.mark.parametrize("n,wgs", [(600, "1"), (2500, "1"), (9000, "2")])
+def test_multi_slots_change_waves_at_the_end_of_the_batch(hip, oracle, force_multi, monkeypatch, n, wgs, mode):
+    """The end of a k_multi batch (round 4): waves that go solo for the last time offer their other slots, waves whose slot has emptied
+    refill it from an offer, waves with nothing left run an offered slot to its end out of the other wave's arena region. Few pairs per
+    wave make most of the launch such an end; 600 pairs run on 75 workgroups -- a wave count that is not a multiple of 64 (the scan over
+    the waves' offer words once ran into the counters behind them there). Every pair is compared with the oracle."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", wgs)
+    pairs = synth.make_pairs(n, (1500, 6000), (100, 600), 300, synth.DNA, seed=77 + n, indels=1, indel_len=(20, 200))
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, mode, threads=16)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_multi_at_production_threshold(hip, oracle, mode):
     """No forcing: a batch above the size from which the library itself picks the multi-pair kernel."""

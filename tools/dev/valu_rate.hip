@@ -106,6 +106,17 @@
 #define K_CND0(r) "v_cndmask_b32_e64 " r ", " r ", %9, s[22:23]\n"
 #define K_CNDEXEC(r) "v_cndmask_b32_e64 " r ", " r ", %9, exec\n"
 
+// ---- round 4: groups shaped like multi_rect's mix (recurrence: packed VOP3P; trace packing / shifts / moves: the candidates for 2.3-cycle VOP2 forms)
+#define L_3PK_AND(r) "v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_max_i16 " r ", " r ", %9\n v_pk_add_i16 " r ", " r ", %9 clamp\n v_and_b32 " r ", " r ", %9\n"
+#define L_3PK_BFI(r) "v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_max_i16 " r ", " r ", %9\n v_pk_add_i16 " r ", " r ", %9 clamp\n v_bfi_b32 " r ", %9, " r ", %9\n"
+#define L_4PK(r) "v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_max_i16 " r ", " r ", %9\n v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_max_i16 " r ", " r ", %9\n"
+#define L_SHR_BFI(r) "v_lshrrev_b32 " r ", 1, " r "\n v_bfi_b32 " r ", %9, " r ", %9\n"
+#define L_SHR_AND_AND_OR(r) "v_lshrrev_b32 " r ", 1, " r "\n v_and_b32 " r ", " r ", %9\n v_and_b32 " r ", " r ", %9\n v_or_b32 " r ", " r ", %9\n"
+#define L_PK_FAST_PK_FAST(r) "v_pk_add_i16 " r ", " r ", %9 clamp\n v_and_b32 " r ", " r ", %9\n v_pk_max_i16 " r ", " r ", %9\n v_lshrrev_b32 " r ", 1, " r "\n"
+#define L_2PK_2FAST(r) "v_pk_add_i16 " r ", " r ", %9 clamp\n v_pk_max_i16 " r ", " r ", %9\n v_and_b32 " r ", " r ", %9\n v_lshrrev_b32 " r ", 1, " r "\n"
+#define L_MAXI16_PAIR(r) "v_max_i16 " r ", " r ", %9\n v_max_i16_sdwa " r ", " r ", %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
+#define L_PERM(r) "v_perm_b32 " r ", " r ", %9, %9\n"
+#define L_SHL16_OR(r) "v_lshlrev_b16 " r ", 8, " r "\n v_or_b32 " r ", " r ", %9\n"
 struct Case { const char* name; int id; int per_group; };   // per_group: VALU instructions counted per accumulator visit
 
 template <int KIND>
@@ -129,6 +140,8 @@ __global__ void __launch_bounds__(256) k(int* out, unsigned long long* ticks, in
         CASE(68, J_ADDF32DPP) CASE(69, J_MAXI16DPP) CASE(70, J_ASHRDPP) CASE(71, J_MED3I) CASE(72, J_MED3F) CASE(73, J_MAX3F) CASE(74, J_ADD3)
         CASE(75, J_MAXF32E64) CASE(76, J_PKMAXF16) CASE(77, J_PKADDF16) CASE(78, J_ADDF32S) CASE(79, J_ADDF32K) CASE(80, J_CNDMASK2)
         CASE(88, K_CNDE64) CASE(89, K_CNDMIX) CASE(90, K_CND0) CASE(91, K_CNDEXEC)
+        CASE(92, L_3PK_AND) CASE(93, L_3PK_BFI) CASE(94, L_4PK) CASE(95, L_SHR_BFI) CASE(96, L_SHR_AND_AND_OR) CASE(97, L_PK_FAST_PK_FAST) CASE(98, L_2PK_2FAST)
+        CASE(99, L_MAXI16_PAIR) CASE(100, L_PERM) CASE(101, L_SHL16_OR)
         CASE(81, J_MAXI16S) CASE(82, J_SUBREV) CASE(83, J_LSHLADD) CASE(84, J_ADDLSHL) CASE(85, J_SADU16) CASE(86, J_MIX2) CASE(87, J_MIX3)
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -173,6 +186,14 @@ int main(int argc, char** argv) {
                 "| instruction | W=1 | W=2 | W=4 | W=8 |\n|---|---|---|---|---|\n", p.name, p.multiProcessorCount, p.clockRate);
 #define RUN(N, NAME) if (N >= first) run<N>(NAME, md);
     const int first = argc > 2 ? atoi(argv[2]) : 0;
+    if (first == 2) {   // round 4 (profiles/r04_valu_rate.md)
+        RUN(94, "group: 4 packed (add, max, add, max)") RUN(93, "group: 3 packed + v_bfi_b32") RUN(92, "group: 3 packed + v_and_b32 (VOP2, vgpr)")
+        RUN(98, "group: 2 packed, then v_and_b32 + v_lshrrev_b32") RUN(97, "group: packed, v_and_b32, packed, v_lshrrev_b32 (interleaved)")
+        RUN(95, "group: v_lshrrev_b32 + v_bfi_b32 (one insert of the trace packing)") RUN(96, "group: v_lshrrev_b32 + 2 v_and_b32 + v_or_b32 (the same insert in VOP2 forms)")
+        RUN(1, "v_pk_max_i16") RUN(99, "group: v_max_i16 + v_max_i16_sdwa WORD_1 (the same maximum in two halves)")
+        RUN(100, "v_perm_b32") RUN(101, "group: v_lshlrev_b16 + v_or_b32")
+        fclose(md); return 0;
+    }
     if (first) { RUN(24, "v_cndmask_b32 vcc") RUN(88, "v_cndmask_b32_e64 sgpr pair") RUN(89, "group: v_cndmask vcc + 3 v_pk_add_i16") RUN(90, "v_cndmask_b32_e64 sgpr pair = 0") RUN(91, "v_cndmask_b32_e64 exec") RUN(16, "v_bfi_b32") fclose(md); return 0; }
     RUN(0, "v_pk_add_i16 clamp") RUN(1, "v_pk_max_i16") RUN(2, "v_pk_max_i16 op_sel_hi") RUN(3, "v_pk_sub_u16") RUN(4, "v_pk_min_u16 inline const")
     RUN(5, "v_pk_mad_u16") RUN(6, "v_pk_ashrrev_i16") RUN(7, "v_add_u32") RUN(8, "v_max_i32") RUN(9, "v_max3_i32") RUN(10, "v_max_i32_dpp row_shr:1")
