@@ -286,7 +286,7 @@ struct BaBatch {
         bp.q_off = q_off.as<uint64_t>(); bp.q_len = q_len.as<uint32_t>();
         bp.r_off = r_off.as<uint64_t>(); bp.r_len = r_len.as<uint32_t>();
         bp.n = n; bp.gap_open = gap_open; bp.gap_extend = gap_extend;
-        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (dev_env("BA_NO_FAST") ? 0x100u : 0u) | ((dev_env("BA_SKIP_WALK") || dev_env("BA_NO_TRACEBACK")) ? 0x200u : 0u) | ((handle_mode || dev_env("BA_NO_SPEC")) ? 0x400u : 0u) | (dev_env("BA_NO_TB_WAVES") ? 0x800u : 0u) | (dev_env("BA_NO_REFILL") ? 0x1000u : 0u) | (dev_env("BA_NO_STEAL") ? 0x2000u : 0u) | (dev_env("BA_X4") ? 0x4000u : 0u) | (dev_env("BA_X8") ? 0x8000u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
+        bp.min_size = min_size; bp.max_size = max_size; bp.x_drop = x_drop; bp.flags = mode | (dev_env("BA_NO_FAST") ? 0x100u : 0u) | ((dev_env("BA_SKIP_WALK") || dev_env("BA_NO_TRACEBACK")) ? 0x200u : 0u) | ((handle_mode || dev_env("BA_NO_SPEC")) ? 0x400u : 0u) | (dev_env("BA_NO_TB_WAVES") ? 0x800u : 0u) | (dev_env("BA_NO_REFILL") ? 0x1000u : 0u) | (dev_env("BA_NO_STEAL") ? 0x2000u : 0u);   // (0x400: no speculative grows -- a handle's trace may be walked from any cell)
         bp.matrix = matrix.as<int8_t>();
         bp.score = score.as<int32_t>(); bp.query_idx = qidx.as<uint32_t>(); bp.reference_idx = ridx.as<uint32_t>();
         bp.cig_ops = ((mode & BA_TRACE) && !handle_mode && !dev_env("BA_NO_TRACEBACK")) ? cig_ops.as<uint32_t>() : nullptr;   // env: development switch

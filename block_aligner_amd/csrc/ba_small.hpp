@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             // (a pair run from start to end here -- one of the batch's longest -- walks its path at once, with the whole wave: the batch's longest
             // walks overlap with the fill. Tried instead: the first waves to run out of work take these walks from a counter -- they all run out
             // at about the same time, so the walks only lengthen the launch: protein set with traceback 11.1 -> 13.3 ms)
-            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh, to_end);
+            st = al.run(s_pair, s_pair, false, nullptr, fresh ? MM_FRESH : MM_RESUME, st, !to_end, !fresh, to_end);   // (walk_now: tried -- these walks left to k_walk_l2's whole-wave walkers: C4 with traceback 11.23 -> 11.07 ms, within the spread)
             __builtin_amdgcn_s_setprio(0);
             live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
             more = unpark<4>(keepv) & 1; excl_more = unpark<4>(keepv) & 2; solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv);
