@@ -570,6 +570,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     const uint64_t per_wg = (uint64_t)ba::WAVES_PER_WG * (b->small ? ba::SM_SLOTS : 1u);
     const uint64_t need = (n + per_wg - 1) / per_wg;
     if (grid > need) grid = need;
+    if (const char* env = dev_env("BA_GRID")) { int v = atoi(env); if (v > 0 && (uint64_t)v < grid) grid = (uint64_t)v; }   // (development: fewer workgroups)
     // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
     // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
     const uint64_t zm = (mode & BA_LOCAL_START) ? 5 : 1;
