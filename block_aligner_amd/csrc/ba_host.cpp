@@ -263,6 +263,7 @@ struct BaBatch {
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
     uint32_t walk_wave_n = 0;   // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (plan_walks)
     uint32_t sm_excl_n = 0;     // k_small: the batch's longest pairs, run one to a wave (plan_exclusive)
+    uint32_t sm_side_n = 0;     // ... of which the first sm_side_n run in a launch of their own beside the main one (TRACE batches: batch_launch)
     bool small = false;         // small-block batch: sixteen pairs per wave while their block is 32 cells, everything else by the same wave (ba_small.hpp)
     bool quad = false;          // small-block batch: pairs run 4 per wave while their block is 32 cells (ba_quad.hpp)
     DevBuf contA, cont_n;       // the PairCont records of the pairs k_quad hands to the per-pair kernel, and the per-pair flags
@@ -306,7 +307,7 @@ struct BaBatch {
         bp.mq_drain = mq_drain;
         bp.mq_waves = grid * ba::WAVES_PER_WG;
         bp.mq_donate = (multi && (mode & BA_TRACE) && donate.p && !dev_env("BA_NO_DONATE")) ? donate.as<uint32_t>() : nullptr;   // (the score-only kernels are compiled without the end-of-batch code)
-        bp.sm_excl_n = small ? sm_excl_n : 0;
+        bp.sm_excl_n = small ? sm_excl_n : 0; bp.sm_excl_first = 0;
         bp.prof = prof.as<unsigned long long>();
         return bp;
     }
@@ -687,7 +688,7 @@ static int batch_alloc_scratch(BaBatch* b) {
     BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short)
                                               : (b->multi ? (size_t)b->grid * ba::WAVES_PER_WG * ba::MQ_WAVE_BYTES : (b->small ? (size_t)b->grid * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES : 0)));
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
-    BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 64);
+    BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 128);
     if (b->multi) BA_ALLOC(donate, ((size_t)b->grid * ba::WAVES_PER_WG + 64) * 4);   // (+ two counters in their own cache lines)
 #undef BA_ALLOC
     return 0;
@@ -824,7 +825,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         if (b->cq_queue.alloc(n * 4) || b->cq_ctrl.alloc(256)) return nullptr;
         if (g_quad_grid[kind](trace ? 1 : 0, (mode & BA_X_DROP) ? 1 : 0, &b->quad_grid) != hipSuccess || !b->quad_grid) { fail("occupancy query failed for the small-block kernel"); return nullptr; }
     }
-    if (b->quad && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
+    if ((b->quad || (b->small && trace)) && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
                                hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess)) {
         fail("hipStreamCreate / hipEventCreate failed"); return nullptr;
     }
@@ -938,6 +939,17 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     size_t cnt = 0;
     while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
     b->sm_excl_n = (uint32_t)cnt;
+    // TRACE: the longest of them -- at least half the longest pair's length, at most one wave in thirty-two -- get a launch of their own
+    // beside the main one (batch_launch): their fill + walk is a serial chain that outlasts the rest of the batch (400 k protein pairs with
+    // traceback: the 8881-residue pair alone takes 8.6 ms, everything else 6 ms), and the walks of all other pairs need not wait for it
+    size_t side = 0;
+    if ((b->mode & BA_TRACE) && cnt && !dev_env("BA_NO_EXCL_SIDE")) {
+        const uint64_t longest = (uint64_t)ql[0] + rl[0];
+        const size_t side_cap = std::max<size_t>(4, (size_t)b->grid / 8);   // (a workgroup of the side launch runs four pairs: at most one workgroup in 32)
+        while (side < cnt && side < side_cap && ((uint64_t)ql[side] + rl[side]) * 2 >= longest) side++;
+        if (b->grid < 16) side = 0;
+    }
+    b->sm_side_n = (uint32_t)side;
 }
 static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves x 64 walking lanes each)
     hipDeviceProp_t prop;
@@ -952,7 +964,7 @@ static int batch_launch(BaBatch* b) {
     if (b->n == 0) return fail("the batch holds no pairs (its last reload failed)");
     HIP_TRY(hipSetDevice(b->device));
     if (!b->handle_mode) {   // (a handle's work counter arrives zeroed with its upload; it has no hand-off structures)
-        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
+        HIP_TRY(hipMemsetAsync(b->counter.p, 0, 128, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
         HIP_TRY(hipMemsetAsync(b->prof.p, 0, 2048, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
@@ -1012,11 +1024,32 @@ static int batch_launch(BaBatch* b) {
         // (the pairs run one to a wave at the start of the launch -- the batch's longest -- walk their paths at once, with the whole wave:
         // the longest walk of the batch overlaps with the fill instead of ending the launch)
         BatchParams p1 = bp; p1.inline_len2 = ~0u;
-        HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));
-        if ((b->mode & BA_TRACE) && bp.cig_ops) {
-            HIP_TRY(hipMemsetAsync(b->counter.p, 0, 64, b->stream));
-            HIP_TRY(ba_launch_walk_l2(b->stream, &bp, walk_grid(b)));
+        const uint32_t side_n = (b->stream2 && bp.cig_ops && b->sm_side_n && b->sm_side_n <= b->sm_excl_n) ? b->sm_side_n : 0u;
+        uint32_t grid_main = b->grid;
+        if (side_n) {
+            // The longest pairs' launch: one wave per pair, workgroups taken off the main launch (together they fill the device as one
+            // launch would); its waves use the tail of the wave-indexed scratch (arena, checkpoints). k_walk_l2 skips these pairs -- their
+            // waves walk them at once --, also while they are still being filled: their hand-over records say "nothing to walk" beforehand.
+            const uint32_t grid_side = (side_n + 3) / 4;   // (four of a workgroup's eight waves take pairs: one per SIMD, see k_small)
+            grid_main = b->grid - grid_side;
+            HIP_TRY(hipMemsetAsync(b->slot_info.p, 0xff, (size_t)side_n * sizeof(ba::SlotInfo), b->stream));
+            HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+            BatchParams ps = p1;
+            ps.n = side_n; ps.sm_excl_n = side_n; ps.sm_excl_first = 0;
+            ps.work_counter = b->counter.as<uint32_t>() + 8;
+            ps.big = (short*)((char*)b->big.p + (size_t)grid_main * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES);
+            ps.ckpt_wave0 = grid_main * ba::WAVES_PER_WG; ps.cq_side = 1;
+            HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+            HIP_TRY(g_launch_sm[b->kind][b->pclass](true, (b->mode & BA_X_DROP) != 0, grid_side, b->lds, b->stream2, &ps));
+            HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
+            p1.sm_excl_first = side_n;
         }
+        HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_main, b->lds, b->stream, &p1));
+        if ((b->mode & BA_TRACE) && bp.cig_ops) {
+            BatchParams pw = bp; pw.work_counter = b->counter.as<uint32_t>() + 16;   // (its own counters, zeroed with the others: the side launch may still be counting)
+            HIP_TRY(ba_launch_walk_l2(b->stream, &pw, walk_grid(b)));
+        }
+        if (side_n) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     } else if (b->pipe) {   // pair-slot batch: the fill stacks, k_walk walks
         BatchParams p1 = bp; p1.cig_ops = nullptr; p1.inline_len2 = ~0u;
         HIP_TRY(launch(1, (b->mode & BA_X_DROP) != 0, b->grid, b->lds, b->stream, &p1));

@@ -106,6 +106,7 @@ struct BatchParams {
     uint32_t mq_waves;           // k_multi: waves of the launch (workgroups x 8): the number of words in mq_donate
     uint32_t walk_wave_n;        // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (walk_wave), the others one to a lane
     uint32_t work_chunk;         // pairs (records) a wave takes per atomic on the work counter (one counter serves ~90 atomics / us)
+    uint32_t sm_excl_first;      // k_small: this launch's exclusive pairs are [sm_excl_first, sm_excl_n) of the batch order (the longest of them run in a launch of their own, beside the main one)
     uint32_t sm_excl_n;          // k_small: the first sm_excl_n pairs of the batch order (its longest) run one to a wave on all lanes, from start to end (work_counter[2])
     // single-pair traceback request (k_traceback): end position
     uint32_t tb_i, tb_j, tb_nblocks, tb_slot;

@@ -195,7 +195,10 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
 }
 
 template <int PMAX, int KIND, bool TRACE, bool XDROP>
-__global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_small(const BatchParams bp) {
+#ifndef SM_WAVES_EU
+#define SM_WAVES_EU 4   // (waves per SIMD the kernel is compiled for; 2 -- 256 registers -- was tried for the traced kernels: see DESIGN.md)
+#endif
+__global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(SM_WAVES_EU, SM_WAVES_EU))) k_small(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), l = lane & (SM_LW - 1), g = lane >> 2;
     const int wave = uni((int)threadIdx.x >> 6);
@@ -212,6 +215,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
         }
     }
     __syncthreads();
+    // (the launch of the batch's longest pairs, beside the main one: one wave per SIMD takes pairs -- four solo drivers to a SIMD would slow
+    // each other down, and these chains are what the launch waits for)
+    if (bp.cq_side && wave >= 4) return;
     constexpr uint32_t LCLS = (uint32_t)PMAX * 128u;
     constexpr uint32_t ab = lds_array_bytes_h(LCLS);
     char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * sm_wave_bytes_h(LCLS);
@@ -237,13 +243,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
     // average length would end the launch alone (400 k protein pairs 22 .. 8881: 10.7 ms with the 77 longest, 5.3 without). Each wave takes
     // at most a few of them, one at a time, before it starts its slots, and runs them from start to end on all its lanes.
     const uint32_t excl_n = bp.sm_excl_n;
-    bool excl_more = excl_n > 0;
+    bool excl_more = excl_n > bp.sm_excl_first;
 
     for (;;) {
         if (excl_more && !live_m && !pend_m) {
             uint32_t e = 0;
             if (is_lane(0)) e = atomicAdd(bp.work_counter + 2, 1u);
-            e = (uint32_t)uni((int)e);
+            e = (uint32_t)uni((int)e) + bp.sm_excl_first;
             if (e < excl_n) {
                 if (is_lane(0)) { int* rc = (int*)(wave_mem + 2 * SM_BUF_BYTES); rc[MR_PAIR] = (int)e; rc[MR_FLAGS] = 3; }
                 pend_m = 1u;
