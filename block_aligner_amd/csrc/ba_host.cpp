@@ -825,7 +825,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         if (b->cq_queue.alloc(n * 4) || b->cq_ctrl.alloc(256)) return nullptr;
         if (g_quad_grid[kind](trace ? 1 : 0, (mode & BA_X_DROP) ? 1 : 0, &b->quad_grid) != hipSuccess || !b->quad_grid) { fail("occupancy query failed for the small-block kernel"); return nullptr; }
     }
-    if ((b->quad || (b->small && trace)) && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
+    if ((b->quad || b->small) && (hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess ||
                                hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) != hipSuccess)) {
         fail("hipStreamCreate / hipEventCreate failed"); return nullptr;
     }
@@ -943,7 +943,7 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     // beside the main one (batch_launch): their fill + walk is a serial chain that outlasts the rest of the batch (400 k protein pairs with
     // traceback: the 8881-residue pair alone takes 8.6 ms, everything else 6 ms), and the walks of all other pairs need not wait for it
     size_t side = 0;
-    if ((b->mode & BA_TRACE) && cnt && !dev_env("BA_NO_EXCL_SIDE")) {
+    if (((b->mode & BA_TRACE) || dev_env("BA_EXCL_SIDE_ALL")) && cnt && !dev_env("BA_NO_EXCL_SIDE")) {
         const uint64_t longest = (uint64_t)ql[0] + rl[0];
         const size_t side_cap = std::max<size_t>(4, (size_t)b->grid / 8);   // (a workgroup of the side launch runs four pairs: at most one workgroup in 32)
         while (side < cnt && side < side_cap && ((uint64_t)ql[side] + rl[side]) * 2 >= longest) side++;
@@ -1024,7 +1024,7 @@ static int batch_launch(BaBatch* b) {
         // (the pairs run one to a wave at the start of the launch -- the batch's longest -- walk their paths at once, with the whole wave:
         // the longest walk of the batch overlaps with the fill instead of ending the launch)
         BatchParams p1 = bp; p1.inline_len2 = ~0u;
-        const uint32_t side_n = (b->stream2 && bp.cig_ops && b->sm_side_n && b->sm_side_n <= b->sm_excl_n) ? b->sm_side_n : 0u;
+        const uint32_t side_n = (b->stream2 && (bp.cig_ops || !(b->mode & BA_TRACE)) && b->sm_side_n && b->sm_side_n <= b->sm_excl_n) ? b->sm_side_n : 0u;
         uint32_t grid_main = b->grid;
         if (side_n) {
             // The longest pairs' launch: one wave per pair, workgroups taken off the main launch (together they fill the device as one
@@ -1040,7 +1040,7 @@ static int batch_launch(BaBatch* b) {
             ps.big = (short*)((char*)b->big.p + (size_t)grid_main * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES);
             ps.ckpt_wave0 = grid_main * ba::WAVES_PER_WG; ps.cq_side = 1;
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
-            HIP_TRY(g_launch_sm[b->kind][b->pclass](true, (b->mode & BA_X_DROP) != 0, grid_side, b->lds, b->stream2, &ps));
+            HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_side, b->lds, b->stream2, &ps));
             HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
             p1.sm_excl_first = side_n;
         }
