@@ -1603,6 +1603,7 @@ extern "C" int ba_shard_slices(const uint32_t* q_len, const uint32_t* r_len, uin
 struct BaMultiBatch {
     std::vector<std::unique_ptr<BaBatch>> part;
     std::vector<uint64_t> bounds;     // part k holds the caller's pairs [bounds[k], bounds[k + 1])
+    std::vector<float> last_ms;       // kernel time of every part in the last ba_multibatch_run (HIP events on the part's own stream)
     uint32_t mode = 0;
 };
 
@@ -1648,10 +1649,13 @@ int ba_multibatch_run(BaMultiBatch* m, float* kernel_ms) {
         if (batch_launch(b.get())) first_err = g_err;
     }
     float worst = 0;
-    for (auto& b : m->part) {
+    m->last_ms.assign(m->part.size(), 0.f);
+    for (size_t k = 0; k < m->part.size(); k++) {
+        auto& b = m->part[k];
         if (!b || !b->in_flight) continue;
         float ms = 0;
         if (batch_wait(b.get(), &ms)) { if (first_err.empty()) first_err = g_err; b->in_flight = false; continue; }
+        m->last_ms[k] = ms;
         worst = std::max(worst, ms);
     }
     if (!first_err.empty()) return fail("%s", first_err.c_str());
@@ -1683,6 +1687,11 @@ int ba_multibatch_cigars(BaMultiBatch* m, uint32_t* runs, uint64_t capacity) {
         at += total;
     }
     return 0;
+}
+int ba_multibatch_kernel_ms(BaMultiBatch* m, float* ms, int capacity) {   // per slice, of the last run; returns the number of slices
+    if (!m) return -1;
+    for (int k = 0; k < capacity && k < (int)m->last_ms.size(); k++) ms[k] = m->last_ms[k];
+    return (int)m->part.size();
 }
 int ba_multibatch_parts(BaMultiBatch* m, uint64_t* bounds, int capacity) {   // slice boundaries (n_devices + 1 entries); returns n_devices
     if (!m) return -1;

@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
         L.ba_multibatch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_multibatch_cigars.argtypes = [vp, vp, C.c_uint64]
         L.ba_multibatch_parts.argtypes = [vp, vp, C.c_int]
+        L.ba_multibatch_kernel_ms.argtypes = [vp, vp, C.c_int]
         L.ba_multibatch_destroy.argtypes = [vp]
         L.ba_shard_slices.argtypes = [vp, vp, sz, C.c_int, vp]
         _lib = L
@@ -543,6 +544,12 @@ class MultiBatchAligner:
         if lib().ba_multibatch_cigars(self._h, runs.ctypes.data, runs.size):
             raise RuntimeError(last_error())
         return runs, off
+
+    def kernel_ms(self):
+        """Kernel time of every slice in the last run() (ms; HIP events on the slice's own stream)."""
+        t = np.zeros(64, np.float32)
+        k = lib().ba_multibatch_kernel_ms(self._h, t.ctypes.data, 64)
+        return t[:k].copy()
 
     def parts(self):
         b = np.zeros(65, np.uint64)

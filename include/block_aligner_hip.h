@@ -271,6 +271,8 @@ int ba_multibatch_results(BaMultiBatch* batch, int32_t* score, uint32_t* query_i
 int ba_multibatch_cigars(BaMultiBatch* batch, uint32_t* runs, uint64_t capacity);
 /* slice boundaries: bounds[k] .. bounds[k + 1] are the pairs of devices[k]; returns the number of slices */
 int ba_multibatch_parts(BaMultiBatch* batch, uint64_t* bounds, int capacity);
+/* kernel time (ms, HIP events on the slice's own stream) of every slice in the last ba_multibatch_run; returns the number of slices */
+int ba_multibatch_kernel_ms(BaMultiBatch* batch, float* ms, int capacity);
 void ba_multibatch_destroy(BaMultiBatch* batch);
 /* The slicing rule on its own (no device needed): bounds[0 .. parts] for contiguous slices of near-equal summed |q| + |r|. */
 int ba_shard_slices(const uint32_t* q_len, const uint32_t* r_len, uintptr_t n_pairs, int parts, uint64_t* bounds);
