@@ -723,20 +723,14 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
     __builtin_amdgcn_wave_barrier();
     const int g = fc.gap_extend;
     int laneKG = lane * 8 * g, lanem1KG = lane ? (lane - 1) * 8 * g : -32768;
-    int G[4], vart3;
+    int G[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) G[k] = pk(max(-32768, (2 * k + 1) * g), max(-32768, (2 * k + 2) * g));
-    {
-        // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338; see k_align): for a lane's first six cells -- cell & 7 =
-        // 2k + h, multiplier 2k + h + 1 -- they are the wave-uniform G[k]; only the last register differs from lane to lane
-        int t[2];
-        for (int h = 0; h < 2; h++) {
-            const int k16 = (8 * lane + 6 + h) & 15;
-            const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
-            t[h] = mult ? max(-32768, mult * g) : -32768;
-        }
-        vart3 = pk(t[0], t[1]);
-    }
+    // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338; see k_align): R of a cell is at least ((cell & 7) + 1) g -- for a
+    // lane's first seven cells that is the wave-uniform G[k], for the eighth 12g in even lanes (vector cell 7) and nothing in odd ones (cell 15).
+    // max(cs + G, G) = max(cs, 0) + G (saturating adds of non-positive constants compose): the carry that enters the lane is floored once per
+    // column at {0, 4g | none} instead of a max with the artefact per register (round 5: 3 instructions fewer per 512-cell column)
+    int w0 = pk(0, (lane & 1) ? -32768 : 4 * g);
     const int offa = splat(off_add);
     int d[NC8][4], c[NC8][4], dmax[NC8][4], jlast[NC8][4], tacc[NC8][4];
     ScoreKey<KIND> key[NC8][4];
@@ -791,7 +785,7 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
         // loop invariants they were, in some builds, reloaded in the middle of an iteration, behind every outstanding memory operation --
         // config 3 176 against 184 ms depending on unrelated code elsewhere in the kernel. The same marks in fast_rect / place_rect:
         // no gain there, and the score-only kernels lose 2.5 %)
-        asm volatile("" : "+v"(laneKG), "+v"(lanem1KG), "+v"(vart3));
+        asm volatile("" : "+v"(laneKG), "+v"(lanem1KG), "+v"(w0));
         if (((t + 1) & 7) == 0) { cbase = (int)(t + 1) - 8; cvec = load_cols(cbase); }   // (t + 1 - c8 >= cbase for every chunk: NC8 <= 4)
         int d_last = 0, r_last = 0;
 #pragma unroll
@@ -841,9 +835,10 @@ __device__ __forceinline__ Best place_rect8(const WaveLds& L, const FillConsts& 
             int cin = add_shr1(pm, lanem1KG);
             cin = max(max(cin, c8 > 0 ? laneKG + carry_r : laneKG), -32768);
             const s16x2 cs = as_s(cin);
-            const int csp = as_i(s16x2{cs.x, cs.x});
+            const s16x2 cf = as_s(vmax(as_i(s16x2{cs.x, cs.x}), w0));
+            const int csp = as_i(cf), csl = as_i(s16x2{cf.x, cf.x});
 #pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = vmax(vmax(r[k], adds(csp, G[k])), k < 3 ? G[k] : vart3);
+            for (int k = 0; k < 4; k++) r[k] = vmax(r[k], adds(k < 3 ? csl : csp, G[k]));
             if (NC8 > 1 && c8 < NC8 - 1) carry_cap[c8] = (int)(short)(__builtin_amdgcn_readlane(r[3], 63) >> 16);
 #pragma unroll
             for (int k = 0; k < 4; k++) {

@@ -41,8 +41,12 @@ __device__ __forceinline__ int splat_lo(int x) { const s16x2 t = as_s(x); return
 struct MultiConsts {
     int G[4];             // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
     int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g, except row lane 0 which holds -32768 (no lane above: a candidate that never wins)
-    int vtop3;            // per cell: max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column) -- for the lane's
-                          // first six cells that is G[k] in every lane (artefact ((cell & 7) + 1) g >= carry (cell + 1) g), only register 3 differs per lane
+    int w0;               // {0, W}: the floor of the carry that enters the lane from above, per half. Per cell the column's R is also at least
+                          // max(zero-shift-in artefact of the reference's in-vector scan, the MIN = 0 carry above the column) =: V(cell); for the lane's
+                          // first seven cells V = G[k] in every lane (artefact ((cell & 7) + 1) g >= carry (cell + 1) g), i.e. max(cs + G, G) =
+                          // max(cs, 0) + G (saturating adds of non-positive constants compose); the eighth cell's V differs per lane -- 8g in lane 0,
+                          // 12g in the other even lanes, (8l + 8) g in the odd ones -- and is written V = W + 8g: ONE max per column (cs against
+                          // {0, W}) replaces the four per-register maxima with V
 };
 
 struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
@@ -97,12 +101,12 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
 #pragma unroll
         for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(splat_hi(r[k - 1]), mc.G[0]));
         const int pm = wave_prefix_max16((int)as_s(r[3]).y - mc.laneKG);
-        const int cs = splat_lo(add_row_shr1(pm, mc.lanem1KG));             // R of the lane above's last cell (no clamp: see fast_rect)
+        const int cs = vmax(splat_lo(add_row_shr1(pm, mc.lanem1KG)), mc.w0);    // R of the lane above's last cell (no clamp: see fast_rect), floored: see MultiConsts::w0
         int dn[4];
         uint32_t sC[4], sR[4], sCo[4], sRo[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), k < 3 ? mc.G[k] : mc.vtop3);
+            r[k] = vmax(r[k], adds(k < 3 ? splat_lo(cs) : cs, mc.G[k]));
             dn[k] = vmax(d11[k], r[k]);
             if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect); packed below, two registers at a time
                 sC[k] = (uint32_t)subs(cn[k], dn[k]); sR[k] = (uint32_t)subs(r[k], dn[k]); sCo[k] = (uint32_t)subs(copen[k], cn[k]); sRo[k] = (uint32_t)subs(x[k], r[k]);
@@ -118,12 +122,14 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
             // nibble {nRo, nCo, nR, nC} (see fast_rect) serve four cells instead of two.
 #pragma unroll
             for (int p2 = 0; p2 < 2; p2++) {
-                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[2 * p2 + 1], (int)sC[2 * p2], 0x07050301), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[2 * p2 + 1], (int)sR[2 * p2], 0x07050301);
-                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[2 * p2 + 1], (int)sCo[2 * p2], 0x07050301), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[2 * p2 + 1], (int)sRo[2 * p2], 0x07050301);
-                const uint32_t hi2 = bfi(0x80808080u, pRo, pCo >> 1), lo2 = bfi(0x80808080u, pR, pC >> 1);
-                const uint32_t nib = bfi(0xC0C0C0C0u, hi2, lo2 >> 2);   // bits 7..4 of every byte
+                // (v_perm selectors 8 .. 11 replicate a sign bit over the byte: four clean 0x00 / 0xff masks, merged by three bit-field inserts
+                // into the nibble {nRo, nCo, nR, nC} in BOTH halves of every byte -- round 5: 7.5 instead of 11 instructions per register pair)
+                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[2 * p2 + 1], (int)sC[2 * p2], 0x0b0a0908), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[2 * p2 + 1], (int)sR[2 * p2], 0x0b0a0908);
+                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[2 * p2 + 1], (int)sCo[2 * p2], 0x0b0a0908), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[2 * p2 + 1], (int)sRo[2 * p2], 0x0b0a0908);
+                const uint32_t lo2 = bfi(0x55555555u, pC, pR), hi2 = bfi(0x55555555u, pCo, pRo);
+                const uint32_t nib = bfi(0x33333333u, lo2, hi2);
                 if (j & 1) tacc[2 * (j >> 1) + p2] = (int)bfi(0xF0F0F0F0u, nib, (uint32_t)tacc[2 * (j >> 1) + p2]);
-                else tacc[2 * (j >> 1) + p2] = (int)(nib >> 4);
+                else tacc[2 * (j >> 1) + p2] = (int)nib;   // (the high nibbles are the odd column's, written next)
             }
         }
         // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
@@ -514,16 +520,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
             mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : -32768;
 #pragma unroll
             for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
-            {
-                int t[2];
-                for (int h = 0; h < 2; h++) {
-                    const int cell = 8 * l + 6 + h, k16 = cell & 15;
-                    const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
-                    const int art = mult ? max(-32768, mult * gx) : -32768;
-                    t[h] = max(art, max(-32768, (cell + 1) * gx));
-                }
-                mc.vtop3 = pk(t[0], t[1]);
-            }
+            mc.w0 = pk(0, l == 0 ? 0 : ((l & 1) ? max(-32768, 8 * l * gx) : 4 * gx));   // (see MultiConsts)
             const uint64_t tcap64 = bp.trace_stride, bcap64 = bp.blocks_stride;
             const uint32_t tcap = (uint32_t)(tcap64 < 0x7fffffffull ? tcap64 : 0x7fffffffull), bcap = (uint32_t)(bcap64 < 0x7fffffffull ? bcap64 : 0x7fffffffull);
             // ---- slot state (row-uniform, replicated over the slot's lanes)
@@ -612,7 +609,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 // time behind every outstanding memory operation)
                 // (should the allocator keep the column code's per-lane constants in scratch memory after all: reloaded here, before the prefetch
                 // is issued, a reload waits for nothing but the previous step's stores)
-                asm volatile("" : "+v"(mc.laneKG), "+v"(mc.lanem1KG), "+v"(mc.vtop3));
+                asm volatile("" : "+v"(mc.laneKG), "+v"(mc.lanem1KG), "+v"(mc.w0));
                 uint32_t l8;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l8));
                 l8 = (l8 & 15u) * 8u;

@@ -70,11 +70,12 @@ struct SmallConsts {
     int G[4];            // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k (wave-uniform)
     int laneKG;          // l * 8g
     int g8;              // 8g (wave-uniform): (l - 1) * 8g = laneKG - g8
-    // Per cell: max(zero-shift-in artefact of the reference's in-vector scan (avx2.rs:315-338), the MIN = 0 carry above the column). For a
-    // lane's first six cells (registers 0 .. 2) that is G[k] in every lane -- cell c of a 16-cell vector sees a virtual zero at distance
-    // (c & 7) + 1 = 2k + 1 + h, never farther than the carry from above the column --; only the last register (vector cells 6, 7 / 14, 15:
-    // the artefact's 12g, its absence) differs from lane to lane: one per-lane register instead of four.
-    int vtop3;
+    // Per cell the column's R is at least V = max(zero-shift-in artefact of the reference's in-vector scan (avx2.rs:315-338), the MIN = 0 carry above
+    // the column). For a lane's first seven cells that is G[k] in every lane -- cell c of a 16-cell vector sees a virtual zero at distance
+    // (c & 7) + 1, never farther than the carry from above the column --; only the eighth cell (vector cell 7: the artefact's 12g, 15: its absence)
+    // differs from lane to lane. Since max(cs + G, G) = max(cs, 0) + G (saturating adds of non-positive constants compose), the carry from the
+    // lane above is floored ONCE per column -- at {0, W}, V(eighth cell) = W + 8g -- instead of a max with V per register (see MultiConsts::w0).
+    int w0;
 };
 
 // One 8-column shift step for the sixteen slots of a wave (multi_rect for quads). first_cell: this lane holds cell (0, 0) of a pair's
@@ -133,7 +134,7 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
         // R of the lane above's last cell; quad lane 0 has no lane above: a candidate that never wins
         int cin = __builtin_amdgcn_update_dpp(pm, pm, 0x90, 0xf, 0xf, false) + mc.laneKG - mc.g8;
         cin = l == 0 ? -32768 : cin;
-        const int cs = splat_lo(cin);
+        const int cs = vmax(splat_lo(cin), mc.w0);   // (floored: see SmallConsts::w0)
         int dn[4];
 #pragma unroll
         for (int p2 = 0; p2 < 2; p2++) {   // two registers at a time: their trace flags are packed before the next two are touched (fewer values alive)
@@ -141,7 +142,7 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 const int k = 2 * p2 + kk;
-                r[k] = vmax(vmax(r[k], adds(cs, mc.G[k])), k < 3 ? mc.G[k] : mc.vtop3);
+                r[k] = vmax(r[k], adds(k < 3 ? splat_lo(cs) : cs, mc.G[k]));
                 dn[k] = vmax(d11[k], r[k]);
                 if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect)
                     sC[kk] = (uint32_t)subs(cn[k], dn[k]); sR[kk] = (uint32_t)subs(r[k], dn[k]); sCo[kk] = (uint32_t)subs(copen[k], cn[k]); sRo[kk] = (uint32_t)subs(x[k], r[k]);
@@ -150,12 +151,12 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
                 d[k] = dn[k]; c[k] = cn[k];
             }
             if (TRACE) {   // trace words: see multi_rect (4 consecutive cells x 2 columns per word, a lane's eight words contiguous)
-                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[1], (int)sC[0], 0x07050301), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[1], (int)sR[0], 0x07050301);
-                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[1], (int)sCo[0], 0x07050301), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[1], (int)sRo[0], 0x07050301);
-                const uint32_t hi2 = bfi(0x80808080u, pRo, pCo >> 1), lo2 = bfi(0x80808080u, pR, pC >> 1);
-                const uint32_t nib = bfi(0xC0C0C0C0u, hi2, lo2 >> 2);   // bits 7..4 of every byte
+                const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[1], (int)sC[0], 0x0b0a0908), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[1], (int)sR[0], 0x0b0a0908);
+                const uint32_t pCo = (uint32_t)__builtin_amdgcn_perm((int)sCo[1], (int)sCo[0], 0x0b0a0908), pRo = (uint32_t)__builtin_amdgcn_perm((int)sRo[1], (int)sRo[0], 0x0b0a0908);
+                const uint32_t lo2 = bfi(0x55555555u, pC, pR), hi2 = bfi(0x55555555u, pCo, pRo);   // (sign-replicating selectors: clean byte masks, see multi_rect)
+                const uint32_t nib = bfi(0x33333333u, lo2, hi2);        // the nibble in both halves of every byte
                 if (j & 1) tacc[p2] = (int)bfi(0xF0F0F0F0u, nib, (uint32_t)tacc[p2]);
-                else tacc[p2] = (int)(nib >> 4);
+                else tacc[p2] = (int)nib;
             }
         }
         if (FIN) {   // (selects in every step, not under a wave-uniform branch on fin_any: the branch cut the step into a basic block per column,
@@ -381,16 +382,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             mc.laneKG = l * 8 * gx; mc.g8 = 8 * gx;
 #pragma unroll
             for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
-            {
-                int t[2];
-                for (int h = 0; h < 2; h++) {
-                    const int cell = 8 * l + 6 + h, k16 = cell & 15;
-                    const int mult = k16 == 15 ? 0 : (k16 == 7 ? 12 : (k16 & 7) + 1);
-                    const int art = mult ? max(-32768, mult * gx) : -32768;
-                    t[h] = max(art, max(-32768, (cell + 1) * gx));
-                }
-                mc.vtop3 = pk(t[0], t[1]);
-            }
+            mc.w0 = pk(0, l == 0 ? 0 : ((l & 1) ? max(-32768, 8 * l * gx) : 4 * gx));   // (see SmallConsts)
             // ---- slot state (row-uniform, replicated over the slot's lanes)
             const bool live0 = (live_m >> g) & 1u;
             const char* rec = slot_mem + 2 * SM_BUF_BYTES;

@@ -4,7 +4,9 @@ Transcribed directly from /root/reference/src/scan_block.rs (align 847-878, alig
 1083-1228, the Trace stack 1361-1462, cigar_core 1482-1672, blocks 1676-1691) and src/avx2.rs (the 16-lane semantics: saturating adds, the
 prefix scan of 297-338 with its zero shift-in inside 8-lane halves, simd_hargmax 266-274), WITHOUT looking at oracle/ -- so that a
 transcription slip in oracle/block_aligner_oracle.hpp is no longer invisible: tests/test_driver_model.py asserts oracle == model on
-thousands of random pairs with forced grows and shrinks. Sequence-to-sequence alignment only (no profiles).
+thousands of random pairs with forced grows and shrinks. Round 5: sequence-to-profile alignment too (Block::align_profile 942-968,
+place_block_profile_right / _down 612-783 -- two different fill functions with position-specific gap_open_C / gap_close_C / gap_open_R --
+over the AAProfile accessors of src/scores.rs:452-715), again written from the Rust source alone.
 
 Deliberately different in form from the oracle: one numpy column at a time over the whole rectangle height (the 16-lane vectors are rows of
 a [vectors, 16] array), the trace kept as a Python list of per-rectangle cell arrays (restore_ckpt = truncating the list), plain Python
@@ -65,8 +67,11 @@ class Matrix:
     """Scores as Matrix::get_scores yields them (scores.rs:116-127, 199-209, 258-267) from the raw tables of block_aligner_amd.scores."""
 
     def __init__(self, m):
-        self.kind = m.KIND
-        self.raw = np.asarray(m.raw(), np.int64).ravel()
+        if m is None:           # a profile's query: AAProfile::convert_char / NULL (scores.rs:483,647-651) are the amino-acid matrix's
+            self.kind = 0; self.raw = None
+        else:
+            self.kind = m.KIND
+            self.raw = np.asarray(m.raw(), np.int64).ravel()
         self.null = {0: ord("A") + 26, 1: ord("Z"), 2: 0}[self.kind]
 
     def convert(self, b: bytes) -> np.ndarray:   # convert_char: scores.rs:130-134, 212-216, 270-272
@@ -129,6 +134,44 @@ class Model:
         self.stack: list[Rect] = []
         self.ckpt_blocks = 0
         self.cells = 0
+        # place_block serves both directions, the sequences swapped by the caller (scan_block.rs:160-176, 212-228)
+        self._right_fn = lambda *a: self._place(self.q, self.qlen, self.r, self.rlen, *a, True)
+        self._down_fn = lambda *a: self._place(self.r, self.rlen, self.q, self.qlen, *a, False)
+        self._core()
+        return dict(score=self.score, query_idx=self.qi, reference_idx=self.ri, cells=self.cells)
+
+    # ------------------------------------------------------------------ Block::align_profile (scan_block.rs:942-968)
+    def align_profile(self, q: bytes, profile, size, x_drop=0):
+        """profile: block_aligner_amd.scores.AAProfile (only its tables are read: pos_aa[position][residue], the three per-position gap
+        arrays, gap_extend, str_len -- the reference keeps a transposed copy aa_pos for the down fill, scores.rs:455,524-529: same numbers)."""
+        assert profile.get_gap_extend() < 0, "Gap extend cost must be negative!"
+        min_size = max(size[0], L); max_size = max(size[1], L)
+        assert min_size < 65535 and max_size < 65535
+        assert min_size & (min_size - 1) == 0 and max_size & (max_size - 1) == 0
+        if self.X_DROP:
+            assert x_drop >= 0
+        assert not (self.LOCAL and self.FQS) and not (self.X_DROP and self.FQE)
+        assert not self.FQE or min_size > len(q), "Min block size must be larger than the query length for FREE_QUERY_END_GAPS!"
+        self.m = Matrix(None)
+        pad = np.full(max_size, self.m.null_conv(), np.int64)
+        self.q = np.concatenate([[self.m.null_conv()], self.m.convert(q), pad])
+        self.r = None
+        self.qlen, self.rlen = len(q), profile.len()
+        self.P_aa = np.asarray(profile.pos_aa, np.int64)                       # [position][residue 0..31]
+        self.P_goC = np.asarray(profile.pos_gap_open_C, np.int64); self.P_clC = np.asarray(profile.pos_gap_close_C, np.int64)
+        self.P_goR = np.asarray(profile.pos_gap_open_R, np.int64)
+        assert self.P_aa.shape[0] >= self.rlen + max_size + 1, "the profile must be padded for the maximum block size (scores.rs:485)"
+        self.ge = int(profile.get_gap_extend()); self.go = None; self.x_drop = x_drop
+        self.min_size, self.max_size = min_size, max_size
+        z = lambda n: np.full(n, MIN, np.int64)
+        self.D_col, self.C_col, self.D_row, self.R_row = z(max_size), z(max_size), z(max_size), z(max_size)
+        self.ck = [z(max_size) for _ in range(4)]
+        self.temp1, self.temp2 = z(L), z(L)
+        self.stack = []
+        self.ckpt_blocks = 0
+        self.cells = 0
+        self._right_fn = lambda *a: self._place_profile(True, *a)
+        self._down_fn = lambda *a: self._place_profile(False, *a)
         self._core()
         return dict(score=self.score, query_idx=self.qi, reference_idx=self.ri, cells=self.cells)
 
@@ -210,6 +253,74 @@ class Model:
                 break                                                                     # (the rest of the rectangle's trace is never read)
         return D_max, am_i, am_j
 
+    # ------------------------------------------------------------------ place_block_profile_right / _down (scan_block.rs:612-783)
+    def _place_profile(self, right, start_i, start_j, width, height, Dc, Cc, Dr, Rr, corner, rel_zero):
+        """right: vectors along the query, one profile position per column (per-column scalars, scores through the position's row);
+        down: vectors along the profile (per-cell gap vectors with the roles of C and R exchanged, scores of the column's residue)."""
+        ge = self.ge
+        lenv, lenc = (self.qlen, self.rlen) if right else (self.rlen, self.qlen)      # $query.len() / $reference.len() of the instantiation
+        D_max = np.full(L, MIN, np.int64); am_i = np.zeros(L, np.int64); am_j = np.zeros(L, np.int64)
+        if width == 0 or height == 0:
+            return D_max, am_i, am_j
+        nv = height // L
+        gap_all = np.array([(k + 1) * ge for k in range(L)], np.int64)
+        rect = self.stack[-1] if self.TRACE else None
+        row_of_vec = start_i + np.arange(nv) * L
+        rows = start_i + np.arange(height)
+        clC = 0; clR = np.zeros(height, np.int64)                                          # simd_set1_i16(MIN) until assigned (640-643)
+        for j in range(width):
+            if right:                                                                     # 658-663
+                idx = start_j + j
+                goC, clC, goR = int(self.P_goC[idx]), int(self.P_clC[idx]), int(self.P_goR[idx])
+                scores = self.P_aa[idx, self.q[rows] & 31]                                # get_scores_pos: the position's 32-entry row, looked up by residue
+            else:                                                                         # 671-676
+                goC, goR, clR = self.P_goR[rows], self.P_goC[rows], self.P_clC[rows]      # get_gap_open_down_R / _down_C / get_gap_close_down_C
+                scores = self.P_aa[rows, int(self.q[start_j + j])]                        # get_scores_aa: residue c's scores at positions idx ..
+            D10 = Dc[:height].copy(); C10 = Cc[:height]
+            D00 = np.empty(height, np.int64); D00[0] = corner; D00[1:] = D10[:-1]
+            corner = MIN
+            D11 = sat(D00 + scores)
+            if (not self.LOCAL and start_i == 0 and start_j + j == 0) or (self.FQS and right and start_i == 0):
+                D11[0] = rel_zero
+            if self.LOCAL:
+                D11 = np.maximum(D11, rel_zero)
+            C11_open = sat(D10 + sat(goC + ge))                                            # 692
+            C11 = np.maximum(sat(C10 + ge), C11_open)
+            C11_end = sat(C11 + clC) if right else C11                                     # 694
+            D11 = np.maximum(D11, C11_end)
+            D11_open = sat(D11 + goR)                                                      # 698
+            R11 = prefix_scan(D11_open.reshape(nv, L), ge)
+            last = MIN
+            for v in range(nv):
+                R11[v] = np.maximum(R11[v], sat(last + gap_all))
+                last = int(R11[v, L - 1])
+            R11 = R11.reshape(height)
+            R11_end = R11 if right else sat(R11 + clR)                                     # 704
+            D11 = np.maximum(D11, R11_end)
+            if self.TRACE:
+                tR = (R11 == D11_open)
+                tR_prev = np.empty(height, bool); tR_prev[0] = False; tR_prev[1:] = tR[:-1]
+                rect.t[j] = (D11 == C11_end).astype(np.uint8) | ((D11 == R11_end).astype(np.uint8) << 1)
+                rect.t2[j] = (C11 == C11_open).astype(np.uint8) | (tR_prev.astype(np.uint8) << 1)
+                if self.LOCAL:
+                    rect.z[j] = (D11 == rel_zero)
+            d2 = D11.reshape(nv, L)
+            acc = np.maximum.accumulate(np.vstack([D_max[None, :], d2]), axis=0)[1:]
+            track = np.ones(nv, bool) if self.X_DROP else ((row_of_vec + L > lenv) if self.FQE else np.zeros(nv, bool))
+            if track.any():
+                hit = (acc == d2) & track[:, None]
+                for k in range(L):
+                    vs = np.nonzero(hit[:, k])[0]
+                    if vs.size:
+                        am_i[k] = int(vs[-1]) * L; am_j[k] = j
+            D_max = acc[-1].copy()
+            Dc[:height] = D11; Cc[:height] = C11                                           # (C11, not C11_end; R_row takes R11, not R11_end: 763-768)
+            Dr[j] = D11[height - 1]; Rr[j] = R11[height - 1]
+            self.cells += height
+            if not self.X_DROP and not self.FQE and start_i + height > lenv and start_j + j >= lenc:
+                break
+        return D_max, am_i, am_j
+
     def _add_block(self, i, j, w, h, right):
         self.stack.append(Rect(i, j, w, h, right))
 
@@ -235,8 +346,8 @@ class Model:
                 if self.TRACE:
                     self._add_block(si, sj + bs - STEP, STEP, bs, True)
                 self._just_offset(bs, Dc, Cc, off_add)
-                Dm, ai, aj = self._place(self.q, qlen, self.r, rlen, si, sj + bs - STEP, STEP, bs, Dc, Cc, t1, t2,
-                                         int(sat(D_corner + off_add)) if prev_dir == DOWN else MIN, clamp(-off + ZERO), True)
+                Dm, ai, aj = self._right_fn(si, sj + bs - STEP, STEP, bs, Dc, Cc, t1, t2,
+                                            int(sat(D_corner + off_add)) if prev_dir == DOWN else MIN, clamp(-off + ZERO))
                 right_max = self._prefix_max(Dc)
                 D_corner = self._shift_and_offset(bs, Dr, Rr, t1, t2, off_add)
                 down_max = self._prefix_max(Dr)
@@ -246,8 +357,8 @@ class Model:
                 if self.TRACE:
                     self._add_block(si + bs - STEP, sj, bs, STEP, False)
                 self._just_offset(bs, Dr, Rr, off_add)
-                Dm, ai, aj = self._place(self.r, rlen, self.q, qlen, sj, si + bs - STEP, STEP, bs, Dr, Rr, t1, t2,
-                                         int(sat(D_corner + off_add)) if prev_dir == RIGHT else MIN, clamp(-off + ZERO), False)
+                Dm, ai, aj = self._down_fn(sj, si + bs - STEP, STEP, bs, Dr, Rr, t1, t2,
+                                           int(sat(D_corner + off_add)) if prev_dir == RIGHT else MIN, clamp(-off + ZERO))
                 down_max = self._prefix_max(Dr)
                 D_corner = self._shift_and_offset(bs, Dc, Cc, t1, t2, off_add)
                 right_max = self._prefix_max(Dc)
@@ -256,12 +367,12 @@ class Model:
                 grow_step = bs - prev_size
                 if self.TRACE:
                     self._add_block(si + prev_size, sj, prev_size, grow_step, False)
-                g_max, g_ai, g_aj = self._place(self.r, rlen, self.q, qlen, sj, si + prev_size, grow_step, prev_size, Dr, Rr,
-                                                Dc[prev_size:], Cc[prev_size:], MIN, clamp(-off + ZERO), False)
+                g_max, g_ai, g_aj = self._down_fn(sj, si + prev_size, grow_step, prev_size, Dr, Rr,
+                                                  Dc[prev_size:], Cc[prev_size:], MIN, clamp(-off + ZERO))
                 if self.TRACE:
                     self._add_block(si, sj + prev_size, grow_step, bs, True)
-                Dm, ai, aj = self._place(self.q, qlen, self.r, rlen, si, sj + prev_size, grow_step, bs, Dc, Cc,
-                                         Dr[prev_size:], Rr[prev_size:], MIN, clamp(-off + ZERO), True)
+                Dm, ai, aj = self._right_fn(si, sj + prev_size, grow_step, bs, Dc, Cc,
+                                            Dr[prev_size:], Rr[prev_size:], MIN, clamp(-off + ZERO))
                 right_max = self._prefix_max(Dc); down_max = self._prefix_max(Dr)
                 for a, b in zip(self.ck, (Dc, Cc, Dr, Rr)):
                     a[:bs] = b[:bs]

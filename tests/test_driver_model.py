@@ -1,6 +1,7 @@
 """oracle == tests/driver_model.py (a second, independent transcription of scan_block.rs / avx2.rs: see its docstring) on random pairs
 with forced grows, checkpoint restores, shrinks and X-drop termination after growth, at (16, 64), (32, 256), (128, 1024) and fixed sizes,
-all mode bits, three matrix kinds: score, end indices, computed cells, both CIGAR forms from the end position, Trace::blocks().
+all mode bits, three matrix kinds: score, end indices, computed cells, both CIGAR forms from the end position, Trace::blocks(); and -- round 5 --
+on random sequence-to-PSSM pairs with position-specific gap costs (place_block_profile_right / _down), same quantities.
 What this pins and what it does not: two readings of the Rust source by the same builder agree cell for cell; the crate itself is pinned
 by the reference-held known answers (tests/golden/reference_kats.json) and -- once somebody runs rust/examples/dump_golden.rs -- by
 tests/test_crate_golden.py."""
@@ -92,19 +93,102 @@ def test_oracle_equals_the_independent_model(kind, sizes, total):
     assert ran >= total * 9 // 10 and grew >= ran // 4, (ran, grew)
 
 
+AA20 = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+
+
+def make_profile_case(rng, size, mode):
+    """examples/pssm_bench.rs:43-98 shaped -- PSSM rows = BLOSUM62 rows of a random consensus -- with position-specific gap_open_C /
+    gap_close_C / gap_open_R (scan_block.rs:658-676), long insertions / deletions in the query (grow, checkpoint restore, shrink) and
+    unrelated tails (X-drop termination after growth); now and then uniform costs, a position without any cost set (the -128 defaults) and
+    scores shifted as set_all does."""
+    n = int(rng.integers(0, 40)) if rng.random() < 0.1 else int(rng.integers(30, 700))
+    cons = AA20[rng.integers(0, 20, n)]
+    ge = int(rng.integers(-3, 0))
+    p = S.AAProfile(n, size[1], ge)
+    b62 = S.static_matrix("BLOSUM62")
+    for i, c in enumerate(cons):
+        for b in AA20:
+            p.set(i + 1, int(b), b62.get(int(c), int(b)))
+    uniform = rng.random() < 0.2
+    for i in range(n + 1):
+        p.set_gap_open_C(i, -10 if uniform else int(rng.integers(-14, -3)))
+        p.set_gap_open_R(i, -10 if uniform else int(rng.integers(-14, -3)))
+        if i >= 1 or rng.random() < 0.5:
+            p.set_gap_close_C(i, 0 if uniform else int(rng.integers(-4, 1)))
+    q = synth.mutate(rng, cons, int(rng.uniform(0, 0.35) * n), AA20) if n else cons
+    if len(q) > 120 and rng.random() < 0.7:
+        at = int(rng.integers(20, len(q) - 20)); ln = int(rng.integers(8, min(250, 3 * size[1])))
+        q = np.concatenate([q[:at], synth.rand_str(rng, ln, AA20), q[at:]]) if rng.random() < 0.5 else np.concatenate([q[:at], q[at + ln:]])
+    if rng.random() < 0.4:
+        q = np.concatenate([q, synth.rand_str(rng, int(rng.integers(0, 150)), AA20)])
+    if "free_query_end_gaps" in mode:
+        k = int(rng.integers(0, max(size[0], 16)))
+        at = int(rng.integers(0, max(1, len(q) - k)))
+        q = q[at: at + k]
+    return q.astype(np.uint8).tobytes(), p
+
+
+def run_profile_chunk(args):
+    seed, count, sizes = args
+    from oracle.oracle_py import Oracle
+    from tests.driver_model import Model
+    oracle = Oracle("avx2")
+    rng = np.random.default_rng(seed)
+    bad, grew, ran = [], 0, 0
+    for c in range(count):
+        size = sizes[c % len(sizes)]
+        mode = MODES[int(rng.integers(0, len(MODES)))]
+        q, p = make_profile_case(rng, size, mode)
+        xd = int(rng.integers(10, 120)) if "x_drop" in mode else 0
+        try:
+            ref = oracle.align_profile(q, p, size, xd, mode)
+        except RuntimeError:
+            continue   # (an end position in the padding: Trace::cigar asserts -- the crate would panic too)
+        m = Model(**{k: True for k in mode})
+        got = m.align_profile(q, p, size, xd)
+        ran += 1
+        grew += m.end_block_size > max(size[0], 16) or len(m.blocks()) > (len(q) + p.str_len) // 8 + 6
+        what = []
+        for k in ("score", "query_idx", "reference_idx", "cells"):
+            if got[k] != ref[k]:
+                what.append((k, got[k], ref[k]))
+        if m.end_block_size != ref["end_block_size"]:
+            what.append(("end_block_size", m.end_block_size, ref["end_block_size"]))
+        if "trace" in mode and not what and m.cigar(got["query_idx"], got["reference_idx"]) != ref["cigar"]:
+            what.append(("cigar",))
+        if what:
+            bad.append((seed, c, size, mode, len(q), p.str_len, what))
+    return ran, grew, bad
+
+
+@pytest.mark.parametrize("sizes,total", [([(16, 64), (32, 256), (16, 16), (32, 32), (32, 128)], 640), ([(128, 1024), (64, 512)], 96)])
+def test_oracle_equals_the_independent_model_on_profiles(sizes, total):
+    """Sequence-to-profile alignment: the oracle against the model's own reading of place_block_profile_right / _down."""
+    workers = 8
+    per = total // workers
+    with mp.get_context("fork").Pool(workers) as pool:
+        out = pool.map(run_profile_chunk, [(7000 + 29 * w + total, per, sizes) for w in range(workers)])
+    ran = sum(o[0] for o in out); grew = sum(o[1] for o in out); bad = [b for o in out for b in o[2]]
+    assert not bad, bad[:5]
+    assert ran >= total * 9 // 10 and grew >= ran // 5, (ran, grew)
+
+
 def test_model_passes_the_reference_known_answers(kats):
     """The model against the reference-held vectors themselves (the alignment KATs of scan_block.rs:1908-2230 that use two sequences)."""
-    from tests.common import kat_matrix
+    from tests.common import kat_matrix, kat_profile
     from tests.driver_model import Model
     from tests.driver_model import prefix_scan
     for k in kats["lane"]:   # avx2.rs:469-489
         assert list(prefix_scan(np.array(k["input"], np.int64), k["gap"])) == k["expect"], k["name"]
     n = 0
+    n_prof = 0
     for k in kats["align"] + kats["inferred"]:
-        if k["kind"] == "profile":
-            continue
         m = Model(**{x: True for x in k["mode"]})
-        got = m.align(k["q"].encode(), k["r"].encode(), kat_matrix(k), tuple(k["gaps"]), tuple(k["size"]), k.get("x_drop", 0))
+        if k["kind"] == "profile":   # scan_block.rs:2123-2168
+            got = m.align_profile(k["q"].encode(), kat_profile(k), tuple(k["size"]), k.get("x_drop", 0))
+            n_prof += 1
+        else:
+            got = m.align(k["q"].encode(), k["r"].encode(), kat_matrix(k), tuple(k["gaps"]), tuple(k["size"]), k.get("x_drop", 0))
         e = k["expect"]
         assert got["score"] == e["score"], (k["name"], got, e)
         for f in ("query_idx", "reference_idx"):
@@ -115,4 +199,4 @@ def test_model_passes_the_reference_known_answers(kats):
         if "cigar_eq" in e:
             assert m.cigar(got["query_idx"], got["reference_idx"], eq=True) == e["cigar_eq"], k["name"]
         n += 1
-    assert n >= 30
+    assert n >= 36 and n_prof == 6
