@@ -60,3 +60,52 @@ def global_score_profile(q: bytes, profile, gap_open: int) -> int:
     rows = profile.pos_aa[1: profile.str_len + 1].astype(np.int64)      # [position][residue]
     e = int(profile.gap_extend)
     return _gotoh_rows(lambda i: rows[:, qa[i]], len(qa), profile.str_len, int(gap_open) + e, e)
+
+
+def global_score_profile_pos(q: bytes, profile) -> int:
+    """Optimal global score of q against a PSSM with POSITION-SPECIFIC gap costs, by the definition the sequence-to-profile recurrence of
+    /root/reference/src/scan_block.rs:658-706 states for its `right` orientation (vectors along the query, one profile position per column)
+    -- the orientation that fills the whole matrix when one block covers it (the first step is a grow from size 0: an empty down
+    rectangle, then one right rectangle, scan_block.rs:247-305):
+      a gap that consumes profile positions j .. j + n - 1 (CIGAR D) costs gap_open_C[j] + n * gap_extend + gap_close_C[j + n - 1];
+      a gap that consumes n query residues between profile positions j and j + 1 (CIGAR I) costs gap_open_R[j] + n * gap_extend.
+    Written from that definition as a full-matrix DP, one profile column at a time; no oracle/, no reference code."""
+    qa = _upper(np.frombuffer(q, np.uint8)) - 65
+    nq, nr = len(qa), profile.str_len
+    sc = profile.pos_aa.astype(np.int64)                                  # [position][residue]
+    goC, clC, goR = (np.asarray(x, np.int64) for x in (profile.pos_gap_open_C, profile.pos_gap_close_C, profile.pos_gap_open_R))
+    e = int(profile.gap_extend)
+    i = np.arange(nq + 1, dtype=np.int64)
+    D = np.empty(nq + 1, np.int64)
+    D[0] = 0
+    D[1:] = goR[0] + i[1:] * e                                            # column 0: one gap over the query's first i residues
+    C = np.full(nq + 1, NEG, np.int64)                                    # best score ending in a gap over profile positions, before its close cost
+    for j in range(1, nr + 1):
+        C = np.maximum(C + e, D + goC[j] + e)
+        T = C + clC[j]
+        if nq:
+            T[1:] = np.maximum(T[1:], D[:-1] + sc[j, qa])
+        pm = np.maximum.accumulate(T - i * e)                              # gaps over query residues inside column j
+        Dn = T.copy()
+        if nq:
+            Dn[1:] = np.maximum(T[1:], pm[:-1] + goR[j] + i[1:] * e)
+        D = Dn
+    return int(D[nq])
+
+
+def rescore_profile_cigar(runs, q: bytes, profile) -> tuple[int, int, int]:
+    """(score, query residues, profile positions) of the path a CIGAR spells out from the origin, by the same definition."""
+    qa = _upper(np.frombuffer(q, np.uint8)) - 65
+    e = int(profile.gap_extend)
+    i = j = 0
+    total = 0
+    for x in np.asarray(runs, np.int64):
+        op, n = int(x) & 15, int(x) >> 4
+        if op in (1, 2, 3):
+            for _ in range(n):
+                total += int(profile.pos_aa[j + 1, qa[i]]); i += 1; j += 1
+        elif op == 4:      # I: query residues against no profile position (between positions j and j + 1)
+            total += int(profile.pos_gap_open_R[j]) + n * e; i += n
+        else:              # D: profile positions j + 1 .. j + n against no residue
+            total += int(profile.pos_gap_open_C[j + 1]) + n * e + int(profile.pos_gap_close_C[j + n]); j += n
+    return total, i, j

@@ -116,8 +116,8 @@ def make_profile_case(rng, size, mode):
         if i >= 1 or rng.random() < 0.5:
             p.set_gap_close_C(i, 0 if uniform else int(rng.integers(-4, 1)))
     q = synth.mutate(rng, cons, int(rng.uniform(0, 0.35) * n), AA20) if n else cons
-    if len(q) > 120 and rng.random() < 0.7:
-        at = int(rng.integers(20, len(q) - 20)); ln = int(rng.integers(8, min(250, 3 * size[1])))
+    if len(q) > 60 and rng.random() < 0.85:
+        at = int(rng.integers(20, len(q) - 20)); ln = int(rng.integers(max(8, size[0] // 2), min(250, 3 * size[1])))
         q = np.concatenate([q[:at], synth.rand_str(rng, ln, AA20), q[at:]]) if rng.random() < 0.5 else np.concatenate([q[:at], q[at + ln:]])
     if rng.random() < 0.4:
         q = np.concatenate([q, synth.rand_str(rng, int(rng.integers(0, 150)), AA20)])
@@ -170,7 +170,7 @@ def test_oracle_equals_the_independent_model_on_profiles(sizes, total):
         out = pool.map(run_profile_chunk, [(7000 + 29 * w + total, per, sizes) for w in range(workers)])
     ran = sum(o[0] for o in out); grew = sum(o[1] for o in out); bad = [b for o in out for b in o[2]]
     assert not bad, bad[:5]
-    assert ran >= total * 9 // 10 and grew >= ran // 5, (ran, grew)
+    assert ran >= total * 9 // 10 and grew >= ran // 6, (ran, grew)
 
 
 def test_model_passes_the_reference_known_answers(kats):

@@ -77,6 +77,35 @@ def test_oracle_profile_full_block_equals_full_dp(oracle):
         assert res["score"] == global_score_profile(q, p, go), (it, L, len(q))
 
 
+def pos_profile_case(rng, B):
+    """A PSSM with position-specific gap_open_C / gap_close_C / gap_open_R (and sometimes gap_extend below -1) that fits one block."""
+    L = int(rng.integers(1, B - 1))
+    aa = np.frombuffer(AA20, np.uint8)
+    cons = aa[rng.integers(0, 20, L)]
+    p = S.AAProfile(L, B, int(rng.integers(-2, 0)))
+    for i, c in enumerate(cons):
+        for a in aa:
+            p.set(i + 1, int(a), S.BLOSUM62.get(int(c), int(a)))
+    for i in range(L + 1):
+        p.set_gap_open_C(i, int(rng.integers(-14, -3))); p.set_gap_open_R(i, int(rng.integers(-14, -3))); p.set_gap_close_C(i, int(rng.integers(-4, 1)))
+    q = synth.mutate(rng, cons, L // 3, aa).astype(np.uint8).tobytes()[: B - 1]
+    return q, p
+
+
+def test_full_block_profile_with_position_specific_gaps(oracle):
+    """Non-uniform PSSM gap costs (scan_block.rs:658-706): with the block covering the matrix the oracle's global score equals the
+    from-scratch DP of tests/gotoh.py global_score_profile_pos, and its CIGAR re-scores to it by the same definition."""
+    from tests.gotoh import global_score_profile_pos, rescore_profile_cigar
+    rng = np.random.default_rng(31)
+    for B in (16, 32, 64, 256, 1024):
+        for it in range(30 if B <= 256 else 8):
+            q, p = pos_profile_case(rng, B)
+            res = oracle.align_profile(q, p, (B, B), 0, ("trace",))
+            want = global_score_profile_pos(q, p)
+            assert res["score"] == want, (B, it, len(q), p.str_len, res["score"], want)
+            assert rescore_profile_cigar(parse_cigar(res["cigar"]), q, p) == (want, len(q), p.str_len), (B, it)
+
+
 MODES = [("trace",), ("trace", "x_drop"), ("trace", "local_start"), ("trace", "local_start", "x_drop"), ("trace", "free_query_start_gaps")]
 
 

@@ -85,6 +85,30 @@ def test_full_block_profile_score_is_the_exact_optimum(hip, B):
     b.close()
 
 
+@pytest.mark.parametrize("B", [16, 32, 64, 256, 1024])
+def test_full_block_profile_with_position_specific_gaps(hip, B):
+    """Non-uniform PSSMs -- every position its own gap_open_C / gap_close_C / gap_open_R (scan_block.rs:658-706) -- at block sizes that cover
+    the matrix: the HIP global score equals the from-scratch DP (tests/gotoh.py global_score_profile_pos) and the HIP CIGAR is a path from
+    the origin to (|q|, |p|) that re-scores to it by the same definition. No oracle involved."""
+    from tests.gotoh import global_score_profile_pos, rescore_profile_cigar
+    from tests.test_gotoh import pos_profile_case
+    rng = np.random.default_rng(70 + B)
+    cases = [pos_profile_case(rng, B) for _ in range(32 if B <= 256 else 10)]
+    pool = np.frombuffer(b"".join(q for q, _ in cases) + b"\0" * 8, np.uint8)
+    q_len = np.array([len(q) for q, _ in cases], np.uint32)
+    q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.uint64)
+    b = hip.ProfileBatchAligner([p for _, p in cases], (B, B), 0, hip.TRACE, pool, q_off, q_len)
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"])
+    for k, (q, p) in enumerate(cases):
+        want = global_score_profile_pos(q, p)
+        assert int(res["score"][k]) == want, (B, k, len(q), p.str_len, int(res["score"][k]), want)
+        assert rescore_profile_cigar(runs[int(off[k]): int(off[k + 1])], q, p) == (want, len(q), p.str_len), (B, k)
+    b.close()
+
+
 def test_config3_cigars_rescore(hip):
     """Config-3 shaped pairs (10 kbp, X-drop, block 128..1024 incl. the closing grow sequence): every HIP CIGAR is a valid
     path from the origin to the HIP end position that re-scores to the HIP score."""
