@@ -220,15 +220,32 @@ struct FqeOut { int M; int j; };   // FREE_QUERY_END_GAPS: D_max / argmax_j of v
 
 // per-chunk substitution-score lookup state, set up once per rectangle from the chunk's two vector-axis bytes
 template <int KIND> struct ScoreKey;
-template <> struct ScoreKey<KIND_NUC> { int off; };          // byte offset of the (a, b) pair inside one 1 KB table row
+template <> struct ScoreKey<KIND_NUC> { int off; };          // byte offset of the (a, b) pair's entries in the packed-pair table (nuc_key_off)
 template <> struct ScoreKey<KIND_AA> { int a, b; };          // column indices (0..31)
 template <> struct ScoreKey<KIND_BYTES> { int a, b; };       // raw bytes
 template <> struct ScoreKey<KIND_PROFILE> { int a, b; };     // query residues (0..31), used by right rectangles only
 
+// The NUC packed-pair table (8 KB of LDS per workgroup): entry (a, b, c) = {score(c, a), score(c, b)} for a lane's two vector-axis bytes (a & 15,
+// b & 15) and a column byte (c & 7), scores.rs:157,196,204-209, at byte offset ((a << 4 | b) << 5) + (c << 2): the column's term is byte-sized, so
+// the multi-pair kernels add it by SDWA byte select (eight columns from two registers, one instruction per score address).
+// (Tried in round 5: a bit permutation of the address chosen for the LDS banks -- the letters that matter are 1, 3, 4, 7, which row-major orders
+// fold onto a few banks: SQ_LDS_BANK_CONFLICT per 50 k-pair launch 8.5 G cycles for [c][a][b], 14.4 G for this order, 2.9 G for the permutation --
+// and config 3 took 169.9 ms with it against 165.9: the fill is bound by vector issue, the conflicts cost nothing, the longer key computation does.)
+BA_HD constexpr uint32_t nuc_key_off(uint32_t a, uint32_t b) { return (((a & 15u) << 4) | (b & 15u)) << 5; }
+constexpr uint32_t NUC_GAM_LO = 0x0C080400u, NUC_GAM_HI = 0x1C181410u;   // byte c & 7 -> (c & 7) * 4
+BA_HD constexpr uint32_t nuc_col_off(uint32_t c) { return (uint32_t)(((((unsigned long long)NUC_GAM_HI << 32) | NUC_GAM_LO) >> ((c & 7u) * 8u)) & 0xffu); }
+// every kernel fills its workgroup's table with this
+__device__ __forceinline__ void nuc_table_fill(char* tab, const int8_t* matrix, int tid, int nthreads) {
+    for (int e = tid; e < 8 * 16 * 16; e += nthreads) {
+        const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
+        *(int*)(tab + nuc_key_off((uint32_t)a, (uint32_t)b) + nuc_col_off((uint32_t)crow)) = (matrix[crow * 16 + a] & 0xffff) | (int)((uint32_t)matrix[crow * 16 + b] << 16);
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ ScoreKey<KIND> make_key(int a, int b) {
     ScoreKey<KIND> k;
-    if constexpr (KIND == KIND_NUC) k.off = (((a & 15) << 4) | (b & 15)) << 2;
+    if constexpr (KIND == KIND_NUC) k.off = (int)nuc_key_off((uint32_t)a, (uint32_t)b);
     else if constexpr (KIND == KIND_AA || KIND == KIND_PROFILE) { k.a = a & 31; k.b = b & 31; }
     else { k.a = a; k.b = b; }
     return k;
@@ -236,7 +253,7 @@ __device__ __forceinline__ ScoreKey<KIND> make_key(int a, int b) {
 // packed {score(cb, a), score(cb, b)} for column byte cb (scores.rs:121-127, 204-209, 263-267)
 template <int KIND>
 __device__ __forceinline__ int fetch_score(const char* table, const ScoreKey<KIND>& k, int cb) {
-    if constexpr (KIND == KIND_NUC) return *(const int*)(table + ((cb & 7) << 10) + k.off);
+    if constexpr (KIND == KIND_NUC) return *(const int*)(table + nuc_col_off((uint32_t)cb) + k.off);
     else if constexpr (KIND == KIND_AA) {
         const signed char* row = (const signed char*)table + cb * 32;
         return pk(row[k.a], row[k.b]);
@@ -245,6 +262,31 @@ __device__ __forceinline__ int fetch_score(const char* table, const ScoreKey<KIN
         return pk(k.a == cb ? t[0] : t[1], k.b == cb ? t[0] : t[1]);
     } else return 0;   // PROFILE: scores come from the profile image, see profile_score
 }
+// NUC, multi-pair kernels: the step's eight column bytes become eight table offsets (nuc_col_off, a byte each) with two operations per four columns
+// (v_perm looks the bytes up in an 8-entry table), the lane's four key offsets come from its eight bytes two at a time (both halves of a register
+// at once), and every score address is ONE instruction: the pair's base (table + key, per step) plus byte j
+__device__ __forceinline__ uint32_t nuc_col_offsets(uint32_t cb4) { return (uint32_t)__builtin_amdgcn_perm((int)NUC_GAM_HI, (int)NUC_GAM_LO, (int)(cb4 & 0x07070707u)); }
+__device__ __forceinline__ uint32_t nuc_keys2(uint32_t w) {   // w = {a, b, a', b'} bytes -> {nuc_key_off(a, b), nuc_key_off(a', b')} as 16-bit halves
+    return ((w << 9) & 0x1E001E00u) | ((w >> 3) & 0x01E001E0u);
+}
+__device__ __forceinline__ uint32_t add_word(uint32_t packed, uint32_t base, int which) {
+    uint32_t r;
+    if (which & 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "v"(packed), "v"(base));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(packed), "v"(base));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_byte(uint32_t packed, uint32_t base, int which) {
+    uint32_t r;
+    switch (which & 3) {
+    case 0: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(packed), "v"(base)); break;
+    case 1: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(packed), "v"(base)); break;
+    case 2: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(packed), "v"(base)); break;
+    default: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(packed), "v"(base)); break;
+    }
+    return r;
+}
+typedef const __attribute__((address_space(3))) int* lds_cint_ptr;
+__device__ __forceinline__ int lds_read_i32(uint32_t addr) { return *(lds_cint_ptr)(uintptr_t)addr; }   // (addr: the 32-bit LDS address, e.g. the low word of a generic pointer into LDS)
 // unaligned (2-byte aligned) load of two consecutive i16
 __device__ __forceinline__ int load_pair_i16(const short* p) { int v; __builtin_memcpy(&v, p, 4); return v; }
 

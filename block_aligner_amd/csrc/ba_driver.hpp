@@ -1330,9 +1330,11 @@ struct Aligner {
             }
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
             BA_TSTAMP(tsa);
-            const bool fast = !kBig && KIND != KIND_PROFILE && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
+            // (plain: a shift step of a single-chunk block that cannot break early -- what the register path and a slot of the multi-pair kernels take)
+            const bool plain = !kBig && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
+            const bool fast = plain && KIND != KIND_PROFILE;
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
-            if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && fast && !forced && block_size == SLOT_B && min_size == SLOT_B && !chain && !no_spec) {
+            if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && plain && !forced && block_size == SLOT_B && min_size == SLOT_B && !chain && !no_spec) {
                 // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
                 // four pairs to a wave. The borders are in LDS (cell order); the checkpoint follows them at entries MQ_B .. 2 MQ_B.
                 step_budget++;   // (the step this iteration counted has not been taken)
@@ -1601,12 +1603,13 @@ struct Aligner {
 #endif
         if (TRACE && XDROP && chain && coldp()->prof) {
             // The speculative (untraced) rectangles left on the stack: cells that needed neither trace flags nor location bookkeeping. Their
-            // sum goes to a counter of the launch (bench.py's ops_required); they sit among the last records of the stack (the chain of grows
-            // that closed the alignment and the shift steps between them). Records read past the L1: this wave's own stores.
+            // sum goes to a counter of the launch (bench.py's ops_required); they all sit behind the record count of the chain's base checkpoint
+            // (ub_nb: the chain of grows that closed the alignment and the shift steps between them -- however many). Records read past the L1:
+            // this wave's own stores.
             uint32_t sc = 0;
-            const uint32_t nscan = nblocks < 512u ? nblocks : 512u;   // (`min` is this function's state parameter)
-            for (uint32_t k = (uint32_t)lane_id(); k < nscan; k += 64u) {
-                const uint32_t* rp = (const uint32_t*)(blocks + (nblocks - 1u - k));
+            const uint32_t first = ub_nb < nblocks ? ub_nb : nblocks;
+            for (uint32_t k = first + (uint32_t)lane_id(); k < nblocks; k += 64u) {
+                const uint32_t* rp = (const uint32_t*)(blocks + k);
                 const uint32_t hw = __hip_atomic_load(rp + 2, BA_RLX_AGENT), tb = __hip_atomic_load(rp + 3, BA_RLX_AGENT);
                 if (tb & 0x40000000u) sc += (hw & 0xffffu) * (hw >> 16);
             }
@@ -1703,6 +1706,30 @@ struct Aligner {
                 if constexpr (KIND != KIND_PROFILE) {
                     if (cright) fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
                     else fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
+                } else {
+                    // sequence-to-profile: the step through the generic rectangle code, on the LDS borders the checkpoint was just written to
+                    // (place_block_profile_right / _down + shift_and_offset, scan_block.rs:147-246); then the borders back into registers
+                    const uint32_t pq_len = coldp()->q_len[pair_in], pr_len = coldp()->r_len[pair_in];
+                    ProfileView pvv{};
+                    pvv.P = profile_positions(pr_len, h_max_size);
+                    pvv.pos_aa = (const signed char*)r;
+                    pvv.aa_pos = (const short*)(r + (uint64_t)pvv.P * 32);
+                    pvv.goC = pvv.aa_pos + (uint64_t)pvv.P * 32; pvv.clC = pvv.goC + pvv.P; pvv.goR = pvv.clC + pvv.P;
+                    short* t1 = L.misc + 16; short* t2 = L.misc + 32;
+                    lds_fill0(t1, 32);
+                    unsigned long long none = 0;
+                    Best cur;
+                    if (cright) {
+                        cur = place_rect<1, KIND, false, XDROP, 1>(L, fc, q, r, pq_len, pr_len, cri, crj, STEP, SLOT_B, L.D_col, L.C_col, t1, t2, ck_corner, 0, ck_offadd, nullptr, none, nullptr, 0u, nullptr, &pvv);
+                        (void)lds_shift_and_offset(SLOT_B, L.D_row, L.R_row, t1, t2, ck_offadd);
+                    } else {
+                        cur = place_rect<1, KIND, false, XDROP, 2>(L, fc, r, q, pr_len, pq_len, cri, crj, STEP, SLOT_B, L.D_row, L.R_row, t1, t2, ck_corner, 0, ck_offadd, nullptr, none, nullptr, 0u, nullptr, &pvv);
+                        (void)lds_shift_and_offset(SLOT_B, L.D_col, L.C_col, t1, t2, ck_offadd);
+                    }
+                    fo.row = cur.row; fo.col = cur.col;
+                    lds_sync();
+                    cDc = *(const int*)(L.D_col + 2 * lane); cCc = *(const int*)(L.C_col + 2 * lane);
+                    cDr = *(const int*)(L.D_row + 2 * lane); cRr = *(const int*)(L.R_row + 2 * lane);
                 }
                 if (XDROP) {
                     if (cright) { best_i = ck_i + (uint32_t)fo.row; best_j = ck_j + (SLOT_B - STEP) + (uint32_t)fo.col; }
@@ -1735,11 +1762,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
     {
         char* tab = smem;
         if (KIND == KIND_NUC) {
-            // T[crow][a][b] = packed {score(crow, a), score(crow, b)}: one 4-byte read yields both cells of a lane
-            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
-                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
-                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
-            }
+            // packed {score(crow, a), score(crow, b)} per (a, b, crow): one 4-byte read yields both cells of a lane
+            nuc_table_fill(tab, bp.matrix, (int)threadIdx.x, WAVES_PER_WG * 64);   // (layout: ba_device.hpp nuc_key_off)
         } else {
             const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_BYTES ? 2 : 0);   // PROFILE: scores live in the pair's image
             for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -68,16 +69,16 @@ BA_DECL_M_KIND(0) BA_DECL_M_KIND(1) BA_DECL_M_KIND(2)
 #define BA_MOROW(K) {ba_occupancy_m_k##K##_p1, ba_occupancy_m_k##K##_p2, ba_occupancy_m_k##K##_p4, ba_occupancy_m_k##K##_p8, ba_occupancy_m_k##K##_p16}
 static const LaunchFn g_launch_m[3][5] = {BA_MROW(0), BA_MROW(1), BA_MROW(2)};
 static const OccFn g_occ_m[3][5] = {BA_MOROW(0), BA_MOROW(1), BA_MOROW(2)};
-// k_small (ba_small.hpp): sixteen pairs per wave at 32 cells; sequence kinds, block classes up to 1024 cells
+// k_small (ba_small.hpp): sixteen pairs per wave at 32 cells; all four kinds (round 5: sequence-to-profile slots), block classes up to 1024 cells
 #define BA_DECL_SM(K, P)                                                                                              \
     extern "C" hipError_t ba_launch_sm_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
     extern "C" hipError_t ba_occupancy_sm_k##K##_p##P(int, int, unsigned, int*);
 #define BA_DECL_SM_KIND(K) BA_DECL_SM(K, 1) BA_DECL_SM(K, 2) BA_DECL_SM(K, 4) BA_DECL_SM(K, 8)
-BA_DECL_SM_KIND(0) BA_DECL_SM_KIND(1) BA_DECL_SM_KIND(2)
+BA_DECL_SM_KIND(0) BA_DECL_SM_KIND(1) BA_DECL_SM_KIND(2) BA_DECL_SM_KIND(3)
 #define BA_SMROW(K) {ba_launch_sm_k##K##_p1, ba_launch_sm_k##K##_p2, ba_launch_sm_k##K##_p4, ba_launch_sm_k##K##_p8}
 #define BA_SMOROW(K) {ba_occupancy_sm_k##K##_p1, ba_occupancy_sm_k##K##_p2, ba_occupancy_sm_k##K##_p4, ba_occupancy_sm_k##K##_p8}
-static const LaunchFn g_launch_sm[3][4] = {BA_SMROW(0), BA_SMROW(1), BA_SMROW(2)};
-static const OccFn g_occ_sm[3][4] = {BA_SMOROW(0), BA_SMOROW(1), BA_SMOROW(2)};
+static const LaunchFn g_launch_sm[4][4] = {BA_SMROW(0), BA_SMROW(1), BA_SMROW(2), BA_SMROW(3)};
+static const OccFn g_occ_sm[4][4] = {BA_SMOROW(0), BA_SMOROW(1), BA_SMOROW(2), BA_SMOROW(3)};
 extern "C" hipError_t ba_launch_walk_l2(hipStream_t, const BatchParams*, uint32_t grid);
 typedef hipError_t (*QuadFn)(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k0(int, int, unsigned, hipStream_t, const BatchParams*);
@@ -603,6 +604,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         if (max_waves < ba::WAVES_PER_WG) { fail("device memory: one workgroup's trace slots need %llu MB, %llu MB are free", (unsigned long long)(per_slot * ba::WAVES_PER_WG >> 20), (unsigned long long)(budget >> 20)); return 1; }
         if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
     }
+    if (b->small) grid = std::min<uint64_t>(grid, 512ull * 32 / ba::WAVES_PER_WG);   // (the trace arena's sink area holds 512 x 32 waves: pipe_regions)
     b->grid = (uint32_t)grid;
     b->cq_grid = 0;
     if (b->quad) {   // the per-pair kernel beside k_quad: one workgroup per CU, so that k_quad always finds room next to it
@@ -621,6 +623,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
         b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
         if (b->small) b->work_chunk = 4;   // (sixteen slots refill one by one; pairs come longest first: a long chunk would queue the longest pairs on one wave)
+        if (const char* env = dev_env("BA_WORK_CHUNK")) { int v = atoi(env); if (v > 0) b->work_chunk = (uint32_t)v; }   // (development)
     }
     // Few pairs: while the batch gives a resident wave no more than about two pairs, the wave walks each path itself with all its lanes
     // (walk_wave: ~0.2 - 0.35 us per cell) instead of handing it to a traceback lane (64 walks in lockstep: 0.55 - 0.9 us per cell, the
@@ -782,8 +785,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // round-3 pipeline / per-pair kernel): 1 kbp DNA X-drop 40 k pairs 941 / 963 / 580, 80 k 1356 / 1154 / 622; with traceback 40 k 512 / 580 /
     // 348, 80 k 791 / 742 / 393; protein pairs 30 k 388 / 303 / 369, 70 k 792 / 651 / 519; with traceback 70 k 258 / 283 / 210, 150 k 487 / 441 /
     // 216. Below them the round-3 rules apply.
-    const size_t small_from = kind == BA_KIND_AA ? (trace_mode ? 98304u : 32768u) : (trace_mode ? 57344u : 49152u);
-    b->small = !profile && !special_of(mode) && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
+    size_t small_from = kind == BA_KIND_AA ? (trace_mode ? 98304u : 32768u) : (trace_mode ? 57344u : 49152u);
+    if (profile) small_from = 10000u;   // (round 5: 11 k PSSM pairs 131 against 128 GCUPS, 20 k 227 against 208, 80 k 641 against 459; below: the round-2 pipeline)
+    b->small = !special_of(mode) && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
     if (b->small) b->quad = false;
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
@@ -934,10 +938,12 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     for (size_t p = 0; p < n; p++) total += (uint64_t)ql[p] + rl[p];
     const uint64_t slots = (uint64_t)b->grid * ba::WAVES_PER_WG * ba::SM_SLOTS;
     uint64_t thr = std::max<uint64_t>(total / std::max<uint64_t>(slots, 1) / 2, 1024);
+    thr = std::max<uint64_t>(thr, 4 * (total / std::max<size_t>(n, 1)));   // ... and many times the batch's average length: a batch of equal pairs has none
     if (const char* e = dev_env("BA_EXCL_LEN2")) thr = (uint64_t)std::max(0, atoi(e));
     const size_t cap = (size_t)b->grid * ba::WAVES_PER_WG / 2;
     size_t cnt = 0;
     while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
+    if (cnt == cap && n > cap && !dev_env("BA_EXCL_LEN2")) cnt = 0;   // (the run did not end inside the cap: these are ordinary pairs, as in plan_walks)
     b->sm_excl_n = (uint32_t)cnt;
     // TRACE: the longest of them -- at least half the longest pair's length, at most one wave in thirty-two -- get a launch of their own
     // beside the main one (batch_launch): their fill + walk is a serial chain that outlasts the rest of the batch (400 k protein pairs with
@@ -1688,6 +1694,112 @@ int ba_multibatch_cigars(BaMultiBatch* m, uint32_t* runs, uint64_t capacity) {
     }
     return 0;
 }
+// ---- every pair with its own block range (lib.rs:109-111 percent_len per pair, as examples/nanopore_bench_global.rs:163,171 calls it):
+// pairs are binned by (min, max), every bin is an ordinary batch of this library -- the multi-pair kernels where the bin's minimum size has one --
+// launched one after the other on the device; results and CIGAR runs come back in the caller's order.
+struct BaSizedBatch {
+    std::vector<std::unique_ptr<BaBatch>> part;
+    std::vector<SizeRange> range;                 // part k's block range
+    std::vector<std::vector<uint32_t>> idx;       // part k's pairs (caller indices, ascending)
+    std::vector<float> last_ms;
+    size_t n = 0;
+    uint32_t mode = 0;
+};
+BaSizedBatch* ba_sized_batch_create(int kind, const void* matrix, Gaps gaps, const SizeRange* size_per_pair, int32_t x_drop, uint32_t mode, const uint8_t* pool,
+                                    const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n) {
+    if (!matrix || !size_per_pair || !pool || !q_off || !q_len || !r_off || !r_len) { fail("null argument"); return nullptr; }
+    if (n == 0) { fail("batch must hold at least one pair"); return nullptr; }
+    if (n >= (1ull << 32)) { fail("too many pairs"); return nullptr; }
+    std::unique_ptr<BaSizedBatch> m(new BaSizedBatch);
+    m->n = n; m->mode = mode;
+    std::map<std::pair<uintptr_t, uintptr_t>, size_t> cls;
+    for (size_t p = 0; p < n; p++) {
+        const auto key = std::make_pair(size_per_pair[p].min, size_per_pair[p].max);
+        auto it = cls.find(key);
+        if (it == cls.end()) { it = cls.emplace(key, m->idx.size()).first; m->idx.emplace_back(); m->range.push_back(size_per_pair[p]); }
+        m->idx[it->second].push_back((uint32_t)p);
+    }
+    m->part.resize(m->idx.size());
+    for (size_t k = 0; k < m->idx.size(); k++) {
+        const auto& ix = m->idx[k];
+        std::vector<uint64_t> qo(ix.size()), ro(ix.size());
+        std::vector<uint32_t> ql(ix.size()), rl(ix.size());
+        for (size_t i = 0; i < ix.size(); i++) { qo[i] = q_off[ix[i]]; ro[i] = r_off[ix[i]]; ql[i] = q_len[ix[i]]; rl[i] = r_len[ix[i]]; }
+        BaBatch* b = ba_batch_create(kind, matrix, gaps, m->range[k], x_drop, mode, pool, qo.data(), ql.data(), ro.data(), rl.data(), ix.size());
+        if (!b) { const std::string e = g_err; fail("block range %llu..%llu (%llu pairs): %s", (unsigned long long)m->range[k].min, (unsigned long long)m->range[k].max, (unsigned long long)ix.size(), e.c_str()); return nullptr; }
+        m->part[k].reset(b);
+    }
+    return m.release();
+}
+BaSizedBatch* ba_sized_batch_create_percent(int kind, const void* matrix, Gaps gaps, float min_percent, float max_percent, int32_t x_drop, uint32_t mode, const uint8_t* pool,
+                                            const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len, uintptr_t n) {
+    if (!q_len || !r_len) { fail("null argument"); return nullptr; }
+    std::vector<SizeRange> sz(n);
+    for (size_t p = 0; p < n; p++) {   // examples/nanopore_bench_global.rs:144-171: both percentages of the longer sequence's length
+        const uintptr_t len = std::max(q_len[p], r_len[p]);
+        sz[p].min = block_percent_len(len, min_percent); sz[p].max = block_percent_len(len, max_percent);
+    }
+    return ba_sized_batch_create(kind, matrix, gaps, sz.data(), x_drop, mode, pool, q_off, q_len, r_off, r_len, n);
+}
+int ba_sized_batch_run(BaSizedBatch* m, float* kernel_ms) {
+    if (!m) return fail("null batch");
+    // (one bin after the other: every launch is a persistent kernel sized for the whole device)
+    float total = 0;
+    m->last_ms.assign(m->part.size(), 0.f);
+    for (size_t k = 0; k < m->part.size(); k++) {
+        float ms = 0;
+        if (ba_batch_run(m->part[k].get(), &ms)) return 1;
+        m->last_ms[k] = ms; total += ms;
+    }
+    if (kernel_ms) *kernel_ms = total;
+    return 0;
+}
+int ba_sized_batch_results(BaSizedBatch* m, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {
+    if (!m) return fail("null batch");
+    for (size_t k = 0; k < m->part.size(); k++) {
+        const auto& ix = m->idx[k];
+        const size_t c = ix.size();
+        std::vector<int32_t> s(score ? c : 0); std::vector<uint32_t> a(qi ? c : 0), b(ri ? c : 0), l(cigar_len ? c : 0), st(status ? c : 0); std::vector<uint64_t> ce(cells ? c : 0);
+        if (ba_batch_results(m->part[k].get(), score ? s.data() : nullptr, qi ? a.data() : nullptr, ri ? b.data() : nullptr, cells ? ce.data() : nullptr,
+                             cigar_len ? l.data() : nullptr, status ? st.data() : nullptr)) return 1;
+        for (size_t i = 0; i < c; i++) {
+            const uint32_t p = ix[i];
+            if (score) score[p] = s[i]; if (qi) qi[p] = a[i]; if (ri) ri[p] = b[i]; if (cells) cells[p] = ce[i]; if (cigar_len) cigar_len[p] = l[i]; if (status) status[p] = st[i];
+        }
+    }
+    return 0;
+}
+int ba_sized_batch_cigars(BaSizedBatch* m, uint32_t* runs, uint64_t capacity) {   // concatenated in the caller's pair order, as ba_batch_cigars
+    if (!m) return fail("null batch");
+    std::vector<uint32_t> len(m->n, 0);
+    if (ba_sized_batch_results(m, nullptr, nullptr, nullptr, nullptr, len.data(), nullptr)) return 1;
+    std::vector<uint64_t> off(m->n + 1, 0);
+    for (size_t p = 0; p < m->n; p++) off[p + 1] = off[p] + len[p];
+    if (off[m->n] > capacity) return fail("cigar buffer too small: need %llu entries", (unsigned long long)off[m->n]);
+    for (size_t k = 0; k < m->part.size(); k++) {
+        const auto& ix = m->idx[k];
+        uint64_t total = 0;
+        for (uint32_t p : ix) total += len[p];
+        if (!total) continue;
+        std::vector<uint32_t> tmp(total);
+        if (ba_batch_cigars(m->part[k].get(), tmp.data(), total)) return 1;
+        uint64_t at = 0;
+        for (uint32_t p : ix) { if (len[p]) std::memcpy(runs + off[p], tmp.data() + at, (size_t)len[p] * 4); at += len[p]; }
+    }
+    return 0;
+}
+int ba_sized_batch_classes(BaSizedBatch* m, SizeRange* ranges, uint64_t* counts, int32_t* kernels, float* kernel_ms, int capacity) {   // the bins; returns their number
+    if (!m) return -1;
+    for (int k = 0; k < capacity && k < (int)m->part.size(); k++) {
+        if (ranges) ranges[k] = m->range[k];
+        if (counts) counts[k] = m->idx[k].size();
+        if (kernels) kernels[k] = ba_batch_kernel(m->part[k].get());
+        if (kernel_ms) kernel_ms[k] = k < (int)m->last_ms.size() ? m->last_ms[k] : 0.f;
+    }
+    return (int)m->part.size();
+}
+void ba_sized_batch_destroy(BaSizedBatch* m) { delete m; }
+
 int ba_multibatch_kernel_ms(BaMultiBatch* m, float* ms, int capacity) {   // per slice, of the last run; returns the number of slices
     if (!m) return -1;
     for (int k = 0; k < capacity && k < (int)m->last_ms.size(); k++) ms[k] = m->last_ms[k];

@@ -88,7 +88,10 @@ extern "C" hipError_t BA_CAT(ba_occupancy_m_k, BA_KIND, _p, BA_PMAX)(int trace, 
 }
 #endif
 
-#if BA_KIND != 3 && !BA_SPECIAL && !BA_BIG && BA_PMAX <= 8
+#if !BA_SPECIAL && !BA_BIG && BA_PMAX <= 8
+#if BA_KIND == 3
+#include "ba_multi.hpp"   // (k_small's column code builds on multi_rect's helpers; k_multi itself has no profile form)
+#endif
 // sixteen pairs per wave while the block is 32 cells, everything else by the same wave on all its lanes (ba_small.hpp): one kernel per
 // kind and block class (up to 1024 cells: the solo driver's LDS borders fit in the slots' region)
 #include "ba_small.hpp"

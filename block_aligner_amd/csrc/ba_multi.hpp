@@ -38,6 +38,13 @@ __device__ __forceinline__ int row_shl1_keep(int last, int src) { return __built
 __device__ __forceinline__ int splat_hi(int x) { const s16x2 t = as_s(x); return as_i(s16x2{t.y, t.y}); }
 __device__ __forceinline__ int splat_lo(int x) { const s16x2 t = as_s(x); return as_i(s16x2{t.x, t.x}); }
 
+// mask bit set ? a : b, as one v_cndmask_b32 (the lane mask in a scalar register pair)
+__device__ __forceinline__ int sel_mask(unsigned long long m, int a, int b) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 struct MultiConsts {
     int G[4];             // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
     int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g, except row lane 0 which holds -32768 (no lane above: a candidate that never wins)
@@ -71,6 +78,12 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
         const uint32_t w = k < 2 ? vb.x : vb.y;
         key[k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
     }
+    uint32_t kb[4] = {0, 0, 0, 0}, cbs_lo = 0, cbs_hi = 0;   // NUC: see add_byte (ba_device.hpp)
+    if constexpr (KIND == KIND_NUC) {
+        const uint32_t tb = (uint32_t)(uintptr_t)table, k01 = nuc_keys2(vb.x), k23 = nuc_keys2(vb.y);
+        kb[0] = add_word(k01, tb, 0); kb[1] = add_word(k01, tb, 1); kb[2] = add_word(k23, tb, 0); kb[3] = add_word(k23, tb, 1);
+        cbs_lo = nuc_col_offsets(cb_lo); cbs_hi = nuc_col_offsets(cb_hi);
+    }
     int dmax[4] = {0, 0, 0, 0}, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int nvD[4] = {0, 0, 0, 0}, nvR[4] = {0, 0, 0, 0};   // the last cells of the 8 new columns: the orthogonal border's new entries (row lane 15)
     int holdD = 0, holdR = 0;
@@ -79,7 +92,10 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
         const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
         int sc[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) sc[k] = fetch_score<KIND>(table, key[k], cb);
+        for (int k = 0; k < 4; k++) {
+            if constexpr (KIND == KIND_NUC) sc[k] = lds_read_i32(add_byte(j < 4 ? cbs_lo : cbs_hi, kb[k], j));
+            else sc[k] = fetch_score<KIND>(table, key[k], cb);
+        }
         // D00: the previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
         int prev = row_shr1_z(d[3]);
         if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
@@ -183,10 +199,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
     {   // workgroup-shared scoring table, as in k_align
         char* tab = smem;
         if (KIND == KIND_NUC) {
-            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
-                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
-                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
-            }
+            nuc_table_fill(tab, bp.matrix, (int)threadIdx.x, WAVES_PER_WG * 64);   // (layout: ba_device.hpp nuc_key_off)
         } else {
             const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
             for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
@@ -270,6 +283,20 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
         }
         return false;
     };
+    // an empty slot of this wave takes a slot that another wave offers (its state in the arena is a complete resumable record: a 2.3 KB copy)
+    auto try_refill = [&](uint32_t my_id) {
+        uint32_t id = 0; int s_o = 0;
+        if ((bp.flags & 0x1000u) || !claim_offer(my_id, id, s_o)) return false;   // (0x1000 / 0x2000: development switches)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int e = __builtin_ctz(~live_m & 15u);
+        const char* src = slot_mem_of(id, (uint32_t)s_o);
+        char* dst = wave_mem + (uint32_t)e * MQ_SLOT_BYTES;
+#pragma unroll
+        for (int k = 0; k < (int)(MQ_SLOT_BYTES / 256u); k++) *(int*)(dst + 256 * k + 4 * lane) = mq_load(src + 256 * k + 4 * lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the copy is in the L2 before this wave reads it back)
+        live_m |= 1u << e;
+        return true;
+    };
     auto my_id_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); return b * WAVES_PER_WG + w; };
 
     for (;;) {
@@ -292,6 +319,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 to_end = drain;                                      // (the batch is running out: this pair is not for a slot)
                 if (new_pair + bp.mq_drain >= bp.n) drain = true;    // from the next pair on
             } else if (live_m && live_m != 15u) {
+                // (tried in round 5: a wave with three live slots goes on stepping instead -- three slots take steps about as efficiently as a pair in
+                // solo mode --: no difference, 167.6 against 167.0 ms)
                 solo = __builtin_ctz(live_m); to_end = true;
                 if (TRACE && bp.mq_donate) {   // (the score-only kernels are compiled without the end-of-batch code: see DESIGN.md)
                     const uint32_t my_id = my_id_of();
@@ -300,18 +329,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     don = (uint32_t)uni((int)don) >> 8;
                     if (!(don & 1u)) {   // (here: the batch has run out, or this wave takes the pairs that are left one at a time -- either way the batch fills none of its slots again)
                         // an empty slot is first filled with a slot that another wave offers: the wave stays at four pairs per step
-                        uint32_t id = 0; int s_o = 0;
-                        if (!(bp.flags & 0x1000u) && claim_offer(my_id, id, s_o)) {   // (0x1000 / 0x2000: development switches)
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                            const int e = __builtin_ctz(~live_m & 15u);
-                            const char* src = slot_mem_of(id, (uint32_t)s_o);
-                            char* dst = wave_mem + (uint32_t)e * MQ_SLOT_BYTES;
-#pragma unroll
-                            for (int k = 0; k < (int)(MQ_SLOT_BYTES / 256u); k++) *(int*)(dst + 256 * k + 4 * lane) = mq_load(src + 256 * k + 4 * lane);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the copy is in the L2 before this wave reads it back)
-                            live_m |= 1u << e;
-                            continue;
-                        }
+                        if (try_refill(my_id)) continue;
                         // nothing on offer: this wave's own slots are, except the one it works on now (solo, to its end)
                         const uint32_t others = live_m & ~(1u << solo);
                         if (others) {
@@ -676,11 +694,12 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     const int ndir = go_down ? DIR_DOWN : DIR_RIGHT;
                     // the borders change roles with the direction (whatever a slot that does not commit holds is not read again: its state is
                     // what was staged before the step)
-                    const bool swap = ndir != dir;
+                    // (sixteen v_cndmask on one lane mask -- round 5: left to itself the compiler made two exec-masked regions of ~30 moves)
+                    const unsigned long long swap_m = __ballot(ndir != dir);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int td = A_d[k], tc = A_c[k];
-                        A_d[k] = swap ? P_d[k] : td; A_c[k] = swap ? P_r[k] : tc; P_d[k] = swap ? td : P_d[k]; P_r[k] = swap ? tc : P_r[k];
+                        A_d[k] = sel_mask(swap_m, P_d[k], td); A_c[k] = sel_mask(swap_m, P_r[k], tc); P_d[k] = sel_mask(swap_m, td, P_d[k]); P_r[k] = sel_mask(swap_m, tc, P_r[k]);
                     }
                     dir = commit ? ndir : dir;
                 }

@@ -139,8 +139,11 @@ BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ?
 BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
 BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > MQ_LDS_BYTES ? lds_wave_bytes_h(max_size) : MQ_LDS_BYTES; }   // k_multi
 BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * mq_wave_bytes_h(max_size); }
-BA_HD constexpr uint32_t sm_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > SM_LDS_BYTES ? lds_wave_bytes_h(max_size) : SM_LDS_BYTES; }   // k_small
-BA_HD constexpr uint32_t sm_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * sm_wave_bytes_h(max_size); }
+constexpr uint32_t SM_PROF_STAGE = 16 * 256;   // k_small, profile batches: per wave, 8 rows x 32 bytes of pos_aa per slot (the columns of a right step; behind the wave's region)
+BA_HD constexpr uint32_t sm_wave_bytes_h(uint32_t max_size, int kind = 0) {   // k_small
+    return (lds_wave_bytes_h(max_size) > SM_LDS_BYTES ? lds_wave_bytes_h(max_size) : SM_LDS_BYTES) + (kind == KIND_PROFILE ? SM_PROF_STAGE : 0u);
+}
+BA_HD constexpr uint32_t sm_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * sm_wave_bytes_h(max_size, kind); }
 // TRACE batches: one more region behind the waves' for the workgroup's traceback wave (ba_driver.hpp tb_step): per lane
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
 constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;

@@ -154,10 +154,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     {   // workgroup-shared scoring table, as in k_align
         char* tab = smem;
         if (KIND == KIND_NUC) {
-            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
-                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
-                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
-            }
+            nuc_table_fill(tab, bp.matrix, (int)threadIdx.x, WAVES_PER_WG * 64);   // (layout: ba_device.hpp nuc_key_off)
         } else {
             const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_BYTES ? 2 : 0);   // PROFILE: scores live in the pair's image
             for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];

@@ -78,6 +78,22 @@ struct SmallConsts {
     int w0;
 };
 
+// Sequence-to-profile steps (place_block_profile_*, scan_block.rs:612-783; ba_quad.hpp QuadProfile for two cells per lane). A slot's step runs along
+// the query ("right": one profile position per column, gap costs uniform in a column) or along the profile ("down": one query residue per column, gap
+// costs per row with the roles of C and R exchanged, scan_block.rs:671-682), and the sixteen slots of a wave differ. The loads have ONE form for both:
+// eight rows of the transposed table aa_pos[residue][position], 16 bytes each, at position `pos` -- right: the rows of the lane's eight residues at the
+// step's first column (S[m] = residue m x 8 columns), down: the rows of the step's eight column residues at the lane's first position (S[j] = column j x
+// 8 cells) -- and three 16-byte vectors of per-position costs at `pos` (right: the 8 columns', down: the lane's 8 cells').
+struct SmallProfile {
+    int S[8][4];                    // scores (see above), packed pairs
+    int G1[4], G2[4], G3[4];        // right: gap_open_C + extend / gap_open_R / gap_close_C of the 8 columns; down: gap_open_R + extend / gap_open_C / gap_close_C of the lane's 8 cells
+    int selE, selO;                 // cost selectors of even / odd columns (v_perm, first source = the column-packed register): right = splat its even / odd half, down = the lane's own pair
+    int selXE, selXO, selY;         // the close cost's: C11_end = C11 + gap_close_C in right steps only, R11_end = R11 + gap_close_R in down steps only (0x0c0c0c0c = zero)
+    unsigned long long rmask;       // lanes of slots that take a right step
+    int twords[8];                  // out (TRACE): the lane's eight trace words of the step -- stored by the caller behind the next step's loads (the memory
+                                    // counter is in order: loads issued behind the stores would wait for them)
+};
+
 // One 8-column shift step for the sixteen slots of a wave (multi_rect for quads). first_cell: this lane holds cell (0, 0) of a pair's
 // first block (scan_block.rs:1130-1132). fin_any / fin_col / dsel: a global alignment's last step is among the slots: D of column fin_col.
 // The orthogonal border pair is not live across the columns: its values of before the step are read back from the buffer the step's state
@@ -87,7 +103,8 @@ struct SmallConsts {
 template <int KIND, bool TRACE, bool FIN>
 __device__ __forceinline__ void small_rect(const char* table, const FillConsts& fc, const SmallConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
                                            int (&Pd)[4], int (&Pr)[4], const char* pstage, uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, bool first_cell,
-                                           uint32_t* __restrict__ tout, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o) {
+                                           uint32_t* __restrict__ tout, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o, SmallProfile* sp = nullptr) {
+    constexpr bool PROF = KIND == KIND_PROFILE;
     const int offa = splat(off_add);
     int d[4], c[4];
 #pragma unroll
@@ -100,6 +117,18 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
         const uint32_t w = k < 2 ? vb.x : vb.y;
         key[k] = make_key<KIND>((int)((w >> (16 * (k & 1))) & 0xffu), (int)((w >> (16 * (k & 1) + 8)) & 0xffu));
     }
+    int Yk[4] = {0, 0, 0, 0};   // profiles, down steps: gap_close_R of the lane's cells (zero in right steps)
+    int tdef[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // profiles: the step's trace words are stored by the caller, behind the loads of the next step (sp->twords)
+    if constexpr (PROF) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) Yk[k] = __builtin_amdgcn_perm(sp->G3[k], sp->G3[k], sp->selY);
+    }
+    uint32_t kb[4] = {0, 0, 0, 0}, cbs_lo = 0, cbs_hi = 0;   // NUC: see add_byte (ba_device.hpp)
+    if constexpr (KIND == KIND_NUC) {
+        const uint32_t tb = (uint32_t)(uintptr_t)table, k01 = nuc_keys2(vb.x), k23 = nuc_keys2(vb.y);
+        kb[0] = add_word(k01, tb, 0); kb[1] = add_word(k01, tb, 1); kb[2] = add_word(k23, tb, 0); kb[3] = add_word(k23, tb, 1);
+        cbs_lo = nuc_col_offsets(cb_lo); cbs_hi = nuc_col_offsets(cb_hi);
+    }
     int dmax[4] = {0, 0, 0, 0}, tacc[2] = {0, 0};
     int nvD[4] = {0, 0, 0, 0}, nvR[4] = {0, 0, 0, 0};   // the last cells of the 8 new columns: the orthogonal border's new entries (quad lane 3)
     int holdD = 0, holdR = 0;
@@ -108,7 +137,16 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
         const int cb = (int)(((j < 4 ? cb_lo : cb_hi) >> (8 * (j & 3))) & 0xffu);
         int sc[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) sc[k] = fetch_score<KIND>(table, key[k], cb);
+        for (int k = 0; k < 4; k++) {
+            if constexpr (KIND == KIND_NUC) sc[k] = lds_read_i32(add_byte(j < 4 ? cbs_lo : cbs_hi, kb[k], j));
+            else if constexpr (PROF) {   // right: cells 2k, 2k + 1 of column j out of their two rows; down: the column's row, cells 2k, 2k + 1
+                const int t = __builtin_amdgcn_perm(sp->S[2 * k + 1][j >> 1], sp->S[2 * k][j >> 1], (j & 1) ? 0x07060302 : 0x05040100);
+                sc[k] = sel_mask(sp->rmask, t, sp->S[j][k]);
+            }
+            else sc[k] = fetch_score<KIND>(table, key[k], cb);
+        }
+        int Xj = 0;   // profiles, right steps: the column's gap_close_C (zero in down steps)
+        if constexpr (PROF) Xj = __builtin_amdgcn_perm(sp->G3[j >> 1], sp->G3[j >> 1], (j & 1) ? sp->selXO : sp->selXE);
         // D00: the previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
         int prev = quad_shr1(d[3]);
         prev = l == 0 ? (j == 0 ? (int)((uint32_t)corner << 16) : 0) : prev;
@@ -116,15 +154,21 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
         d00[0] = __builtin_amdgcn_alignbit(d[0], prev, 16);
 #pragma unroll
         for (int k = 1; k < 4; k++) d00[k] = __builtin_amdgcn_alignbit(d[k], d[k - 1], 16);
-        int d11[4], copen[4], cn[4], x[4], r[4];
+        int d11[4], copen[4], cn[4], cend[4], x[4], r[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             d11[k] = adds(d00[k], sc[k]);
             if (j == 0 && k == 0) d11[0] = first_cell ? (int)(((uint32_t)d11[0] & 0xffff0000u) | (uint32_t)ZERO) : d11[0];   // cell (0,0) starts from the relative zero
-            copen[k] = adds(d[k], fc.go2);
+            int goC = fc.go2, goR = fc.ome2;
+            if constexpr (PROF) {   // position-specific costs: the column's (right) or the cell's (down), scan_block.rs:658-676
+                const int gsel = (j & 1) ? sp->selO : sp->selE;
+                goC = __builtin_amdgcn_perm(sp->G1[j >> 1], sp->G1[k], gsel); goR = __builtin_amdgcn_perm(sp->G2[j >> 1], sp->G2[k], gsel);
+            }
+            copen[k] = adds(d[k], goC);
             cn[k] = vmax(adds(c[k], fc.ge2), copen[k]);
-            d11[k] = vmax(d11[k], cn[k]);
-            x[k] = adds(d11[k], fc.ome2);                                  // D11_open
+            cend[k] = PROF ? adds(cn[k], Xj) : cn[k];                      // C11_end (scan_block.rs:694)
+            d11[k] = vmax(d11[k], cend[k]);
+            x[k] = adds(d11[k], goR);                                      // D11_open
             r[k] = vmax(x[k], splat_lo(adds(x[k], fc.ge2)));               // inside the register
         }
         // R11: the chain over the lane's registers, then a scan over the quad's four lanes on values re-based by l * 8g
@@ -143,9 +187,10 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
             for (int kk = 0; kk < 2; kk++) {
                 const int k = 2 * p2 + kk;
                 r[k] = vmax(r[k], adds(k < 3 ? splat_lo(cs) : cs, mc.G[k]));
-                dn[k] = vmax(d11[k], r[k]);
+                const int rend = PROF ? adds(r[k], Yk[k]) : r[k];          // R11_end (scan_block.rs:704)
+                dn[k] = vmax(d11[k], rend);
                 if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect)
-                    sC[kk] = (uint32_t)subs(cn[k], dn[k]); sR[kk] = (uint32_t)subs(r[k], dn[k]); sCo[kk] = (uint32_t)subs(copen[k], cn[k]); sRo[kk] = (uint32_t)subs(x[k], r[k]);
+                    sC[kk] = (uint32_t)subs(cend[k], dn[k]); sR[kk] = (uint32_t)subs(rend, dn[k]); sCo[kk] = (uint32_t)subs(copen[k], cn[k]); sRo[kk] = (uint32_t)subs(x[k], r[k]);
                 }
                 dmax[k] = vmax(dmax[k], dn[k]);
                 d[k] = dn[k]; c[k] = cn[k];
@@ -164,7 +209,8 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
 #pragma unroll
             for (int k = 0; k < 4; k++) dsel[k] = fin_col == (uint32_t)j ? dn[k] : dsel[k];
         }
-        if (TRACE && (j & 1)) *(int2*)(tout + 2 * (j >> 1)) = int2{tacc[0], tacc[1]};   // (a column pair's two words: the accumulators do not live on; unpredicated: a slot without a step writes to the wave's sink)
+        if constexpr (TRACE && PROF) { if (j & 1) { tdef[2 * (j >> 1)] = tacc[0]; tdef[2 * (j >> 1) + 1] = tacc[1]; } }
+        else if (TRACE && (j & 1)) *(int2*)(tout + 2 * (j >> 1)) = int2{tacc[0], tacc[1]};   // (a column pair's two words: the accumulators do not live on; unpredicated: a slot without a step writes to the wave's sink)
         // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
         if (j & 1) { nvD[j >> 1] = __builtin_amdgcn_perm(dn[3], holdD, 0x07060302); nvR[j >> 1] = __builtin_amdgcn_perm(r[3], holdR, 0x07060302); }
         else { holdD = dn[3]; holdR = r[3]; }
@@ -193,25 +239,27 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
     const int mm = vmax(vmax(dmax[0], dmax[1]), vmax(dmax[2], dmax[3]));
     const int m32 = max(mm & 0xffff, (int)((uint32_t)mm >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
     o.mx = quad_all_max(m32);
+    if constexpr (TRACE && PROF) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sp->twords[k] = tdef[k];
+    }
 }
 
 template <int PMAX, int KIND, bool TRACE, bool XDROP>
 #ifndef SM_WAVES_EU
 #define SM_WAVES_EU 4   // (waves per SIMD the kernel is compiled for; 2 -- 256 registers -- was tried for the traced kernels: see DESIGN.md)
 #endif
-__global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(SM_WAVES_EU, SM_WAVES_EU))) k_small(const BatchParams bp) {
+// (sequence-to-profile steps hold 32 score and 12 cost registers across their columns: that instantiation is compiled for two waves per SIMD)
+__global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(KIND == KIND_PROFILE ? 2 : SM_WAVES_EU, KIND == KIND_PROFILE ? 2 : SM_WAVES_EU))) k_small(const BatchParams bp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), l = lane & (SM_LW - 1), g = lane >> 2;
     const int wave = uni((int)threadIdx.x >> 6);
     {   // workgroup-shared scoring table, as in k_align
         char* tab = smem;
         if (KIND == KIND_NUC) {
-            for (int e = (int)threadIdx.x; e < 8 * 16 * 16; e += WAVES_PER_WG * 64) {
-                const int crow = e >> 8, a = (e >> 4) & 15, b = e & 15;
-                ((int*)tab)[e] = pk(bp.matrix[crow * 16 + a], bp.matrix[crow * 16 + b]);
-            }
+            nuc_table_fill(tab, bp.matrix, (int)threadIdx.x, WAVES_PER_WG * 64);   // (layout: ba_device.hpp nuc_key_off)
         } else {
-            const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
+            const int nbytes = KIND == KIND_AA ? 27 * 32 : (KIND == KIND_BYTES ? 2 : 0);   // PROFILE: scores live in the pair's image
             for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
         }
     }
@@ -221,7 +269,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
     if (bp.cq_side && wave >= 4) return;
     constexpr uint32_t LCLS = (uint32_t)PMAX * 128u;
     constexpr uint32_t ab = lds_array_bytes_h(LCLS);
-    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * sm_wave_bytes_h(LCLS);
+    char* base = smem + lds_table_bytes_h(KIND) + (uint32_t)wave * sm_wave_bytes_h(LCLS, KIND);
     WaveLds L;
     L.D_col = (short*)(base + 0 * ab); L.C_col = (short*)(base + 1 * ab);
     L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
@@ -445,6 +493,42 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             // sequence bytes of the next step, fetched one step ahead for both possible directions
             uint2 pf_qv = {0, 0}, pf_rv = {0, 0}, pf_qc = {0, 0}, pf_rc = {0, 0}; bool pf_ok = false;
             bool leave = false;
+            // Sequence-to-profile slots: the step's operands (SmallProfile) are loaded one step ahead -- at the end of the step before, as soon as its
+            // decisions have fixed where the next one goes, in front of that step's trace stores -- out of two 16-byte windows of the query that are
+            // themselves fetched a step earlier (win_v: the lane's residues q[win_si + 8l ..], win_c: the column residues q[win_si + 24 ..]; the next
+            // step starts at win_si or win_si + 8, so either half of a window serves it). Two dependent round trips per step otherwise: with two waves
+            // per SIMD they were 64 % of the fill's time (80 k PSSM pairs: 2.2 ms for 0.76 ms of vector instructions).
+            SmallProfile spf{};
+            bool sp_ok = false;
+            uint2 sp_vb = {0, 0};   // the lane's eight residues of the step the operands were loaded for
+            uint4 win_v = {0, 0, 0, 0}, win_c = {0, 0, 0, 0}; uint32_t win_si = 0;
+            auto load_profile_ops = [&](SmallProfile& sp_, bool right_, uint32_t ri_, uint32_t rj_, uint2 vb_, uint2 cb_, const uint8_t* rp_, uint32_t rlen_) {
+                // rp = the pair's AAProfile image (ba_params.h). One form of loads for both directions (see SmallProfile): eight rows of aa_pos and
+                // three cost vectors at `pos` -- the step's first column (right) or the lane's first position (down)
+                const uint32_t P = profile_positions(rlen_, max_size);
+                const short* aa_pos = (const short*)(rp_ + (uint64_t)P * 32);
+                const short* goCp = aa_pos + (uint64_t)P * 32; const short* clCp = goCp + P; const short* goRp = clCp + P;
+                const uint32_t pos = right_ ? rj_ : ri_ + 8u * (uint32_t)l;
+                const uint32_t b_lo = right_ ? vb_.x : cb_.x, b_hi = right_ ? vb_.y : cb_.y;   // the lane's eight residues / the step's eight column residues
+                // (right steps: NOT the rows of the lane's eight residues out of aa_pos -- 32 cache lines per slot and step for 512 bytes of use: 80 k PSSM
+                // pairs moved 10 GB per launch and ran at the memory's pace, 2.2 ms for 0.76 ms of vector instructions -- but the eight columns' rows of
+                // pos_aa[position][residue], 256 contiguous bytes per SLOT, 64 per lane, which stage_right_rows looks the residues up in through LDS)
+                const signed char* pos_rows = (const signed char*)rp_ + (uint64_t)rj_ * 32 + 64u * (uint32_t)l;
+                uint4 row[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const uint32_t res = ((m < 4 ? b_lo : b_hi) >> (8 * (m & 3))) & 31u;
+                    const void* src = right_ ? (const void*)(pos_rows + 16 * (m & 3)) : (const void*)(aa_pos + (uint64_t)res * P + pos);
+                    __builtin_memcpy(&row[m], src, 16);
+                }
+                uint4 g1, g2, g3;
+                __builtin_memcpy(&g1, (right_ ? goCp : goRp) + pos, 16); __builtin_memcpy(&g2, (right_ ? goRp : goCp) + pos, 16); __builtin_memcpy(&g3, clCp + pos, 16);
+#pragma unroll
+                for (int m = 0; m < 8; m++) { sp_.S[m][0] = (int)row[m].x; sp_.S[m][1] = (int)row[m].y; sp_.S[m][2] = (int)row[m].z; sp_.S[m][3] = (int)row[m].w; }
+                sp_.G1[0] = adds((int)g1.x, fq.ge2); sp_.G1[1] = adds((int)g1.y, fq.ge2); sp_.G1[2] = adds((int)g1.z, fq.ge2); sp_.G1[3] = adds((int)g1.w, fq.ge2);
+                sp_.G2[0] = (int)g2.x; sp_.G2[1] = (int)g2.y; sp_.G2[2] = (int)g2.z; sp_.G2[3] = (int)g2.w;
+                sp_.G3[0] = (int)g3.x; sp_.G3[1] = (int)g3.y; sp_.G3[2] = (int)g3.z; sp_.G3[3] = (int)g3.w;
+            };
             // the slot's A registers and the scalars of the step at the top into the buffer `which` (see ba_multi.hpp; rectangle records as
             // absolute positions here)
             auto stageA = [&](uint32_t which, int s_flag, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
@@ -484,6 +568,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
 #pragma unroll
                         for (int k = 0; k < 4; k++) { A_d[k] = 0; A_c[k] = 0; }
                         *(int4*)(lbuf + 256u + 128u + l * 16) = int4{0, 0, 0, 0}; *(int4*)(lbuf + 256u + 192u + l * 16) = int4{0, 0, 0, 0};   // P of buffer 1 (sel = 0)
+                        if (l == 0) { *(int4*)lsc = int4{0, 0, 0, 0}; *(int4*)(lsc + 4) = int4{0, 0, 0, 0}; }   // buffer 0's scalars: "no checkpoint" (flag 0) until an improving step writes them -- a slot that leaves before (trace room exhausted at max_size == 32) must not hand the solo driver what the previous tenant left
                         qp = bp.pool + bp.q_off[idx]; rp = bp.pool + bp.r_off[idx];
                         if (TRACE) {
                             const uint64_t t0 = bp.trace_off[idx], b0 = bp.blocks_off[idx];
@@ -496,7 +581,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                             rc[MR_BUDGET] = (int)(64u * ((qlen + rlen) / STEP + 64u)); rc[MR_STATUS] = 0; rc[MR_TSLOT] = (int)idx;
                             rc[MR_SI] = 0; rc[MR_SJ] = -(SM_B - STEP); rc[MR_NSTEPS] = 0;   // (the position the steps are counted from)
                         }
-                        pf_ok = false;
+                        pf_ok = false; sp_ok = false;
                     }
                 }
                 const bool live = pair != ~0u;
@@ -565,6 +650,40 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     }
 #endif
                 }
+                if constexpr (KIND == KIND_PROFILE) {
+                    // The step's operands were loaded at the end of the previous step (behind its decisions, see below) -- unless the slot has just taken its
+                    // pair (back): then here, with the latency in the open.
+                    if (__any(run && !sp_ok)) {
+                        if (run && !sp_ok) {
+                            load_profile_ops(spf, right, ri, rj, vb, cbv, rp, rlen);
+                            sp_vb = vb;
+                            const uint32_t* wv = (const uint32_t*)(qp + si + 8 * l); const uint32_t* wc = (const uint32_t*)(qp + si + (SM_B - STEP));
+                            win_v = uint4{wv[0], wv[1], wv[2], wv[3]}; win_c = uint4{wc[0], wc[1], wc[2], wc[3]}; win_si = si;
+                            sp_ok = true;
+                        }
+                    }
+                    {   // right steps: the eight columns' rows (this lane's 64 of the slot's 256 bytes in S[0 .. 3]) through LDS, then S[m] = residue m x 8 columns
+                        signed char* stg = (signed char*)base + sm_wave_bytes_h(LCLS) + (uint32_t)g * 256u;
+                        const bool rr = run && right;
+                        if (rr) {
+#pragma unroll
+                            for (int m = 0; m < 4; m++) *(int4*)(stg + 64 * l + 16 * m) = int4{spf.S[m][0], spf.S[m][1], spf.S[m][2], spf.S[m][3]};
+                        }
+                        lds_sync();
+                        if (rr) {
+#pragma unroll
+                            for (int m = 0; m < 8; m++) {
+                                const uint32_t res = ((m < 4 ? sp_vb.x : sp_vb.y) >> (8 * (m & 3))) & 31u;
+#pragma unroll
+                                for (int c = 0; c < 4; c++) spf.S[m][c] = pk((int)stg[(2 * c) * 32 + res], (int)stg[(2 * c + 1) * 32 + res]);
+                            }
+                        }
+                        lds_sync();
+                    }
+                    spf.selE = right ? 0x05040504 : 0x03020100; spf.selO = right ? 0x07060706 : 0x03020100;
+                    spf.selXE = right ? 0x05040504 : 0x0c0c0c0c; spf.selXO = right ? 0x07060706 : 0x0c0c0c0c; spf.selY = right ? 0x0c0c0c0c : 0x03020100;
+                    spf.rmask = __ballot(right);
+                }
                 const bool fin = !XDROP && run && boot == 0 && q_out && r_out;   // the last step of a global alignment
                 const bool fin_any = !XDROP && __any(fin);
                 const uint32_t fin_col = lenC - rj;   // its last computed column (0 .. 7: columns rj .. lenC)
@@ -572,12 +691,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 int Pn_d[4], Pn_r[4];   // the orthogonal border pair after the step
                 MultiOut o;
                 small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, Pn_d, Pn_r, lbuf + (sel ^ 1u) * 256u + 128u + l * 16, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw,
-                                                fin_any, fin ? fin_col : 8u, dsel, o);
+                                                fin_any, fin ? fin_col : 8u, dsel, o, KIND == KIND_PROFILE ? &spf : nullptr);
 #ifndef SM_PREFETCH_EARLY
                 // sequence bytes of the step after this one, whichever way it goes: issued behind the columns (the eight registers are not live
                 // across them; consecutive steps read consecutive bytes, mostly out of the L1). The alternative -- issued at the top, in flight
                 // across the columns (-DSM_PREFETCH_EARLY) -- costs ~60 more instructions per step for the same time (same-box A/B: C2 -3.5 %).
-                if (run) {
+                // (profiles: the query's bytes come out of the windows, see load_profile_ops)
+                if (KIND != KIND_PROFILE && run) {
                     const uint32_t* a = (const uint32_t*)(qp + si + 8 * l); const uint32_t* b = (const uint32_t*)(rp + (boot > 1 ? 0u : sj) + 8 * l);
                     const uint32_t* cq = (const uint32_t*)(qp + si + SM_B); const uint32_t* cr = (const uint32_t*)(rp + (uint32_t)(sj + SM_B));
                     pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
@@ -657,6 +777,22 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     for (int k = 0; k < 4; k++) { A_d[k] = swap ? Pn_d[k] : A_d[k]; A_c[k] = swap ? Pn_r[k] : A_c[k]; }
                     char* b = lbuf + (sel ^ 1u) * 256u + l * 16;
                     *(int4*)(b + 128) = npd; *(int4*)(b + 192) = npr;
+                }
+                if constexpr (KIND == KIND_PROFILE) {
+                    // ---- the next step's operands, as soon as it is known where it goes (see load_profile_ops); then this step's trace words
+                    const bool goes_on = (commit || bsub) && pair != ~0u;
+                    if (goes_on) {
+                        const bool nright = dir == DIR_RIGHT;
+                        const bool hi = si != win_si;   // (the next step starts at win_si or 8 further down)
+                        uint2 nvb, ncb;
+                        nvb.x = hi ? win_v.z : win_v.x; nvb.y = hi ? win_v.w : win_v.y; ncb.x = hi ? win_c.z : win_c.x; ncb.y = hi ? win_c.w : win_c.y;
+                        load_profile_ops(spf, nright, nright ? si : sj, (nright ? sj : si) + (SM_B - STEP), nvb, ncb, rp, rlen);
+                        sp_vb = nvb;
+                        const uint32_t* wv = (const uint32_t*)(qp + si + 8 * l); const uint32_t* wc = (const uint32_t*)(qp + si + (SM_B - STEP));
+                        win_v = uint4{wv[0], wv[1], wv[2], wv[3]}; win_c = uint4{wc[0], wc[1], wc[2], wc[3]}; win_si = si;
+                    }
+                    sp_ok = goes_on; pf_ok = goes_on;
+                    if (TRACE) { *(int4*)tw = int4{spf.twords[0], spf.twords[1], spf.twords[2], spf.twords[3]}; *(int4*)(tw + 4) = int4{spf.twords[4], spf.twords[5], spf.twords[6], spf.twords[7]}; }
                 }
                 if (__any(leave)) break;
             }

@@ -138,6 +138,15 @@ def lib() -> C.CDLL:
         L.ba_multibatch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_multibatch_cigars.argtypes = [vp, vp, C.c_uint64]
         L.ba_multibatch_parts.argtypes = [vp, vp, C.c_int]
+        L.ba_sized_batch_create.restype = vp
+        L.ba_sized_batch_create.argtypes = [C.c_int, vp, GapsC, vp, i32, u32, vp, vp, vp, vp, vp, sz]
+        L.ba_sized_batch_create_percent.restype = vp
+        L.ba_sized_batch_create_percent.argtypes = [C.c_int, vp, GapsC, C.c_float, C.c_float, i32, u32, vp, vp, vp, vp, vp, sz]
+        L.ba_sized_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
+        L.ba_sized_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.ba_sized_batch_cigars.argtypes = [vp, vp, C.c_uint64]
+        L.ba_sized_batch_classes.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+        L.ba_sized_batch_destroy.argtypes = [vp]
         L.ba_multibatch_kernel_ms.argtypes = [vp, vp, C.c_int]
         L.ba_multibatch_destroy.argtypes = [vp]
         L.ba_shard_slices.argtypes = [vp, vp, sz, C.c_int, vp]
@@ -559,6 +568,69 @@ class MultiBatchAligner:
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.ba_multibatch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class SizedBatchAligner:
+    """Every pair with its own block range (ba_sized_batch_*): `sizes` = an (n, 2) array of (min, max), or percent = (min_percent, max_percent) of
+    the longer sequence's length per pair, as examples/nanopore_bench_global.rs:144-171 calls percent_len."""
+
+    def __init__(self, matrix, gaps, x_drop: int, mode: int, pool, q_off, q_len, r_off, r_len, sizes=None, percent=None):
+        L = lib()
+        self.n = len(q_len)
+        self.mode = mode
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64); r_off = np.ascontiguousarray(r_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint32); r_len = np.ascontiguousarray(r_len, dtype=np.uint32)
+        raw = matrix.raw()
+        g = GapsC(gaps.open, gaps.extend) if isinstance(gaps, S.Gaps) else GapsC(gaps[0], gaps[1])
+        if (sizes is None) == (percent is None):
+            raise ValueError("give either sizes or percent")
+        if sizes is not None:
+            sz = np.ascontiguousarray(sizes, dtype=np.uint64).reshape(self.n, 2)   # SizeRange {uintptr min, max}
+            self._h = L.ba_sized_batch_create(matrix.KIND, raw.ctypes.data, g, sz.ctypes.data, x_drop, mode, pool.ctypes.data, q_off.ctypes.data,
+                                              q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, self.n)
+        else:
+            self._h = L.ba_sized_batch_create_percent(matrix.KIND, raw.ctypes.data, g, percent[0], percent[1], x_drop, mode, pool.ctypes.data, q_off.ctypes.data,
+                                                      q_len.ctypes.data, r_off.ctypes.data, r_len.ctypes.data, self.n)
+        if not self._h:
+            raise RuntimeError(last_error())
+
+    def run(self) -> float:
+        ms = C.c_float()
+        if lib().ba_sized_batch_run(self._h, C.byref(ms)):
+            raise RuntimeError(last_error())
+        return ms.value
+
+    def results(self):
+        n = self.n
+        out = dict(score=np.zeros(n, np.int32), query_idx=np.zeros(n, np.uint32), reference_idx=np.zeros(n, np.uint32),
+                   cells=np.zeros(n, np.uint64), cigar_len=np.zeros(n, np.uint32), status=np.zeros(n, np.uint32))
+        if lib().ba_sized_batch_results(self._h, *(out[k].ctypes.data for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"))):
+            raise RuntimeError(last_error())
+        return out
+
+    def cigars(self, cigar_len=None):
+        if cigar_len is None:
+            cigar_len = self.results()["cigar_len"]
+        off = np.zeros(self.n + 1, np.uint64)
+        np.cumsum(cigar_len, out=off[1:])
+        runs = np.zeros(int(off[-1]), np.uint32)
+        if lib().ba_sized_batch_cigars(self._h, runs.ctypes.data, runs.size):
+            raise RuntimeError(last_error())
+        return runs, off
+
+    def classes(self):
+        """[(min, max, pairs, fill kernel, kernel ms of the last run)] per bin."""
+        r = np.zeros((64, 2), np.uint64); c = np.zeros(64, np.uint64); k = np.zeros(64, np.int32); t = np.zeros(64, np.float32)
+        nb = lib().ba_sized_batch_classes(self._h, r.ctypes.data, c.ctypes.data, k.ctypes.data, t.ctypes.data, 64)
+        return [(int(r[i, 0]), int(r[i, 1]), int(c[i]), int(k[i]), float(t[i])) for i in range(nb)]
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.ba_sized_batch_destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -256,6 +256,26 @@ int ba_batch_spec_cells(BaBatch* batch, uint64_t* cells);
 int ba_batch_retried(BaBatch* batch);
 void ba_batch_destroy(BaBatch* batch);
 
+/* ---- every pair with its own block range. The reference's callers choose the range per pair -- percent_len(max(|q|, |r|), 0.01) ..=
+ * percent_len(max(|q|, |r|), p) in /root/reference/examples/nanopore_bench_global.rs:144-171, Block::align(..., min..=max, x) in
+ * src/scan_block.rs:847 --, while ba_batch_create takes one range for the whole batch. These calls bin the pairs by (min, max), align every bin as
+ * a batch of its own (same kernels, same results as ba_batch_create with that range) and give results and CIGAR runs back in the caller's order. */
+typedef struct BaSizedBatch BaSizedBatch;
+BaSizedBatch* ba_sized_batch_create(int kind, const void* matrix, struct Gaps gaps, const struct SizeRange* size_per_pair, int32_t x_drop, uint32_t mode,
+                                    const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len,
+                                    uintptr_t n_pairs);
+/* ... the range of pair p = block_percent_len(max(|q|, |r|), min_percent) .. block_percent_len(max(|q|, |r|), max_percent) (lib.rs:109-111) */
+BaSizedBatch* ba_sized_batch_create_percent(int kind, const void* matrix, struct Gaps gaps, float min_percent, float max_percent, int32_t x_drop, uint32_t mode,
+                                            const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len,
+                                            uintptr_t n_pairs);
+int ba_sized_batch_run(BaSizedBatch* batch, float* kernel_ms);   /* kernel_ms: the bins' kernel times added up */
+int ba_sized_batch_results(BaSizedBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells, uint32_t* cigar_len,
+                           uint32_t* status);
+int ba_sized_batch_cigars(BaSizedBatch* batch, uint32_t* runs, uint64_t capacity);
+/* the bins: their ranges, pair counts, fill kernels (ba_batch_kernel) and kernel times of the last run; any pointer may be NULL; returns the number of bins */
+int ba_sized_batch_classes(BaSizedBatch* batch, struct SizeRange* ranges, uint64_t* counts, int32_t* kernels, float* kernel_ms, int capacity);
+void ba_sized_batch_destroy(BaSizedBatch* batch);
+
 /* ---- one batch over several GPUs of a node (pairs are independent, so the batch shards without any exchange
  * step). The pair list is cut into contiguous cost-balanced slices (cost = |q| + |r|), one per entry of `devices` (an
  * entry may repeat a device); every slice is a batch of its own, built by its own host thread and launched on its own

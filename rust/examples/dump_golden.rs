@@ -9,7 +9,10 @@
 // (-m gpu, every line) with it: score, end indices, CIGAR, Trace::blocks(). No dependency beyond the crate itself.
 //
 // Input: one case per line, tab-separated (tests/golden/make_crate_golden_input.py writes it):
-//   id  kind(aa|nuc|bytes)  matrix  gap_open  gap_extend  min_size  max_size  x_drop  mode  query  reference
+//   id  kind(aa|nuc|bytes|profile)  matrix  gap_open  gap_extend  min_size  max_size  x_drop  mode  query  reference
+//   kind "profile" (Block::align_profile): matrix = "pssm" -- row i of the profile is the BLOSUM62 row of reference[i] over the 20 standard residues,
+//   as examples/pssm_bench.rs builds one --, gap_open = one "gap_open_C/gap_close_C/gap_open_R" triple per position 0 ..= len, comma-separated,
+//   gap_extend = the profile's, reference = the consensus the rows come from.
 //   matrix: a static of scores.rs (BLOSUM62, NW1, BYTES1, ...) or "simple:<match>:<mismatch>"; mode: '+'-joined subset of
 //   trace,x_drop,local_start,free_query_start_gaps,free_query_end_gaps ("-" = none); sequences are printable ASCII ("-" = empty).
 // Output: one line per case:
@@ -47,6 +50,47 @@ fn run<M: Matrix, const TRACE: bool, const X_DROP: bool, const LOCAL_START: bool
     } else {
         format!("{}\t{}\t{}\t-\t-\t-", res.score, res.query_idx, res.reference_idx)
     }
+}
+
+// Sequence-to-profile: the same with Block::align_profile (scan_block.rs:942-968); no cigar_eq (there is no second sequence) and no blocks().
+fn run_profile<const TRACE: bool, const X_DROP: bool, const LOCAL_START: bool, const FQS: bool, const FQE: bool>(p: &AAProfile, c: &Case) -> String {
+    let qp = PaddedBytes::from_bytes::<AAMatrix>(c.q, c.max);
+    let mut b = Block::<TRACE, X_DROP, LOCAL_START, FQS, FQE>::new(c.q.len(), p.len(), c.max);
+    b.align_profile(&qp, p, c.min..=c.max, c.x_drop);
+    let res = b.res();
+    if TRACE {
+        let mut cg = Cigar::new(c.q.len(), p.len());
+        b.trace().cigar(res.query_idx, res.reference_idx, &mut cg);
+        let s1 = cg.to_string();
+        format!("{}\t{}\t{}\t{}\t-\t{}", res.score, res.query_idx, res.reference_idx, if s1.is_empty() { "-".to_string() } else { s1 }, blocks_str(&b.trace().blocks()))
+    } else {
+        format!("{}\t{}\t{}\t-\t-\t-", res.score, res.query_idx, res.reference_idx)
+    }
+}
+
+fn dispatch_profile(p: &AAProfile, mode: &str, c: &Case) -> String {
+    let has = |k: &str| mode.split('+').any(|x| x == k);
+    let (t, x, l, s, e) = (has("trace"), has("x_drop"), has("local_start"), has("free_query_start_gaps"), has("free_query_end_gaps"));
+    macro_rules! go { ($t:literal, $x:literal, $l:literal, $s:literal, $e:literal) => { if (t, x, l, s, e) == ($t, $x, $l, $s, $e) { return run_profile::<$t, $x, $l, $s, $e>(p, c); } } }
+    macro_rules! both { ($x:literal, $l:literal, $s:literal, $e:literal) => { go!(false, $x, $l, $s, $e); go!(true, $x, $l, $s, $e); } }
+    both!(false, false, false, false); both!(true, false, false, false);
+    both!(false, true, false, false); both!(true, true, false, false);
+    both!(false, false, true, false); both!(true, false, true, false);
+    both!(false, false, false, true); both!(false, true, false, true); both!(false, false, true, true);
+    panic!("mode {:?} is not one Block::align_profile accepts", mode);
+}
+
+// a PSSM as examples/pssm_bench.rs:64-84 builds one: row i = BLOSUM62 row of consensus[i]; per-position gap costs from the triples
+fn build_profile(cons: &[u8], triples: &str, gap_extend: i8, max: usize) -> AAProfile {
+    let mut p = AAProfile::new(cons.len(), max, gap_extend);
+    for (i, &c) in cons.iter().enumerate() {
+        for &b in b"ACDEFGHIKLMNPQRSTVWY" { p.set(i + 1, b, BLOSUM62.get(c, b)); }
+    }
+    for (i, t) in triples.split(',').enumerate() {
+        let v: Vec<i8> = t.split('/').map(|x| x.parse().unwrap()).collect();
+        p.set_gap_open_C(i, v[0]); p.set_gap_close_C(i, v[1]); p.set_gap_open_R(i, v[2]);
+    }
+    p
 }
 
 // the combinations Block::align accepts (scan_block.rs:860-862: not LOCAL_START with FREE_QUERY_START_GAPS, not X_DROP with FREE_QUERY_END_GAPS)
@@ -88,9 +132,16 @@ fn main() {
         let seq = |s: &'static str| -> &'static [u8] { if s == "-" { b"" } else { s.as_bytes() } };
         // (the fields borrow from `text`, which lives to the end of main: extend the borrow for the helper above)
         let (qs, rs): (&'static str, &'static str) = unsafe { (std::mem::transmute(f[9]), std::mem::transmute(f[10])) };
+        let mode = if f[8] == "-" { "" } else { f[8] };
+        if f[1] == "profile" {
+            let max: usize = f[6].parse().unwrap();
+            let c = Case { gaps: Gaps { open: -2, extend: -1 }, min: f[5].parse().unwrap(), max, x_drop: f[7].parse().unwrap(), q: seq(qs), r: seq(rs) };   // (gaps unused)
+            let p = build_profile(seq(rs), f[3], f[4].parse().unwrap(), max);
+            writeln!(out, "{}\t{}", f[0], dispatch_profile(&p, mode, &c)).unwrap();
+            continue;
+        }
         let c = Case { gaps: Gaps { open: f[3].parse().unwrap(), extend: f[4].parse().unwrap() }, min: f[5].parse().unwrap(), max: f[6].parse().unwrap(),
                        x_drop: f[7].parse().unwrap(), q: seq(qs), r: seq(rs) };
-        let mode = if f[8] == "-" { "" } else { f[8] };
         let res = match f[1] {
             "aa" => match (aa_static(f[2]), simple(f[2])) {
                 (Some(m), _) => dispatch(m, mode, &c),

@@ -3,7 +3,9 @@ backend) to produce tests/golden/crate_golden.tsv -- golden vectors from the ref
 image has none). tests/test_crate_golden.py compares the oracle and the HIP path with that file when it exists.
 
 Seeded; the cases aim at what the reference's own 48 known answers do not reach: grows, checkpoint restores, shrinks and X-drop
-termination after growth at (16, 64), (32, 256), (128, 1024), all mode bits. Format: rust/examples/dump_golden.rs.
+termination after growth at (16, 64), (32, 256), (128, 1024), all mode bits; and -- round 5 -- sequence-to-profile cases (Block::align_profile over
+PSSMs whose rows are BLOSUM62 rows of a consensus, examples/pssm_bench.rs:43-98, with position-specific gap_open_C / gap_close_C / gap_open_R).
+Format: rust/examples/dump_golden.rs.
 
     python tests/golden/make_crate_golden_input.py
 """
@@ -66,6 +68,46 @@ def main():
                         continue
                     lines.append("\t".join(str(x) for x in (cid, kind, m, go, ge, size[0], size[1], xd, mode, qs, rs)))
                     cid += 1
+    # ---- sequence-to-profile (kind "profile"): matrix = "pssm" (row i = BLOSUM62 row of consensus[i] over the 20 standard residues), the gap_open field
+    # holds one "gap_open_C/gap_close_C/gap_open_R" triple per position 0 .. len (comma-separated), gap_extend the profile's, reference = the consensus
+    aa20 = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    prng = np.random.default_rng(20261004)
+    n_prof = 0
+    for size in [(16, 16), (16, 64), (32, 32), (32, 256), (32, 128), (128, 1024)]:
+        for mode in MODES:
+            n = int(prng.integers(0, 40)) if size[1] <= 16 and prng.random() < 0.3 else int(prng.integers(40, 900 if size[1] >= 1024 else 500))
+            cons = aa20[prng.integers(0, 20, n)]
+            ge = int(prng.integers(-2, 0))
+            prof = S.AAProfile(n, size[1], ge)
+            for i, c in enumerate(cons):
+                for b in aa20:
+                    prof.set(i + 1, int(b), S.BLOSUM62.get(int(c), int(b)))
+            triples = []
+            for i in range(n + 1):
+                t = (int(prng.integers(-14, -3)), int(prng.integers(-4, 1)), int(prng.integers(-14, -3)))
+                prof.set_gap_open_C(i, t[0]); prof.set_gap_close_C(i, t[1]); prof.set_gap_open_R(i, t[2])
+                triples.append("%d/%d/%d" % t)
+            q = synth.mutate(prng, cons, int(prng.uniform(0, 0.3) * n), aa20) if n else cons
+            if len(q) > 80 and prng.random() < 0.8:   # a long insertion or deletion: grow, checkpoint restore, shrink
+                at = int(prng.integers(20, len(q) - 20)); ln = int(prng.integers(max(8, size[0] // 2), min(250, 3 * size[1])))
+                q = np.concatenate([q[:at], synth.rand_str(prng, ln, aa20), q[at:]]) if prng.random() < 0.5 else np.concatenate([q[:at], q[at + ln:]])
+            if prng.random() < 0.4:
+                q = np.concatenate([q, synth.rand_str(prng, int(prng.integers(0, 150)), aa20)])
+            if "free_query_end_gaps" in mode:
+                k = int(prng.integers(0, size[0]))
+                at = int(prng.integers(0, max(1, len(q) - k)))
+                q = q[at: at + k]
+            xd = int(prng.integers(10, 120)) if "x_drop" in mode else 0
+            qb = q.astype(np.uint8).tobytes()
+            try:
+                oracle.align_profile(qb, prof, size, xd, tuple(mode.split("+")) if mode != "-" else ())
+            except RuntimeError:
+                dropped += 1
+                continue
+            lines.append("\t".join(str(x) for x in (cid, "profile", "pssm", ",".join(triples), ge, size[0], size[1], xd, mode, qb.decode("ascii") or "-",
+                                                     cons.astype(np.uint8).tobytes().decode("ascii") or "-")))
+            cid += 1; n_prof += 1
+    print("profile cases:", n_prof)
     path = os.path.join(ROOT, "tests", "golden", "crate_golden_input.tsv")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -35,9 +35,26 @@ def read_cases():
                 continue
             cid, kind, m, go, ge, mn, mx, xd, mode, q, r = line.split("\t")
             mode = tuple(sorted(mode.split("+"))) if mode != "-" else ()
+            if kind == "profile":   # (gap_open: one gap_open_C/gap_close_C/gap_open_R triple per position; reference: the consensus -- see dump_golden.rs)
+                cases.append(dict(id=int(cid), kind=kind, matrix=m, triples=[tuple(int(v) for v in t.split("/")) for t in go.split(",")], gap_extend=int(ge),
+                                  size=(int(mn), int(mx)), x_drop=int(xd), mode=mode, q=b"" if q == "-" else q.encode(), r=b"" if r == "-" else r.encode()))
+                continue
             cases.append(dict(id=int(cid), kind=kind, matrix=m, gaps=(int(go), int(ge)), size=(int(mn), int(mx)), x_drop=int(xd), mode=mode,
                               q=b"" if q == "-" else q.encode(), r=b"" if r == "-" else r.encode()))
     return cases
+
+
+def profile_of(c):
+    """The PSSM of a "profile" case, as rust/examples/dump_golden.rs build_profile makes it (examples/pssm_bench.rs:64-84)."""
+    cons = c["r"]
+    p = S.AAProfile(len(cons), c["size"][1], c["gap_extend"])
+    for i, ch in enumerate(cons):
+        for b in b"ACDEFGHIKLMNPQRSTVWY":
+            p.set(i + 1, b, S.BLOSUM62.get(ch, b))
+    assert len(c["triples"]) == len(cons) + 1
+    for i, (goc, clc, gor) in enumerate(c["triples"]):
+        p.set_gap_open_C(i, goc); p.set_gap_close_C(i, clc); p.set_gap_open_R(i, gor)
+    return p
 
 
 def read_golden():
@@ -57,16 +74,24 @@ def read_golden():
 def test_input_file_is_well_formed_and_the_oracle_runs_every_case(oracle):
     cases = read_cases()
     assert len(cases) >= 300 and [c["id"] for c in cases] == list(range(len(cases)))
-    seen_modes, grew = set(), 0
+    seen_modes, grew, n_prof, prof_grew = set(), 0, 0, 0
     for c in cases:
         assert set(c["mode"]) <= ALL_MODES and not ({"local_start", "free_query_start_gaps"} <= set(c["mode"])) and not ({"x_drop", "free_query_end_gaps"} <= set(c["mode"]))
-        assert c["gaps"][0] < c["gaps"][1] < 0 and c["size"][0] <= c["size"][1]
+        assert c["size"][0] <= c["size"][1]
         if "free_query_end_gaps" in c["mode"]:
             assert len(c["q"]) < c["size"][0]
+        if c["kind"] == "profile":
+            assert c["gap_extend"] < 0 and all(t[0] < 0 and t[2] < 0 for t in c["triples"])
+            res = oracle.align_profile(c["q"], profile_of(c), c["size"], c["x_drop"], c["mode"])
+            n_prof += 1
+            prof_grew += res["end_block_size"] > c["size"][0] or res["cells"] > (len(c["q"]) + len(c["r"]) + 2 * c["size"][0]) * c["size"][0]
+            continue
+        assert c["gaps"][0] < c["gaps"][1] < 0
         res = oracle.align(matrix_of(c["kind"], c["matrix"]), c["q"], c["r"], c["gaps"], c["size"], c["x_drop"], c["mode"])
         seen_modes.add(c["mode"])
         grew += res["end_block_size"] > c["size"][0] or res["cells"] > (len(c["q"]) + len(c["r"]) + 2 * c["size"][0]) * c["size"][0]
     assert len(seen_modes) >= 12 and grew >= 60   # the file does reach past the reference's own fixed-size known answers
+    assert n_prof >= 60 and prof_grew >= 12       # ... and into place_block_profile_* with position-specific gap costs, growing blocks included
 
 
 needs_golden = pytest.mark.skipif(not os.path.exists(GOLDEN), reason="tests/golden/crate_golden.tsv not present: produce it with rust/examples/dump_golden.rs "
@@ -80,6 +105,12 @@ def test_oracle_equals_the_crate(oracle):
     assert set(golden) == {c["id"] for c in cases}
     for c in cases:
         g = golden[c["id"]]
+        if c["kind"] == "profile":
+            res = oracle.align_profile(c["q"], profile_of(c), c["size"], c["x_drop"], c["mode"])
+            assert (res["score"], res["query_idx"], res["reference_idx"]) == (g["score"], g["query_idx"], g["reference_idx"]), c["id"]
+            if "trace" in c["mode"]:
+                assert res["cigar"] == g["cigar"], c["id"]
+            continue
         m = matrix_of(c["kind"], c["matrix"])
         res = oracle.align(m, c["q"], c["r"], c["gaps"], c["size"], c["x_drop"], c["mode"])
         assert (res["score"], res["query_idx"], res["reference_idx"]) == (g["score"], g["query_idx"], g["reference_idx"]), c["id"]
@@ -95,6 +126,17 @@ def test_hip_equals_the_crate(hip):
     golden = read_golden()
     for c in read_cases():
         g = golden[c["id"]]
+        if c["kind"] == "profile":
+            blk = hip.Block(len(c["q"]), len(c["r"]), c["size"][1], **{k: True for k in c["mode"]})
+            qp = hip.PaddedBytes.from_bytes(c["q"], c["size"][1], S.AAMatrix)
+            blk.align_profile(qp, profile_of(c), c["size"], c["x_drop"])
+            res = blk.res()
+            assert (res.score, res.query_idx, res.reference_idx) == (g["score"], g["query_idx"], g["reference_idx"]), c["id"]
+            if "trace" in c["mode"]:
+                cg = hip.Cigar(len(c["q"]), len(c["r"]))
+                blk.trace().cigar(res.query_idx, res.reference_idx, cg)
+                assert str(cg) == g["cigar"], c["id"]
+            continue
         m = matrix_of(c["kind"], c["matrix"])
         mc = type(m)
         blk = hip.Block(len(c["q"]), len(c["r"]), c["size"][1], **{k: True for k in c["mode"]})

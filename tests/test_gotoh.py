@@ -77,12 +77,12 @@ def test_oracle_profile_full_block_equals_full_dp(oracle):
         assert res["score"] == global_score_profile(q, p, go), (it, L, len(q))
 
 
-def pos_profile_case(rng, B):
-    """A PSSM with position-specific gap_open_C / gap_close_C / gap_open_R (and sometimes gap_extend below -1) that fits one block."""
+def pos_profile_case(rng, B, ge=None):
+    """A PSSM with position-specific gap_open_C / gap_close_C / gap_open_R (gap_extend -1 or -2 unless given) that fits one block."""
     L = int(rng.integers(1, B - 1))
     aa = np.frombuffer(AA20, np.uint8)
     cons = aa[rng.integers(0, 20, L)]
-    p = S.AAProfile(L, B, int(rng.integers(-2, 0)))
+    p = S.AAProfile(L, B, int(rng.integers(-2, 0)) if ge is None else ge)
     for i, c in enumerate(cons):
         for a in aa:
             p.set(i + 1, int(a), S.BLOSUM62.get(int(c), int(a)))

@@ -93,7 +93,8 @@ def test_full_block_profile_with_position_specific_gaps(hip, B):
     from tests.gotoh import global_score_profile_pos, rescore_profile_cigar
     from tests.test_gotoh import pos_profile_case
     rng = np.random.default_rng(70 + B)
-    cases = [pos_profile_case(rng, B) for _ in range(32 if B <= 256 else 10)]
+    ge = -1 - (B // 16) % 2   # (one gap_extend per profile batch)
+    cases = [pos_profile_case(rng, B, ge) for _ in range(32 if B <= 256 else 10)]
     pool = np.frombuffer(b"".join(q for q, _ in cases) + b"\0" * 8, np.uint8)
     q_len = np.array([len(q) for q, _ in cases], np.uint32)
     q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.uint64)

@@ -82,6 +82,19 @@ def test_small_trace_regions_overflow_and_rerun(hip, oracle, force_small, monkey
     compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 80, mode)
 
 
+def test_small_trace_overflow_at_the_minimum_size(hip, oracle, force_small, monkeypatch):
+    """Global alignment at (32, 32): a slot keeps no checkpoint (its buffer-0 scalars are only ever the zeros written when it takes its pair), and a
+    slot that leaves because its trace region is exhausted hands exactly that to the solo driver (round-4 advisor finding)."""
+    monkeypatch.setenv("BA_TRACE_MARGIN_PCT", "30")
+    pairs = synth.make_pairs(600, (200, 1500), (10, 150), 40, synth.DNA, seed=43)
+    b = hip.BatchAligner(NUC, (-5, -1), (32, 32), 0, hip.TRACE | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_small"
+    b.run()
+    assert b.retried() > 0
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), (32, 32), 0, ("trace",))
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_small_dna_at_production_threshold(hip, oracle, mode):
     """No forcing, the release library: 60 k DNA pairs at 32..256 (the library takes k_small from 49152 pairs, 57344 with traceback)."""
@@ -97,3 +110,74 @@ def test_small_protein_at_production_threshold(hip, oracle, mode):
     w = W.config4(100000, seed=92, trace="trace" in mode)
     assert kernel_of(hip, w.matrix, w.gaps, w.size, 60 if "x_drop" in mode else 0, mode_bits(hip, mode, False), w.pairs) == "k_small"
     run_and_compare(hip, oracle, w.pairs, w.matrix, w.gaps, w.size, 60 if "x_drop" in mode else 0, mode, False, ("protein 32..256 k_small", mode))
+
+
+def _pssm_case(rng, length, block_max, indel=False):
+    """examples/pssm_bench.rs:43-98 shaped: PSSM rows = BLOSUM62 rows of a random consensus, position-specific gap costs (scan_block.rs:658-676)."""
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    cons = aa[rng.integers(0, 20, length)]
+    p = S.AAProfile(length, block_max, -1)
+    for i, c in enumerate(cons):
+        for b in aa:
+            p.set(i + 1, int(b), S.BLOSUM62.get(int(c), int(b)))
+    for i in range(length + 1):
+        p.set_gap_open_C(i, int(rng.integers(-14, -7)))
+        p.set_gap_open_R(i, int(rng.integers(-14, -7)))
+        if i >= 1:
+            p.set_gap_close_C(i, int(rng.integers(-3, 1)))
+    q = synth.mutate(rng, cons, int(0.3 * length), aa)
+    if indel and len(q) > 80:   # a long insertion or deletion: the pair grows in solo mode and comes back to its slot
+        at = int(rng.integers(20, len(q) - 20)); ln = int(rng.integers(10, 90))
+        q = np.concatenate([q[:at], synth.rand_str(rng, ln, aa), q[at:]]) if rng.random() < 0.5 else np.concatenate([q[:at], q[at + ln:]])
+    return q.astype(np.uint8).tobytes(), p
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("size", [(32, 32), (32, 256)])
+def test_small_profile(hip, oracle, force_small, mode, size):
+    """Sequence-to-profile slots (round 5): right steps read the profile's rows of the lane's residues and per-column gap costs, down steps the
+    rows of the column residues and per-cell gap costs with the roles of C and R exchanged (scan_block.rs:658-682); every pair its own PSSM and
+    position-specific costs; empty and shorter-than-a-block pairs share the waves. Compared with the oracle pair by pair."""
+    rng = np.random.default_rng(77 + size[1] + len(mode))
+    cases = [_pssm_case(rng, int(rng.integers(1, 600)), size[1], indel=(k % 3 == 0)) for k in range(500)]
+    cases.append((b"", cases[0][1]))
+    cases.append((cases[1][0], S.AAProfile(0, size[1], -1)))
+    pool = np.frombuffer(b"".join(q for q, _ in cases) + b"\0" * 8, np.uint8)
+    q_len = np.array([len(q) for q, _ in cases], np.uint32)
+    q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.uint64)
+    m = 0
+    for name in mode:
+        m |= {"trace": hip.TRACE, "x_drop": hip.X_DROP}[name]
+    b = hip.ProfileBatchAligner([p for _, p in cases], size, 30, m, pool, q_off, q_len)
+    assert b.info()["kernel"] == "k_small"
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"]) if "trace" in mode else (None, None)
+    for k, (q, p) in enumerate(cases):
+        ref = oracle.align_profile(q, p, size, 30, mode)
+        got = (int(res["score"][k]), int(res["query_idx"][k]), int(res["reference_idx"][k]), int(res["cells"][k]))
+        assert got == (ref["score"], ref["query_idx"], ref["reference_idx"], ref["cells"]), (k, len(q), p.str_len, got, ref)
+        if "trace" in mode:
+            assert hip.runs_to_string(runs[int(off[k]): int(off[k + 1])]) == ref["cigar"], k
+    b.close()
+
+
+def test_small_profile_at_production_threshold(hip, oracle):
+    """No forcing, the release library: 20 k PSSM alignments with traceback (the library takes k_small from 10000 profile pairs), every pair compared."""
+    assert hip.lib().ba_dev_build() == 0
+    w = W.config5(20000, seed=9)
+    b = W.make_batch(hip, w)
+    assert b.info()["kernel"] == "k_small"
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"])
+    ref = oracle.batch_align_profile(w.pairs.pool, w.pairs.q_off, w.pairs.q_len, w.profiles, w.size, w.x_drop, w.mode, threads=8)
+    assert np.array_equal(ref["scores"], res["score"]) and np.array_equal(ref["cells"], res["cells"].astype(np.uint64))
+    assert np.array_equal(ref["cig_len"], res["cigar_len"])
+    ln = ref["cig_len"].astype(np.int64)
+    start = np.repeat(ref["cig_off"].astype(np.int64), ln)
+    within = np.arange(int(ln.sum()), dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+    assert np.array_equal(ref["cig_ops"][start + within], runs[: int(off[len(w.profiles)])])
+    b.close()
