@@ -939,11 +939,12 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     const uint64_t slots = (uint64_t)b->grid * ba::WAVES_PER_WG * ba::SM_SLOTS;
     uint64_t thr = std::max<uint64_t>(total / std::max<uint64_t>(slots, 1) / 2, 1024);
     thr = std::max<uint64_t>(thr, 4 * (total / std::max<size_t>(n, 1)));   // ... and many times the batch's average length: a batch of equal pairs has none
+    // (no "the run did not end inside the cap" rule as in plan_walks: the protein set's 2048 longest of 400 k pairs fill the cap and are exactly the pairs
+    // meant -- with that rule none ran alone and the launch took 8.05 instead of 3.8 ms)
     if (const char* e = dev_env("BA_EXCL_LEN2")) thr = (uint64_t)std::max(0, atoi(e));
     const size_t cap = (size_t)b->grid * ba::WAVES_PER_WG / 2;
     size_t cnt = 0;
     while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
-    if (cnt == cap && n > cap && !dev_env("BA_EXCL_LEN2")) cnt = 0;   // (the run did not end inside the cap: these are ordinary pairs, as in plan_walks)
     b->sm_excl_n = (uint32_t)cnt;
     // TRACE: the longest of them -- at least half the longest pair's length, at most one wave in thirty-two -- get a launch of their own
     // beside the main one (batch_launch): their fill + walk is a serial chain that outlasts the rest of the batch (400 k protein pairs with
