@@ -144,8 +144,13 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             }
             table = tb_resolve(right_blk, table, nib);
             if (local && table == 0) {                                                   // scan_block.rs:1604-1611
-                const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
-                if ((z >> ((v & 1) * 16)) & 1) { stop = true; break; }
+                if (l2) {   // a slot's rectangle (32 cells x 8 columns, ba_small.hpp): a bit per cell, the columns of a cell in one byte, after the 32 trace words
+                    const uint32_t z = trace[tbase + 32 + (v >> 3) * 2 + ((v >> 2) & 1)];
+                    if ((z >> ((v & 3) * 8 + w)) & 1) { stop = true; break; }
+                } else {
+                    const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
+                    if ((z >> ((v & 1) * 16)) & 1) { stop = true; break; }
+                }
             }
             const Move m = tb_lut(right_blk, nib & 3, (nib >> 2) & 1, table);
             uint32_t op = m.op;
@@ -523,12 +528,22 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
         uint32_t nib;
         if (local) {   // no window in this mode: one cell per call
             if (!(s == 0 && fresh)) break;
-            const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
-            nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;
+            if (L2OK && t.l2) {
+                const uint32_t word = t.trace[t.tbase + (v >> 3) * 8 + (w >> 1) * 2 + ((v >> 2) & 1)];
+                nib = ((word >> ((v & 3) * 8 + (w & 1) * 4)) ^ 15u) & 15u;
+            } else {
+                const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
+                nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;
+            }
             t.table = tb_resolve(t.right, t.table, nib);
             if (t.table == 0) {   // zero mask (scan_block.rs:1604-1611)
-                const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
-                if ((z >> ((v & 1) * 16)) & 1) { t.i = t.j = 0; break; }
+                if (L2OK && t.l2) {
+                    const uint32_t z = t.trace[t.tbase + 32 + (v >> 3) * 2 + ((v >> 2) & 1)];
+                    if ((z >> ((v & 3) * 8 + w)) & 1) { t.i = t.j = 0; break; }
+                } else {
+                    const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
+                    if ((z >> ((v & 1) * 16)) & 1) { t.i = t.j = 0; break; }
+                }
             }
         } else {
             const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
@@ -788,7 +803,8 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     // The batch order is longest first and the launch ends with its longest walk: the first bp.walk_wave_n paths (ba_host.cpp plan_walks)
     // go one to a wave (walk_wave), one at a time from their own counter (work_counter[1]); the lanes start behind them. Few: such a walk
     // is scalar code, and a CU has one scalar unit for all its waves.
-    const uint32_t n_wave = (bp.flags & (F_LOCAL | F_FQS)) ? 0u : min(bp.walk_wave_n, bp.n);
+    const uint32_t spec_flags = bp.flags & (F_LOCAL | F_FQS);
+    const uint32_t n_wave = spec_flags ? 0u : min(bp.walk_wave_n, bp.n);
     if (n_wave) {
         __builtin_amdgcn_s_setprio(3);   // (the launch's longest chains: ahead of the lanes' walks on the same SIMD -- protein set with traceback +4 %)
         for (;;) {
@@ -855,6 +871,9 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             // (no fill wave shares the SIMD here: a call walks on while its window lasts; the mode bits as constants: a walk is a
             // serial chain of ~200 instructions per cell whose length, for the batch's longest pair, ends the launch)
             if (t.i > 0 || t.j > 0) {
+                // (k_small's LOCAL_START / FREE_QUERY_START_GAPS batches: the early stops, scan_block.rs:1597-1611)
+                if (LB == (int)TB_LANE_BYTES_L2 && spec_flags) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, spec_flags | (eq ? (uint32_t)F_CIGAR_EQ : 0u), bp.cig_ops, lrec, lut);
+                else
                 if (eq) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, (uint32_t)F_CIGAR_EQ, bp.cig_ops, lrec, lut);
                 else tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, 0u, bp.cig_ops, lrec, lut);
             }
@@ -1331,8 +1350,9 @@ struct Aligner {
             // bit 8: development switch, generic path only; profiles and the special modes also take the generic path
             BA_TSTAMP(tsa);
             // (plain: a shift step of a single-chunk block that cannot break early -- what the register path and a slot of the multi-pair kernels take)
-            const bool plain = !kBig && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !special && fast_eligible(ri, rh, lenV, rj, lenC);
-            const bool fast = plain && KIND != KIND_PROFILE;
+            // (LOCAL_START / FREE_QUERY_START_GAPS steps are a slot's too -- k_small's special instantiations --, FREE_QUERY_END_GAPS ones are not; none takes the register path)
+            const bool plain = !kBig && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !(special & F_FQE) && (!special || MULTI) && fast_eligible(ri, rh, lenV, rj, lenC);
+            const bool fast = plain && KIND != KIND_PROFILE && !special;
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
             if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && plain && !forced && block_size == SLOT_B && min_size == SLOT_B && !chain && !no_spec) {
                 // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
@@ -1639,7 +1659,7 @@ struct Aligner {
         }
         // pair-slot batches: pairs shorter than inline_len2 leave their paths to k_walk (one pair per lane) instead of this wave's lane 0
         // (walk_now: k_small's longest pairs, run one to a wave at the start of the launch -- their walks, the batch's longest, overlap with the fill)
-        const bool walk_later = TRACE && coldp()->trace_off && qlen + rlen < coldp()->inline_len2 && !(MULTI && walk_now);
+        const bool walk_later = TRACE && coldp()->trace_off && qlen + rlen < coldp()->inline_len2 && !(MULTI && walk_now && !SPECIAL);   // (the special modes' inline walk is one lane's: always k_walk's)
         if (TRACE && coldp()->cig_ops && !status && !walk_later) {
             // the trace words and rectangle list were written with plain stores and this slot's arena was read
             // during the previous pair's traceback: drain the stores and drop stale L1 lines before reading back
@@ -1679,7 +1699,7 @@ struct Aligner {
     // nor the borders after it): that step -- direction ck_dir at block position (ck_i, ck_j) -- is taken once more here, for the
     // location (returned in best_i / best_j; scan_block.rs:370-404) and the borders the reference's checkpoint holds (406-427).
     __device__ __forceinline__ void import_slot(const int (&reg)[16], const int (&ckr)[16], uint32_t pair_in, bool have_ck, bool ck_pre, int ck_dir, int ck_offadd, int ck_corner,
-                                                uint32_t ck_i, uint32_t ck_j, uint32_t& best_i, uint32_t& best_j) {
+                                                uint32_t ck_i, uint32_t ck_j, uint32_t& best_i, uint32_t& best_j, int ck_off = 0) {
         constexpr int SLOT_LANES = (int)SLOT_B / 8;   // the slot's lanes (8 cells each): 16 (k_multi) or 4 (k_small)
         const int lane = lane_id(), l8 = 8 * (lane & (SLOT_LANES - 1));
         const bool mine = lane < SLOT_LANES;
@@ -1703,27 +1723,32 @@ struct Aligner {
                 const int vc = 2 * lane < (int)SLOT_B ? (int)*(const unsigned short*)(seqV + cri + 2 * lane) : 0;
                 const unsigned long long cb = load_cols(seqC + crj);
                 FastOut fo{};
-                if constexpr (KIND != KIND_PROFILE) {
+                if constexpr (KIND != KIND_PROFILE && !SPECIAL) {
                     if (cright) fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
                     else fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
                 } else {
-                    // sequence-to-profile: the step through the generic rectangle code, on the LDS borders the checkpoint was just written to
-                    // (place_block_profile_right / _down + shift_and_offset, scan_block.rs:147-246); then the borders back into registers
+                    // sequence-to-profile / the special modes: the step through the generic rectangle code, on the LDS borders the checkpoint was just
+                    // written to (place_block[_profile_right / _down] + shift_and_offset, scan_block.rs:147-246); then the borders back into registers
                     const uint32_t pq_len = coldp()->q_len[pair_in], pr_len = coldp()->r_len[pair_in];
                     ProfileView pvv{};
-                    pvv.P = profile_positions(pr_len, h_max_size);
-                    pvv.pos_aa = (const signed char*)r;
-                    pvv.aa_pos = (const short*)(r + (uint64_t)pvv.P * 32);
-                    pvv.goC = pvv.aa_pos + (uint64_t)pvv.P * 32; pvv.clC = pvv.goC + pvv.P; pvv.goR = pvv.clC + pvv.P;
+                    if constexpr (KIND == KIND_PROFILE) {
+                        pvv.P = profile_positions(pr_len, h_max_size);
+                        pvv.pos_aa = (const signed char*)r;
+                        pvv.aa_pos = (const short*)(r + (uint64_t)pvv.P * 32);
+                        pvv.goC = pvv.aa_pos + (uint64_t)pvv.P * 32; pvv.clC = pvv.goC + pvv.P; pvv.goR = pvv.clC + pvv.P;
+                    }
+                    constexpr int PD_R = KIND == KIND_PROFILE ? 1 : 0, PD_D = KIND == KIND_PROFILE ? 2 : 0;
+                    const uint32_t spb = SPECIAL ? (((h_flags & F_LOCAL) ? SP_LOCAL : 0u) | (((h_flags & F_FQS) && cright) ? SP_FQS_ROW0 : 0u)) : 0u;
+                    const int crz = clamp16(-ck_off + ZERO);   // the step's relative zero (LOCAL_START / FREE_QUERY_START_GAPS)
                     short* t1 = L.misc + 16; short* t2 = L.misc + 32;
                     lds_fill0(t1, 32);
                     unsigned long long none = 0;
                     Best cur;
                     if (cright) {
-                        cur = place_rect<1, KIND, false, XDROP, 1>(L, fc, q, r, pq_len, pr_len, cri, crj, STEP, SLOT_B, L.D_col, L.C_col, t1, t2, ck_corner, 0, ck_offadd, nullptr, none, nullptr, 0u, nullptr, &pvv);
+                        cur = place_rect<1, KIND, false, XDROP, PD_R>(L, fc, q, r, pq_len, pr_len, cri, crj, STEP, SLOT_B, L.D_col, L.C_col, t1, t2, ck_corner, crz, ck_offadd, nullptr, none, nullptr, spb, nullptr, &pvv);
                         (void)lds_shift_and_offset(SLOT_B, L.D_row, L.R_row, t1, t2, ck_offadd);
                     } else {
-                        cur = place_rect<1, KIND, false, XDROP, 2>(L, fc, r, q, pr_len, pq_len, cri, crj, STEP, SLOT_B, L.D_row, L.R_row, t1, t2, ck_corner, 0, ck_offadd, nullptr, none, nullptr, 0u, nullptr, &pvv);
+                        cur = place_rect<1, KIND, false, XDROP, PD_D>(L, fc, r, q, pr_len, pq_len, cri, crj, STEP, SLOT_B, L.D_row, L.R_row, t1, t2, ck_corner, crz, ck_offadd, nullptr, none, nullptr, spb, nullptr, &pvv);
                         (void)lds_shift_and_offset(SLOT_B, L.D_col, L.C_col, t1, t2, ck_offadd);
                     }
                     fo.row = cur.row; fo.col = cur.col;

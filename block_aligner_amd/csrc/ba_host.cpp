@@ -79,6 +79,16 @@ BA_DECL_SM_KIND(0) BA_DECL_SM_KIND(1) BA_DECL_SM_KIND(2) BA_DECL_SM_KIND(3)
 #define BA_SMOROW(K) {ba_occupancy_sm_k##K##_p1, ba_occupancy_sm_k##K##_p2, ba_occupancy_sm_k##K##_p4, ba_occupancy_sm_k##K##_p8}
 static const LaunchFn g_launch_sm[4][4] = {BA_SMROW(0), BA_SMROW(1), BA_SMROW(2), BA_SMROW(3)};
 static const OccFn g_occ_sm[4][4] = {BA_SMOROW(0), BA_SMOROW(1), BA_SMOROW(2), BA_SMOROW(3)};
+// ... and its LOCAL_START / FREE_QUERY_START_GAPS instantiations (sequence kinds; the batch's flags choose)
+#define BA_DECL_SMS(K, P)                                                                                             \
+    extern "C" hipError_t ba_launch_sms_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);   \
+    extern "C" hipError_t ba_occupancy_sms_k##K##_p##P(int, int, unsigned, int*);
+#define BA_DECL_SMS_KIND(K) BA_DECL_SMS(K, 1) BA_DECL_SMS(K, 2) BA_DECL_SMS(K, 4) BA_DECL_SMS(K, 8)
+BA_DECL_SMS_KIND(0) BA_DECL_SMS_KIND(1) BA_DECL_SMS_KIND(2)
+#define BA_SMSROW(K) {ba_launch_sms_k##K##_p1, ba_launch_sms_k##K##_p2, ba_launch_sms_k##K##_p4, ba_launch_sms_k##K##_p8}
+#define BA_SMSOROW(K) {ba_occupancy_sms_k##K##_p1, ba_occupancy_sms_k##K##_p2, ba_occupancy_sms_k##K##_p4, ba_occupancy_sms_k##K##_p8}
+static const LaunchFn g_launch_sms[3][4] = {BA_SMSROW(0), BA_SMSROW(1), BA_SMSROW(2)};
+static const OccFn g_occ_sms[3][4] = {BA_SMSOROW(0), BA_SMSOROW(1), BA_SMSOROW(2)};
 extern "C" hipError_t ba_launch_walk_l2(hipStream_t, const BatchParams*, uint32_t grid);
 typedef hipError_t (*QuadFn)(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k0(int, int, unsigned, hipStream_t, const BatchParams*);
@@ -518,14 +528,15 @@ static void pipe_regions(const BaBatch* b, const uint32_t* ql, const uint32_t* r
                          std::vector<uint64_t>& boff) {
     toff.resize(n + 1); boff.resize(n + 1);
     const uint64_t mx = b->max_size, mn = b->min_size;
+    const uint64_t zm = (b->mode & BA_LOCAL_START) ? 5 : 1;   // (LOCAL_START: the zero masks, see batch_plan)
     // (k_small: the arena starts with the waves' sinks -- 64 lanes x 16 words each, where the slots without a step put their trace stores;
     // sized for any launch geometry: 4 workgroups of 8 waves per CU on up to 512 CUs)
     uint64_t t = b->small ? 512ull * 32 * 64 * 16 + 64 : 0, r = 0;
     t = (t + 15) & ~15ull;
     for (size_t p = 0; p < n; p++) {
         const uint64_t len2 = (uint64_t)ql[p] + rl[p] + 2;
-        const uint64_t full = (mx / 16) * (len2 + 2 * mx) * 2 + 64;
-        const uint64_t want = (len2 * mn / 8 + mx * mx / 8 + 16 * mx) * pct / 100 + 4096;
+        const uint64_t full = (mx / 16) * (len2 + 2 * mx) * 2 * zm + 64;
+        const uint64_t want = (len2 * mn / 8 + mx * mx / 8 + 16 * mx) * zm * pct / 100 + 4096;
         toff[p] = t; t += (std::min(want, full) + 15) & ~15ull;
         boff[p] = r; r += len2 / 4 + 64;
     }
@@ -562,7 +573,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? g_occ_m[kind][pc] : (b->small ? g_occ_sm[kind][pc] : g_occ[special_of(mode)][kind][pc]));
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? g_occ_m[kind][pc] : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
@@ -787,7 +798,15 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // 216. Below them the round-3 rules apply.
     size_t small_from = kind == BA_KIND_AA ? (trace_mode ? 98304u : 32768u) : (trace_mode ? 57344u : 49152u);
     if (profile) small_from = 10000u;   // (round 5: 11 k PSSM pairs 131 against 128 GCUPS, 20 k 227 against 208, 80 k 641 against 459; below: the round-2 pipeline)
-    b->small = !special_of(mode) && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
+    // (round 5: LOCAL_START / FREE_QUERY_START_GAPS batches of the sequence kinds too -- k_small's special instantiations; FREE_QUERY_END_GAPS stays per pair)
+    // Same-box sweep (tools/dev/local_sweep.py: 1 kbp DNA pairs behind 100..300 unrelated bases, X-drop 50, block 32..256; GCUPS k_small / per-pair
+    // kernel): LOCAL_START with traceback 50 k pairs 253 / 254, 100 k 378 / 301, 150 k 440 / 327, 250 k 503 / 352; without 50 k 610 / 836, 100 k 833 /
+    // 851, 150 k 917 / 848, 250 k 1009 / 857. FREE_QUERY_START_GAPS on the same pairs stays behind the per-pair kernel up to 250 k pairs (with
+    // traceback 100 k 581 / 682, 250 k 740 / 763; without 100 k 896 / 1144, 250 k 1090 / 1167): those batches take k_small only when forced.
+    const bool small_mode = !special_of(mode) || (!profile && !(mode & BA_FREE_QUERY_END_GAPS));
+    if (mode & BA_LOCAL_START) small_from = trace_mode ? 65536u : 131072u;
+    if ((mode & BA_FREE_QUERY_START_GAPS) && !dev_env("BA_FORCE_SMALL")) small_from = ~(size_t)0;
+    b->small = small_mode && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
     if (b->small) b->quad = false;
     // Pair-slot batches: every pair's trace stack stays in its own region of the arenas until the fill is over, then k_walk
     // walks all paths with one pair per lane. The small-block pipeline needs this form with TRACE; profile batches without small
@@ -795,7 +814,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // sequence pairs do not: their walks are few hundred steps, cheapest done at once by the fill wave's lane 0 (protein pairs,
     // 8k..65k pairs: 3 .. 20 % slower with k_walk, whose latest wave ends one longest-path walk after the fill).
     std::vector<uint64_t> toff, boff;
-    if (trace && !special_of(mode) && pc != BA_PCLASS_BIG && (b->quad || b->small || (profile && n >= 4096) || dev_env("BA_FORCE_PIPE"))) {
+    if (trace && (!special_of(mode) || b->small) && pc != BA_PCLASS_BIG && (b->quad || b->small || (profile && n >= 4096) || dev_env("BA_FORCE_PIPE"))) {
         const uint64_t fixed = total + cig_total * 4 + (uint64_t)n * (64 + sizeof(ba::PairCont) + 40);
         if (!dev_env("BA_NO_PIPE") && !pipe_cut(b.get(), ql.data(), rl.data(), n, fixed, toff, boff)) {
             b->pipe = true; b->pipe_words = toff[n] + toff[n] / 8; b->pipe_recs = boff[n] + boff[n] / 8;   // (headroom for ba_batch_reload)
@@ -1033,7 +1052,8 @@ static int batch_launch(BaBatch* b) {
         // (the pairs run one to a wave at the start of the launch -- the batch's longest -- walk their paths at once, with the whole wave:
         // the longest walk of the batch overlaps with the fill instead of ending the launch)
         BatchParams p1 = bp; p1.inline_len2 = ~0u;
-        const uint32_t side_n = (b->stream2 && (bp.cig_ops || !(b->mode & BA_TRACE)) && b->sm_side_n && b->sm_side_n <= b->sm_excl_n) ? b->sm_side_n : 0u;
+        const LaunchFn launch_sm = special_of(b->mode) ? g_launch_sms[b->kind][b->pclass] : g_launch_sm[b->kind][b->pclass];
+        const uint32_t side_n = (b->stream2 && !special_of(b->mode) && (bp.cig_ops || !(b->mode & BA_TRACE)) && b->sm_side_n && b->sm_side_n <= b->sm_excl_n) ? b->sm_side_n : 0u;
         uint32_t grid_main = b->grid;
         if (side_n) {
             // The longest pairs' launch: one wave per pair, workgroups taken off the main launch (together they fill the device as one
@@ -1049,11 +1069,11 @@ static int batch_launch(BaBatch* b) {
             ps.big = (short*)((char*)b->big.p + (size_t)grid_main * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES);
             ps.ckpt_wave0 = grid_main * ba::WAVES_PER_WG; ps.cq_side = 1;
             HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
-            HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_side, b->lds, b->stream2, &ps));
+            HIP_TRY(launch_sm((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_side, b->lds, b->stream2, &ps));
             HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
             p1.sm_excl_first = side_n;
         }
-        HIP_TRY(g_launch_sm[b->kind][b->pclass]((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_main, b->lds, b->stream, &p1));
+        HIP_TRY(launch_sm((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_main, b->lds, b->stream, &p1));
         if ((b->mode & BA_TRACE) && bp.cig_ops) {
             BatchParams pw = bp; pw.work_counter = b->counter.as<uint32_t>() + 16;   // (its own counters, zeroed with the others: the side launch may still be counting)
             HIP_TRY(ba_launch_walk_l2(b->stream, &pw, walk_grid(b)));

@@ -100,11 +100,16 @@ struct SmallProfile {
 // was staged in (pstage: this lane's 16 bytes of P_d, P_r 64 bytes behind) when the step shifts it -- eight registers fewer in the columns,
 // which is what keeps the loop of steps free of scratch reloads (a reload waits for every memory operation in flight, the step's trace
 // stores included: with 9 of them in the loop the TRACE kernels ran 1.6 x slower than the score-only ones).
-template <int KIND, bool TRACE, bool FIN>
+// SPM (round 5): the special alignment modes a slot takes -- 1 = LOCAL_START (every cell's D is at least the relative zero, scan_block.rs:1134-1136; TRACE: a
+// zero mask of one bit per cell behind the rectangle's trace words -- two words per lane: cells 0 .. 3 / 4 .. 7, byte = cell, bit = column), 2 =
+// FREE_QUERY_START_GAPS (row 0 of a right step starts from the relative zero in every column, scan_block.rs:1130-1132). rz2 = the relative zero, both halves.
+template <int KIND, bool TRACE, bool FIN, int SPM = 0>
 __device__ __forceinline__ void small_rect(const char* table, const FillConsts& fc, const SmallConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
                                            int (&Pd)[4], int (&Pr)[4], const char* pstage, uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add, bool first_cell,
-                                           uint32_t* __restrict__ tout, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o, SmallProfile* sp = nullptr) {
+                                           uint32_t* __restrict__ tout, bool fin_any, uint32_t fin_col, int (&dsel)[4], MultiOut& o, SmallProfile* sp = nullptr,
+                                           int rz2 = 0, bool fqs_row0 = false, int* zout = nullptr) {
     constexpr bool PROF = KIND == KIND_PROFILE;
+    uint32_t zacc[2] = {0, 0};   // LOCAL_START + TRACE: "D differs from the relative zero", inverted at the end
     const int offa = splat(off_add);
     int d[4], c[4];
 #pragma unroll
@@ -159,6 +164,8 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
         for (int k = 0; k < 4; k++) {
             d11[k] = adds(d00[k], sc[k]);
             if (j == 0 && k == 0) d11[0] = first_cell ? (int)(((uint32_t)d11[0] & 0xffff0000u) | (uint32_t)ZERO) : d11[0];   // cell (0,0) starts from the relative zero
+            if (SPM == 2 && k == 0) d11[0] = fqs_row0 ? (int)(((uint32_t)d11[0] & 0xffff0000u) | ((uint32_t)rz2 & 0xffffu)) : d11[0];   // row 0 of a right step: a free start in every column
+            if (SPM == 1) d11[k] = vmax(d11[k], rz2);   // a local alignment may start anywhere
             int goC = fc.go2, goR = fc.ome2;
             if constexpr (PROF) {   // position-specific costs: the column's (right) or the cell's (down), scan_block.rs:658-676
                 const int gsel = (j & 1) ? sp->selO : sp->selE;
@@ -194,6 +201,10 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
                 }
                 dmax[k] = vmax(dmax[k], dn[k]);
                 d[k] = dn[k]; c[k] = cn[k];
+            }
+            if (TRACE && SPM == 1) {   // zero mask (scan_block.rs:1184-1187): D >= the relative zero, so "differs" is the sign of rz - D
+                const uint32_t pZ = (uint32_t)__builtin_amdgcn_perm(subs(rz2, dn[2 * p2 + 1]), subs(rz2, dn[2 * p2]), 0x0b0a0908);
+                zacc[p2] |= pZ & (0x01010101u << j);
             }
             if (TRACE) {   // trace words: see multi_rect (4 consecutive cells x 2 columns per word, a lane's eight words contiguous)
                 const uint32_t pC = (uint32_t)__builtin_amdgcn_perm((int)sC[1], (int)sC[0], 0x0b0a0908), pR = (uint32_t)__builtin_amdgcn_perm((int)sR[1], (int)sR[0], 0x0b0a0908);
@@ -243,9 +254,10 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
 #pragma unroll
         for (int k = 0; k < 8; k++) sp->twords[k] = tdef[k];
     }
+    if constexpr (TRACE && SPM == 1) { zout[0] = (int)~zacc[0]; zout[1] = (int)~zacc[1]; }
 }
 
-template <int PMAX, int KIND, bool TRACE, bool XDROP>
+template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0>
 #ifndef SM_WAVES_EU
 #define SM_WAVES_EU 4   // (waves per SIMD the kernel is compiled for; 2 -- 256 registers -- was tried for the traced kernels: see DESIGN.md)
 #endif
@@ -278,6 +290,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
     const int gx = bp.gap_extend;
     const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
     const uint32_t max_size = bp.max_size;
+    // a slot rectangle's words on the trace stack. LOCAL_START: the zero mask takes 8 words behind the 32 trace words, but the stack advances as the
+    // per-pair kernel's does (4 mask words per trace word, Aligner::add_block), so that a pair's trace words count its cells the same way on every path
+    constexpr uint32_t SM_TW = (STEP * SM_B / 8) * (SPM == 1 ? 5u : 1u);
     const bool keep_pre = XDROP || (uint32_t)SM_B < max_size;   // a slot keeps the state before its last improving step
     char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * SM_WAVE_BYTES;
 
@@ -323,7 +338,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 fc.vconst = pk(v[0], v[1]);
                 fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
             }
-            Aligner<PMAX, KIND, TRACE, XDROP, false, true, SM_B> al(bp, L, fc);
+            Aligner<PMAX, KIND, TRACE, XDROP, SPM != 0, true, SM_B> al(bp, L, fc);
             PairState st{};
             char* const smem_s = wave_mem + (uint32_t)solo * SM_SLOT_BYTES;
             char* const rec = smem_s + 2 * SM_BUF_BYTES;
@@ -351,7 +366,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                     st.status = (uint32_t)BA_W(rv, MR_STATUS);
                     const bool ck_pre = flag != 0;
                     st.ck_i = (uint32_t)BA_W(cv, 1); st.ck_j = (uint32_t)BA_W(cv, 2); st.ck_off = BA_W(cv, 3);
-                    st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * SM_B / 8 : 0u);
+                    st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? SM_TW : 0u);
                     st.ck_nb = (uint32_t)BA_W(cv, 5) - (TRACE ? (uint32_t)bp.blocks_off[s_pair] : 0u) + (flag ? 1u : 0u);   // (staged as an absolute record position)
                     const int ck_dir = (BA_W(cv, 0) >> 8) & 0xff, ck_offadd = BA_W(cv, 6), ck_corner = BA_W(cv, 7);
                     {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 3), into the canonical order D_col, C_col, D_row, R_row
@@ -364,7 +379,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                             reg[k] = mq_load(live_b + oAd + 4 * k); reg[4 + k] = mq_load(live_b + oAc + 4 * k); reg[8 + k] = mq_load(live_b + oPd + 4 * k); reg[12 + k] = mq_load(live_b + oPr + 4 * k);
                             ckr[k] = mq_load(ck_b + cAd + 4 * k); ckr[4 + k] = mq_load(ck_b + cAc + 4 * k); ckr[8 + k] = mq_load(ck_b + cPd + 4 * k); ckr[12 + k] = mq_load(ck_b + cPr + 4 * k);
                         }
-                        al.import_slot(reg, ckr, s_pair, ck_pre || (uint32_t)SM_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j);
+                        al.import_slot(reg, ckr, s_pair, ck_pre || (uint32_t)SM_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j, st.ck_off);
                     }
                 }
             }
@@ -451,7 +466,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             // the number of steps region and record list still have room for
             uint32_t tr16 = 0, bpos = 0; int room = 0;
             auto room_of = [](uint32_t tcap, uint32_t bcap, uint32_t tt, uint32_t nb) -> int {
-                const uint32_t a = tcap >= tt + 64u ? (tcap - 64u - tt) / (STEP * SM_B / 8) : 0u, b = bcap > nb ? bcap - nb : 0u;
+                const uint32_t a = tcap >= tt + 64u ? (tcap - 64u - tt) / SM_TW : 0u, b = bcap > nb ? bcap - nb : 0u;
                 return (int)min(min(a, b), 0x7fffffffu);
             };
             if (TRACE && live0) {
@@ -690,8 +705,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 int dsel[4] = {0, 0, 0, 0};
                 int Pn_d[4], Pn_r[4];   // the orthogonal border pair after the step
                 MultiOut o;
-                small_rect<KIND, TRACE, !XDROP>(smem, fq, mc, l, A_d, A_c, Pn_d, Pn_r, lbuf + (sel ^ 1u) * 256u + 128u + l * 16, vb, cbv.x, cbv.y, corner, off_add, run && boot == NBOOT && l == 0, tw,
-                                                fin_any, fin ? fin_col : 8u, dsel, o, KIND == KIND_PROFILE ? &spf : nullptr);
+                int zw[2] = {0, 0};
+                small_rect<KIND, TRACE, !XDROP, SPM>(smem, fq, mc, l, A_d, A_c, Pn_d, Pn_r, lbuf + (sel ^ 1u) * 256u + 128u + l * 16, vb, cbv.x, cbv.y, corner, off_add,
+                                                     run && boot == NBOOT && l == 0 && SPM != 1, tw, fin_any, fin ? fin_col : 8u, dsel, o, KIND == KIND_PROFILE ? &spf : nullptr,
+                                                     SPM ? splat(sat16(ZERO - off_n)) : 0, SPM == 2 && right && ri == 0u && l == 0, zw);
+                if (TRACE && SPM == 1) *(int2*)(tw - 8 * l + 32 + 2 * l) = int2{zw[0], zw[1]};   // the rectangle's zero mask behind its 32 trace words (idle slots: the sink)
 #ifndef SM_PREFETCH_EARLY
                 // sequence bytes of the step after this one, whichever way it goes: issued behind the columns (the eight registers are not live
                 // across them; consecutive steps read consecutive bytes, mostly out of the L1). The alternative -- issued at the top, in flight
@@ -741,7 +759,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                         if (bp.cells) bp.cells[pair] = cells0 + (unsigned long long)nsteps * (STEP * SM_B) + (unsigned long long)(fin_col + 1u) * SM_B;
                         if (bp.status) bp.status[pair] = (uint32_t)mq_load(rcp + 4 * MR_STATUS);
                         if (bp.nblocks_out) bp.nblocks_out[pair] = nb1;
-                        if (bp.trace_words_out) bp.trace_words_out[pair] = TRACE ? trace_top + STEP * SM_B / 8 : 0;
+                        if (bp.trace_words_out) bp.trace_words_out[pair] = TRACE ? trace_top + SM_TW : 0;
                         if (bp.slot_out) bp.slot_out[pair] = pair;
                         if (TRACE) bp.slot_info[pair] = SlotInfo{pair, nb1, qlen, rlen};
                     }
@@ -751,7 +769,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                 leave = leave || again || (run && stop && !bsub && !blast && !fin);   // rolled back: the pair's state is what was staged before this step
                 if (bsub) {
                     sj += STEP; bits -= 1u;
-                    if (TRACE) { trace_top += STEP * SM_B / 8; bpos++; room--; }
+                    if (TRACE) { trace_top += SM_TW; bpos++; room--; }
                 }
                 bool swap = false;
                 if (commit) {
@@ -760,7 +778,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
                         best_max = new_off_max;
                     }
                     off = off_n; off_max = new_off_max; ymix = (int)new_y; D_corner = blast ? 0 : o.corner_new;
-                    if (TRACE) { trace_top += STEP * SM_B / 8; bpos++; room--; }
+                    if (TRACE) { trace_top += SM_TW; bpos++; room--; }
                     const uint32_t nx = (XDROP && off_max < best_max - x_drop) ? (uint32_t)x_iter + 1u : 0u;
                     bits = ((uint32_t)(blast ? DIR_GROW : dir) << 4) | (nx << 6);   // boot = 0, no restart flag
                     const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)

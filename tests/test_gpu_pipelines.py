@@ -19,7 +19,7 @@ MODES = [(), ("x_drop",), ("trace",), ("trace", "x_drop")]
 def mode_bits(H, mode, cigar_eq):
     m = 0
     for k in mode:
-        m |= {"trace": H.TRACE, "x_drop": H.X_DROP}[k]
+        m |= {"trace": H.TRACE, "x_drop": H.X_DROP, "local_start": H.LOCAL_START, "free_query_start_gaps": H.FREE_QUERY_START_GAPS}[k]
     if cigar_eq and "trace" in mode:
         m |= H.CIGAR_EQ
     return m

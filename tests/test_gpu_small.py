@@ -95,6 +95,54 @@ def test_small_trace_overflow_at_the_minimum_size(hip, oracle, force_small, monk
     compare(hip, oracle, pairs, NUC, (-5, -1), (32, 32), 0, ("trace",))
 
 
+SPECIAL_MODES = [("trace", "local_start"), ("trace", "x_drop", "local_start"), ("local_start",), ("x_drop", "local_start"), ("trace", "free_query_start_gaps"),
+                 ("trace", "x_drop", "free_query_start_gaps"), ("free_query_start_gaps",)]
+
+
+def _flanked_pairs(n, seed):
+    """Related cores behind unrelated flanks of different lengths (what LOCAL_START skips), plus queries cut out of a longer reference (what
+    FREE_QUERY_START_GAPS skips), plus ordinary related pairs with indels."""
+    rng = np.random.default_rng(seed)
+    lists = []
+    for k in range(n):
+        core = synth.rand_str(rng, int(rng.integers(40, 900)), synth.DNA)
+        other = synth.mutate(rng, core, int(rng.integers(0, 1 + len(core) // 10)), synth.DNA)
+        if k % 3 == 0:
+            q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 120)), synth.DNA), core])
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 120)), synth.DNA), other])
+        elif k % 3 == 1:
+            q = core
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 300)), synth.DNA), other, synth.rand_str(rng, int(rng.integers(0, 100)), synth.DNA)])
+        else:
+            q, r = core, other
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    return synth.PairSet.from_lists(lists)
+
+
+@pytest.mark.parametrize("mode", SPECIAL_MODES)
+@pytest.mark.parametrize("size", [(32, 32), (32, 256)])
+def test_small_local_and_free_start(hip, oracle, force_small, mode, size):
+    """Round 5: the slots take LOCAL_START / FREE_QUERY_START_GAPS steps too (k_small's special instantiations): every cell at least the
+    relative zero, a zero mask of one bit per cell behind a slot rectangle's trace words (scan_block.rs:1130-1136, 1184-1187, 1597-1611)."""
+    m = 0
+    for k in mode:
+        m |= {"trace": hip.TRACE, "x_drop": hip.X_DROP, "local_start": hip.LOCAL_START, "free_query_start_gaps": hip.FREE_QUERY_START_GAPS}[k]
+    pairs = _flanked_pairs(600, 70 + size[1])
+    assert kernel_of(hip, NUC, (-5, -1), size, 60, m, pairs) == "k_small"
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 60, mode)
+    pairs = synth.make_pairs(400, (0, 1500), (0, 150), 40, synth.DNA, seed=71 + size[1], indels=2, indel_len=(5, 100))
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 60, mode)
+    w = W.config4(800, seed=9, trace="trace" in mode)
+    compare(hip, oracle, w.pairs, w.matrix, w.gaps, size, 60, mode)
+
+
+def test_small_free_query_end_gaps_stays_per_pair(hip, force_small):
+    """FREE_QUERY_END_GAPS needs the mode's running column maxima (scan_block.rs:1189-1201): not a slot's."""
+    pairs = synth.make_pairs(100, (5, 25), (0, 3), 0, synth.DNA, seed=3)
+    assert kernel_of(hip, NUC, (-5, -1), (32, 128), 0, hip.FREE_QUERY_END_GAPS, pairs) != "k_small"
+    assert kernel_of(hip, NUC, (-5, -1), (32, 128), 0, hip.FREE_QUERY_END_GAPS | hip.LOCAL_START, pairs) != "k_small"
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_small_dna_at_production_threshold(hip, oracle, mode):
     """No forcing, the release library: 60 k DNA pairs at 32..256 (the library takes k_small from 49152 pairs, 57344 with traceback)."""
@@ -102,6 +150,18 @@ def test_small_dna_at_production_threshold(hip, oracle, mode):
     pairs = synth.make_pairs(60000, (0, 1500), (0, 150), 40, synth.DNA, seed=812, indels=1, indel_len=(5, 60))
     assert kernel_of(hip, NUC, (-5, -1), (32, 256), 100, mode_bits(hip, mode, True), pairs) == "k_small"
     run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 100, mode, True, ("dna 32..256 k_small", mode))
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop", "local_start"), ("x_drop", "local_start")])
+def test_small_local_start_at_production_threshold(hip, oracle, mode):
+    """No forcing, the release library: LOCAL_START batches take k_small from 65536 pairs with traceback, 131072 without; FREE_QUERY_START_GAPS batches
+    stay with the per-pair kernel (ba_host.cpp: measured)."""
+    assert hip.lib().ba_dev_build() == 0
+    n = 70000 if "trace" in mode else 135000
+    pairs = _flanked_pairs(n, 5)
+    assert kernel_of(hip, NUC, (-5, -1), (32, 256), 50, mode_bits(hip, mode, True), pairs) == "k_small"
+    assert kernel_of(hip, NUC, (-5, -1), (32, 256), 50, mode_bits(hip, ("trace", "x_drop", "free_query_start_gaps"), True), pairs) != "k_small"
+    run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (32, 256), 50, mode, True, ("dna local 32..256 k_small", mode))
 
 
 @pytest.mark.parametrize("mode", MODES)
