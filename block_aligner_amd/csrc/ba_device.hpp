@@ -505,7 +505,12 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
     int top_d_hold = below ? tc->corner0 : 0, top_d_next = 0, top_r_next = 0;
     if (below) { top_d_next = load_uniform_i16(tc->topD); top_r_next = load_uniform_i16(tc->topR); }
     const int rz2 = splat(rel_zero);
-    const uint32_t zwords = (width >> 2) * (uint32_t)((tc ? tc->nch_total : NCH) * nl);   // SP_LOCAL: the zero mask follows the (whole) rectangle's trace words
+    // SP_LOCAL: every trace word is followed by the zero mask of its cells (scan_block.rs:1184-1187) -- bit 0 of the cell's nibble position; the
+    // walk's window takes both with the same loads
+    const uint32_t tmul = (TRACE && (sp & SP_LOCAL)) ? 2u : 1u;
+    int zacc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) zacc[ch] = 0;
     int corner_cur = corner;
     int cvec = PDIR == 1 ? 0 : (int)seqC[start_j + (lane & 7)];   // 8 column bytes at a time, one per lane (lanes 0..7)
     // Profiles, blocks up to 256 cells: the scores (and per-position gap costs) of a whole group of 8 columns are fetched
@@ -633,8 +638,7 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
                 nib = pk_mad_k<4>(nCo, nib);
                 nib = pk_mad_k<8>(nRo, nib);
                 tacc[ch] |= nib << ((j & 3) * 4);
-                if ((sp & SP_LOCAL) && active)    // zero mask (scan_block.rs:1184-1187): one word per lane and column
-                    trace_out[zwords + (j * NCHT + CHB + ch) * nl + lane] = (uint32_t)eq01(dn, rz2, fc.ones);
+                if (sp & SP_LOCAL) zacc[ch] |= eq01(dn, rz2, fc.ones) << ((j & 3) * 4);
             }
             if (sp & SP_FQE) {
                 // D_max / argmax_j of vector lane k = len % 16 in the reference's visiting order (columns outer, vectors
@@ -668,10 +672,14 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         if (TRACE && (j & 3) == 3) {
             if (active) {
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCHT + CHB + ch) * nl + lane] = (uint32_t)tacc[ch];
+                for (int ch = 0; ch < NCH; ch++) {
+                    const uint32_t at = (((j >> 2) * NCHT + CHB + ch) * nl + lane) * tmul;
+                    if (sp & SP_LOCAL) *(uint2*)(trace_out + at) = uint2{(uint32_t)tacc[ch], (uint32_t)zacc[ch]};
+                    else trace_out[at] = (uint32_t)tacc[ch];
+                }
             }
 #pragma unroll
-            for (int ch = 0; ch < NCH; ch++) tacc[ch] = 0;
+            for (int ch = 0; ch < NCH; ch++) { tacc[ch] = 0; zacc[ch] = 0; }
         }
         // last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214)
         if (last_lane) { Dr[j] = (short)(d[NCH - 1] >> 16); Rr[j] = (short)(r_last >> 16); }
@@ -683,7 +691,11 @@ __device__ __forceinline__ Best place_rect(const WaveLds& L, const FillConsts& f
         if (break_armed && start_j + j >= lenC) {   // scan_block.rs:1216-1224
             if (TRACE && (j & 3) != 3 && active) {
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) trace_out[((j >> 2) * NCHT + CHB + ch) * nl + lane] = (uint32_t)tacc[ch];
+                for (int ch = 0; ch < NCH; ch++) {
+                    const uint32_t at = (((j >> 2) * NCHT + CHB + ch) * nl + lane) * tmul;
+                    if (sp & SP_LOCAL) *(uint2*)(trace_out + at) = uint2{(uint32_t)tacc[ch], (uint32_t)zacc[ch]};
+                    else trace_out[at] = (uint32_t)tacc[ch];
+                }
             }
             return false;
         }

@@ -139,7 +139,8 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
                 const uint32_t word = trace[tbase + (v >> 3) * 8 + (w >> 1) * 2 + ((v >> 2) & 1)];
                 nib = ((word >> ((v & 3) * 8 + (w & 1) * 4)) ^ 15u) & 15u;
             } else {
-                const uint32_t word = trace[tbase + ((w >> 2) * nch + chunk) * nl + lane];
+                // (LOCAL_START batches: a trace word is followed by its cells' zero-mask word, place_rect)
+                const uint32_t word = trace[tbase + (((w >> 2) * nch + chunk) * nl + lane) * (local ? 2u : 1u)];
                 nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;   // all four bits are stored as "differs"
             }
             table = tb_resolve(right_blk, table, nib);
@@ -148,8 +149,8 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
                     const uint32_t z = trace[tbase + 32 + (v >> 3) * 2 + ((v >> 2) & 1)];
                     if ((z >> ((v & 3) * 8 + w)) & 1) { stop = true; break; }
                 } else {
-                    const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (w * nch + chunk) * nl + lane];
-                    if ((z >> ((v & 1) * 16)) & 1) { stop = true; break; }
+                    const uint32_t z = trace[tbase + (((w >> 2) * nch + chunk) * nl + lane) * 2u + 1u];
+                    if ((z >> ((v & 1) * 16 + (w & 3) * 4)) & 1) { stop = true; break; }
                 }
             }
             const Move m = tb_lut(right_blk, nib & 3, (nib >> 2) & 1, table);
@@ -364,11 +365,11 @@ constexpr int TB_CELLS_PER_STEP = 4;
 template <int CELLS = TB_CELLS_PER_STEP, int DEPTH = 1, int LB = (int)TB_LANE_BYTES>
 __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __restrict__ out, unsigned char* lrec,
                                         const unsigned char* lut, unsigned long long* tacc = nullptr) {
-    constexpr bool L2OK = LB == (int)TB_LANE_BYTES_L2;
-    constexpr int SEQ_Q = L2OK ? 64 : 40, SEQ_R = SEQ_Q + 16;   // byte offsets of the sequence windows in the record
-    const bool eq = flags & F_CIGAR_EQ, local = flags & F_LOCAL, fqs = flags & F_FQS;
+    constexpr bool LOCREC = LB == (int)TB_LANE_BYTES_LOC;   // records with room for the zero-mask bits: the only ones LOCAL_START walks use
+    constexpr bool L2OK = LB == (int)TB_LANE_BYTES_L2 || LOCREC;
+    constexpr int SEQ_Q = LOCREC ? 80 : (L2OK ? 64 : 40), SEQ_R = SEQ_Q + 16;   // byte offsets of the sequence windows in the record
+    const bool eq = flags & F_CIGAR_EQ, local = LOCREC && (flags & F_LOCAL), fqs = flags & F_FQS;
     BA_TSTAMP(ts0);
-    bool fresh = true;   // LOCAL_START only: may this call still issue a direct load?
     if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
         bool found = false, untraced = false;
 #pragma unroll
@@ -413,17 +414,36 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
             // (column >> 1) * 2 + cell quad); the window is the two 8-cell lanes ending at the cell's: 64 contiguous bytes, four
             // 16-byte loads into one cache line (mostly). tw_lane0: the first lane8.
             const uint32_t L8 = v >> 3;
-            if (!local && !(t.tw_ok && t.tw_chunk == 0xffffu && L8 - t.tw_lane0 < 2u)) {
+            if (!(t.tw_ok && t.tw_chunk == 0xffffu && L8 - t.tw_lane0 < 2u)) {
                 t.tw_chunk = 0xffffu; t.tw_g = 0; t.tw_lane0 = L8 ? L8 - 1 : 0u; t.tw_ok = true;
                 const uint32_t* wp = t.trace + t.tbase + t.tw_lane0 * 8;
                 uint4 a0, a1, a2, a3;
                 __builtin_memcpy(&a0, wp, 16); __builtin_memcpy(&a1, wp + 4, 16); __builtin_memcpy(&a2, wp + 8, 16); __builtin_memcpy(&a3, wp + 12, 16);
                 uint4* lw = (uint4*)lrec;
                 lw[0] = a0; lw[1] = a1; lw[2] = a2; lw[3] = a3;
-                fresh = false;
+                if (local) {   // the two lanes' zero-mask words (k_small: two per lane behind the rectangle's 32 trace words), at record bytes 64 .. 79
+                    uint4 z;
+                    __builtin_memcpy(&z, t.trace + t.tbase + 32 + t.tw_lane0 * 2, 16);
+                    lw[4] = z;
+                }
             }
         } else
-        if (!local && !(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u)) {
+        if (local) {
+            // LOCAL_START batches, per-pair rectangles: every trace word is followed by its cells' zero-mask word (place_rect) -- the same window
+            // of two column groups x five lanes is 2 x 10 contiguous words
+            if (!(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u)) {
+                t.tw_chunk = chunk; t.tw_g = g; t.tw_lane0 = min(lc >= 4 ? lc - 4 : 0u, t.nl - 5u); t.tw_ok = true;
+                const uint32_t* hi = t.trace + t.tbase + ((g * t.nch + chunk) * t.nl + t.tw_lane0) * 2u;
+                const uint32_t* lo = g ? hi - t.nch * t.nl * 2u : hi;
+                uint4 h0, h1, l0, l1; uint2 h2, l2;
+                __builtin_memcpy(&h0, hi, 16); __builtin_memcpy(&h1, hi + 4, 16); __builtin_memcpy(&h2, hi + 8, 8);
+                __builtin_memcpy(&l0, lo, 16); __builtin_memcpy(&l1, lo + 4, 16); __builtin_memcpy(&l2, lo + 8, 8);
+                uint32_t* lw = (uint32_t*)lrec;
+                lw[0] = h0.x; lw[1] = h0.y; lw[2] = h0.z; lw[3] = h0.w; lw[4] = h1.x; lw[5] = h1.y; lw[6] = h1.z; lw[7] = h1.w; lw[8] = h2.x; lw[9] = h2.y;
+                lw[10] = l0.x; lw[11] = l0.y; lw[12] = l0.z; lw[13] = l0.w; lw[14] = l1.x; lw[15] = l1.y; lw[16] = l1.z; lw[17] = l1.w; lw[18] = l2.x; lw[19] = l2.y;
+            }
+        } else
+        if (!(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u)) {
             // the two column groups ending at the cell's and the five lanes ending at the cell's
             // (five consecutive words per group: one 16-byte and one 4-byte load each -- the walks of a wave are in 64 different
             // places, so every load instruction is 64 transactions; the window is pushed down where it would pass the last lane)
@@ -439,7 +459,6 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
             }
 #pragma unroll
             for (int k = 0; k < 10; k++) ((uint32_t*)lrec)[k] = wv[k];
-            fresh = false;
         }
         if (eq) {   // refill the sequence windows when fewer than 8 positions are left below the current one
             if (t.qw0 == 0xffffffffu || t.i < t.qw0 + 8 || t.i >= t.qw0 + 16) {
@@ -468,9 +487,9 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
     if (tacc) { tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; }
 #endif
-    if (!local) {
+    {
         // Straight-line, predicated: the lanes of the wave are at different places of different walks, so every `break`
-        // of the plain loop below is an exec-mask region that all of them pay for (it had ~15 per cell). `alive` = this
+        // of a plain loop is an exec-mask region that all of them pay for (it had ~15 per cell). `alive` = this
         // lane still walks in this call; a lane that is not alive computes on clamped indices and commits nothing.
         bool alive = true;
 #pragma unroll
@@ -485,21 +504,29 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
                 alive = alive && !stop;
             }
             const uint32_t gi = t.tw_g - (w >> 2);
-            uint32_t baddr;
+            uint32_t baddr, zaddr = 0, zbit = 0;   // (zaddr / zbit: LOCAL_START -- the cell's zero-mask bit in the record)
             if (L2OK && t.l2) {
                 const uint32_t k8 = (v >> 3) - t.tw_lane0;
                 alive = alive && t.tw_chunk == 0xffffu && k8 <= 1u;
                 baddr = k8 * 32 + (w >> 1) * 8 + ((v >> 2) & 1) * 4 + (v & 3);
+                zaddr = 64 + k8 * 8 + ((v >> 2) & 1) * 4 + (v & 3); zbit = w;
             } else {
                 const uint32_t k = lc - t.tw_lane0;
                 alive = alive && (v >> 7) == t.tw_chunk && gi <= 1u && k <= 4u;             // else: left the window, the next call reloads it
-                baddr = gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1);
+                baddr = local ? gi * 40 + k * 8 + (v & 1) * 2 + ((w & 3) >> 1) : gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1);
+                zaddr = baddr + 4; zbit = (w & 1) * 4;
             }
             const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
             const uint32_t byte = lrec[alive ? baddr : 0u];
             const uint32_t qb = lrec[SEQ_Q + (qo & 15u)], rb = lrec[SEQ_R + (ro & 15u)];    // for a match at this cell (read alongside, used if needed)
             const uint32_t nib = ((byte >> ((w & 1) * 4)) ^ 15u) & 15u;                      // all four bits stored as "differs"
             const uint32_t table = tb_resolve(t.right, t.table, nib);
+            if (local) {                                                                    // scan_block.rs:1604-1611: the path starts at a cell whose D is the zero
+                const uint32_t zb = lrec[alive ? zaddr : 0u];
+                const bool stop = alive && table == 0 && ((zb >> zbit) & 1u);
+                if (stop) t.i = t.j = 0;
+                alive = alive && !stop;
+            }
             const uint32_t m = lut[((uint32_t)t.right << 6) | (table << 4) | nib];          // op | di << 3 | dj << 4 | next << 5
             uint32_t op = m & 7u;
             const uint32_t di = (m >> 3) & 1u, dj = (m >> 4) & 1u;
@@ -517,53 +544,6 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
             t.run_len = alive ? (same ? t.run_len + 1 : 1u) : t.run_len;
             t.run_op = alive ? op : t.run_op;
         }
-        return;
-    }
-    for (int s = 0; s < CELLS; s++) {
-        if (!(t.i > 0 || t.j > 0) || !(t.i >= t.bi && t.j >= t.bj)) break;
-        const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
-        const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
-        const uint32_t lc = (v & 127) >> 1;
-        if (t.right && fqs && t.i == 0) { t.i = t.j = 0; break; }                       // scan_block.rs:1597-1599
-        uint32_t nib;
-        if (local) {   // no window in this mode: one cell per call
-            if (!(s == 0 && fresh)) break;
-            if (L2OK && t.l2) {
-                const uint32_t word = t.trace[t.tbase + (v >> 3) * 8 + (w >> 1) * 2 + ((v >> 2) & 1)];
-                nib = ((word >> ((v & 3) * 8 + (w & 1) * 4)) ^ 15u) & 15u;
-            } else {
-                const uint32_t word = t.trace[t.tbase + ((w >> 2) * t.nch + (v >> 7)) * t.nl + lc];
-                nib = ((word >> ((v & 1) * 16 + (w & 3) * 4)) ^ 15u) & 15u;
-            }
-            t.table = tb_resolve(t.right, t.table, nib);
-            if (t.table == 0) {   // zero mask (scan_block.rs:1604-1611)
-                if (L2OK && t.l2) {
-                    const uint32_t z = t.trace[t.tbase + 32 + (v >> 3) * 2 + ((v >> 2) & 1)];
-                    if ((z >> ((v & 3) * 8 + w)) & 1) { t.i = t.j = 0; break; }
-                } else {
-                    const uint32_t z = t.trace[t.tbase + t.zoff + (w * t.nch + (v >> 7)) * t.nl + lc];
-                    if ((z >> ((v & 1) * 16)) & 1) { t.i = t.j = 0; break; }
-                }
-            }
-        } else {
-            const uint32_t gi = t.tw_g - (w >> 2), k = lc - t.tw_lane0;
-            if ((v >> 7) != t.tw_chunk || gi > 1u || k > 4u) break;                     // left the window: next call reloads it
-            const uint32_t byte = lrec[gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1)];
-            nib = ((byte >> ((w & 1) * 4)) ^ 15u) & 15u;                                 // all four bits stored as "differs"
-            t.table = tb_resolve(t.right, t.table, nib);
-        }
-        const uint32_t m = lut[((uint32_t)t.right << 6) | (t.table << 4) | nib];        // op | di << 3 | dj << 4 | next << 5
-        uint32_t op = m & 7u;
-        const uint32_t di = (m >> 3) & 1u, dj = (m >> 4) & 1u;
-        if (eq && op == 1) {
-            const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
-            if (qo > 15u || ro > 15u) break;                                            // next call refills the windows
-            op = lrec[SEQ_Q + qo] == lrec[SEQ_R + ro] ? 2 : 3;
-        }
-        if (di > t.i || dj > t.j) { tb_fail(t); return; }   // would leave the matrix: corrupt trace
-        t.i -= di; t.j -= dj; t.table = tb_next(t.right, m >> 5, v);
-        if (op == t.run_op) t.run_len++;
-        else { tb_emit(t, out); t.run_op = op; t.run_len = 1; }
     }
 }
 
@@ -781,10 +761,11 @@ __device__ __forceinline__ void traceback_helper_wave(const BatchParams& bp, uin
 // batch after its fill kernels, one pair per LANE, all 64 lanes of every wave walking (tb_step). Lanes that finish take the
 // next pairs of the batch order (longest first, so the lanes of a wave walk paths of similar length) with one atomic per wave.
 // L2OK: the batch holds slot rectangles of k_small (words of 4 cells x 2 columns, see multi_rect): the lanes' records are TB_LANE_BYTES_L2 bytes
-template <bool L2OK = false>
+// LOC: a LOCAL_START / FREE_QUERY_START_GAPS batch of k_small (records with room for the zero-mask bits; the early stops of scan_block.rs:1597-1611)
+template <bool L2OK = false, bool LOC = false>
 __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t flag_mask, unsigned char* tb_lds) {
-    constexpr int LB = L2OK ? (int)TB_LANE_BYTES_L2 : (int)TB_LANE_BYTES;
-    constexpr uint32_t WAVE_LDS = L2OK ? TB_LDS_BYTES_L2 : TB_LDS_BYTES;
+    constexpr int LB = LOC ? (int)TB_LANE_BYTES_LOC : (L2OK ? (int)TB_LANE_BYTES_L2 : (int)TB_LANE_BYTES);
+    constexpr uint32_t WAVE_LDS = LOC ? TB_LDS_BYTES_LOC : (L2OK ? TB_LDS_BYTES_L2 : TB_LDS_BYTES);
     const uint32_t eq = bp.flags & flag_mask;
     unsigned char* lut = tb_lds;
     unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * (uint32_t)LB;
@@ -804,7 +785,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     // go one to a wave (walk_wave), one at a time from their own counter (work_counter[1]); the lanes start behind them. Few: such a walk
     // is scalar code, and a CU has one scalar unit for all its waves.
     const uint32_t spec_flags = bp.flags & (F_LOCAL | F_FQS);
-    const uint32_t n_wave = spec_flags ? 0u : min(bp.walk_wave_n, bp.n);
+    const uint32_t n_wave = (LOC || spec_flags) ? 0u : min(bp.walk_wave_n, bp.n);
     if (n_wave) {
         __builtin_amdgcn_s_setprio(3);   // (the launch's longest chains: ahead of the lanes' walks on the same SIMD -- protein set with traceback +4 %)
         for (;;) {
@@ -872,7 +853,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             // serial chain of ~200 instructions per cell whose length, for the batch's longest pair, ends the launch)
             if (t.i > 0 || t.j > 0) {
                 // (k_small's LOCAL_START / FREE_QUERY_START_GAPS batches: the early stops, scan_block.rs:1597-1611)
-                if (LB == (int)TB_LANE_BYTES_L2 && spec_flags) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, spec_flags | (eq ? (uint32_t)F_CIGAR_EQ : 0u), bp.cig_ops, lrec, lut);
+                if constexpr (LOC) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, spec_flags | (eq ? (uint32_t)F_CIGAR_EQ : 0u), bp.cig_ops, lrec, lut);
                 else
                 if (eq) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, (uint32_t)F_CIGAR_EQ, bp.cig_ops, lrec, lut);
                 else tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, 0u, bp.cig_ops, lrec, lut);
@@ -1103,8 +1084,8 @@ struct Aligner {
 
     __device__ __forceinline__ void add_block(uint32_t i, uint32_t j, uint32_t w, uint32_t h, bool right, bool untraced = false) {
         if (nblocks >= (uint32_t)unpark<13>(parked)) { status |= ST_BLOCKS_OVERFLOW; return; }
-        // LOCAL_START: the rectangle's zero mask (one word per lane and column = 4x the trace words) follows its trace
-        const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 5u : 1u);
+        // LOCAL_START: every trace word is followed by its cells' zero-mask word (place_rect)
+        const uint32_t words = (w * h / 8) * ((SPECIAL && (h_flags & F_LOCAL)) ? 2u : 1u);
         if (trace_top + words + 64 > (uint32_t)unpark<12>(parked)) { status |= ST_TRACE_OVERFLOW; return; }   // (64 words of slack stay free: see the host's trace_stride)
         {   // every lane stores the same 16 bytes to the same address (one transaction): no exec-mask region per step
             BlockRec br; br.i = i; br.j = j; br.h = (uint16_t)h; br.w = (uint16_t)w;
@@ -1192,7 +1173,7 @@ struct Aligner {
             head = (uint32_t)uni((int)head);
             if (head != seen) { seen = head; idle = 0; }
             // nobody has taken a traceback for a few milliseconds: walk one here (a launch whose traceback waves are not resident)
-            else if ((++idle & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, tb_lds)) idle = 0;
+            else if ((++idle & 2047u) == 0 && traceback_help_one<SPECIAL ? (int)TB_LANE_BYTES_LOC : (int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, tb_lds)) idle = 0;
             __builtin_amdgcn_s_sleep(64);
         }
     }
@@ -1833,8 +1814,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         if (!(bp.flags & 0x800u))   // (development switch: the traceback waves leave at once, as if they were never resident -- see traceback_help_one)
-        traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
-                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(LCLS), 64u, true);
+        traceback_consumer<SPECIAL ? (int)TB_LANE_BYTES_LOC : (int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ,
+                           (unsigned char*)smem + lds_table_bytes_h(KIND) + WAVES_PER_WG * lds_wave_bytes_h(LCLS), 64u, true);   // (the special modes' records also hold zero-mask bits)
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -1953,7 +1934,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
     // lane once the batch has no pairs left for it; its record and move table go where its block borders were.
     if (batch_traceback) {
         lds_sync();
-        traceback_consumer(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 1u, false);
+        traceback_consumer<SPECIAL ? (int)TB_LANE_BYTES_LOC : (int)TB_LANE_BYTES>(bp, SPECIAL ? ~0u : (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 1u, false);
 #ifdef BA_TIMING
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

@@ -90,6 +90,7 @@ BA_DECL_SMS_KIND(0) BA_DECL_SMS_KIND(1) BA_DECL_SMS_KIND(2)
 static const LaunchFn g_launch_sms[3][4] = {BA_SMSROW(0), BA_SMSROW(1), BA_SMSROW(2)};
 static const OccFn g_occ_sms[3][4] = {BA_SMSOROW(0), BA_SMSOROW(1), BA_SMSOROW(2)};
 extern "C" hipError_t ba_launch_walk_l2(hipStream_t, const BatchParams*, uint32_t grid);
+extern "C" hipError_t ba_launch_walk_loc(hipStream_t, const BatchParams*, uint32_t grid);
 typedef hipError_t (*QuadFn)(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k0(int, int, unsigned, hipStream_t, const BatchParams*);
 extern "C" hipError_t ba_launch_quad_k1(int, int, unsigned, hipStream_t, const BatchParams*);
@@ -528,7 +529,7 @@ static void pipe_regions(const BaBatch* b, const uint32_t* ql, const uint32_t* r
                          std::vector<uint64_t>& boff) {
     toff.resize(n + 1); boff.resize(n + 1);
     const uint64_t mx = b->max_size, mn = b->min_size;
-    const uint64_t zm = (b->mode & BA_LOCAL_START) ? 5 : 1;   // (LOCAL_START: the zero masks, see batch_plan)
+    const uint64_t zm = (b->mode & BA_LOCAL_START) ? 2 : 1;   // (LOCAL_START: the zero masks, see batch_plan)
     // (k_small: the arena starts with the waves' sinks -- 64 lanes x 16 words each, where the slots without a step put their trace stores;
     // sized for any launch geometry: 4 workgroups of 8 waves per CU on up to 512 CUs)
     uint64_t t = b->small ? 512ull * 32 * 64 * 16 + 64 : 0, r = 0;
@@ -567,7 +568,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
     // (k_multi's traceback waves keep their records in their own wave's region: no extra space)
-    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : (b->small ? ba::sm_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? ba::TB_LDS_BYTES : 0u));
+    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : (b->small ? ba::sm_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? (special_of(mode) ? ba::TB_LDS_BYTES_LOC : ba::TB_LDS_BYTES) : 0u));   // (the special modes' walk records also hold zero-mask bits)
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
@@ -585,8 +586,8 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     if (grid > need) grid = need;
     if (const char* env = dev_env("BA_GRID")) { int v = atoi(env); if (v > 0 && (uint64_t)v < grid) grid = (uint64_t)v; }   // (development: fewer workgroups)
     // trace stack capacity per slot: same bound as Trace::new (scan_block.rs:1363-1366), in 32-bit words
-    // (LOCAL_START keeps a zero mask of one word per lane and column behind every rectangle's trace words: x5)
-    const uint64_t zm = (mode & BA_LOCAL_START) ? 5 : 1;
+    // (LOCAL_START keeps a zero-mask word behind every trace word: x2)
+    const uint64_t zm = (mode & BA_LOCAL_START) ? 2 : 1;
     b->trace_full = trace ? (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * zm + 64 : 0;   // (+ 64 words of slack: unpredicated stores of the fast path)
     b->trace_stride = b->trace_full;
     // That bound assumes the block sits at its maximum size for the whole alignment (11.9 MB per 10 kbp pair at 1024, of
@@ -599,7 +600,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         uint64_t pct = 175;   // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT)
         if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
         const uint64_t want = est * pct / 100 + 4096;
-        if (want < b->trace_full) { b->trace_stride = want; b->adaptive = true; }
+        if (want < b->trace_full) { b->trace_stride = (want + 15) & ~15ull; b->adaptive = true; }   // (16-word multiples: LOCAL_START stores word pairs)
     }
     b->blocks_stride = trace ? maxlen2 : 0;
     if (b->trace_stride >= (1ull << 30)) { fail("trace stack of %llu words per pair exceeds the 2^30 limit", (unsigned long long)b->trace_stride); return 1; }
@@ -800,11 +801,12 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (profile) small_from = 10000u;   // (round 5: 11 k PSSM pairs 131 against 128 GCUPS, 20 k 227 against 208, 80 k 641 against 459; below: the round-2 pipeline)
     // (round 5: LOCAL_START / FREE_QUERY_START_GAPS batches of the sequence kinds too -- k_small's special instantiations; FREE_QUERY_END_GAPS stays per pair)
     // Same-box sweep (tools/dev/local_sweep.py: 1 kbp DNA pairs behind 100..300 unrelated bases, X-drop 50, block 32..256; GCUPS k_small / per-pair
-    // kernel): LOCAL_START with traceback 50 k pairs 253 / 254, 100 k 378 / 301, 150 k 440 / 327, 250 k 503 / 352; without 50 k 610 / 836, 100 k 833 /
-    // 851, 150 k 917 / 848, 250 k 1009 / 857. FREE_QUERY_START_GAPS on the same pairs stays behind the per-pair kernel up to 250 k pairs (with
-    // traceback 100 k 581 / 682, 250 k 740 / 763; without 100 k 896 / 1144, 250 k 1090 / 1167): those batches take k_small only when forced.
+    // kernel): LOCAL_START with traceback 50 k pairs 311 / 367, 150 k 529 / 478 (before the zero mask became one word per trace word: 253 / 254 and
+    // 440 / 327; 100 k 378 / 301, 250 k 503 / 352); without 50 k 610 / 836, 100 k 833 / 851, 150 k 917 / 848, 250 k 1009 / 857.
+    // FREE_QUERY_START_GAPS on the same pairs stays behind the per-pair kernel up to 250 k pairs (with traceback 100 k 581 / 682, 250 k 740 / 763;
+    // without 100 k 896 / 1144, 250 k 1090 / 1167): those batches take k_small only when forced.
     const bool small_mode = !special_of(mode) || (!profile && !(mode & BA_FREE_QUERY_END_GAPS));
-    if (mode & BA_LOCAL_START) small_from = trace_mode ? 65536u : 131072u;
+    if (mode & BA_LOCAL_START) small_from = trace_mode ? 98304u : 131072u;
     if ((mode & BA_FREE_QUERY_START_GAPS) && !dev_env("BA_FORCE_SMALL")) small_from = ~(size_t)0;
     b->small = small_mode && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
     if (b->small) b->quad = false;
@@ -1076,7 +1078,8 @@ static int batch_launch(BaBatch* b) {
         HIP_TRY(launch_sm((b->mode & BA_TRACE) != 0, (b->mode & BA_X_DROP) != 0, grid_main, b->lds, b->stream, &p1));
         if ((b->mode & BA_TRACE) && bp.cig_ops) {
             BatchParams pw = bp; pw.work_counter = b->counter.as<uint32_t>() + 16;   // (its own counters, zeroed with the others: the side launch may still be counting)
-            HIP_TRY(ba_launch_walk_l2(b->stream, &pw, walk_grid(b)));
+            if (special_of(b->mode)) HIP_TRY(ba_launch_walk_loc(b->stream, &pw, walk_grid(b)));   // (records with the zero-mask bits, the early stops)
+            else HIP_TRY(ba_launch_walk_l2(b->stream, &pw, walk_grid(b)));
         }
         if (side_n) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
     } else if (b->pipe) {   // pair-slot batch: the fill stacks, k_walk walks
@@ -1283,7 +1286,7 @@ int ba_batch_surviving_cells(BaBatch* b, uint64_t* cells) {
     HIP_TRY(hipSetDevice(b->device));
     std::vector<uint32_t> w(b->n);
     if (d2h(b->trace_words, w.data(), b->n)) return 1;
-    const uint64_t per_word = (b->mode & BA_LOCAL_START) ? 5 : 1;   // LOCAL_START: 4 zero-mask words follow every trace word
+    const uint64_t per_word = (b->mode & BA_LOCAL_START) ? 2 : 1;   // LOCAL_START: a zero-mask word follows every trace word
     for (uint32_t s = 0; s < b->n; s++) cells[b->h_order.empty() ? s : b->h_order[s]] = (uint64_t)w[s] / per_word * 8;
     return 0;
 }
@@ -1864,7 +1867,7 @@ struct BlockImpl {
 };
 
 static uint64_t handle_trace_stride(size_t max_size, uint64_t maxlen2, uint32_t mode) {   // Trace::new's bound, scan_block.rs:1363-1366 (+ zero mask, + slack)
-    return (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 5 : 1) + 64;
+    return (uint64_t)(max_size / 16) * (maxlen2 + 2 * max_size) * 2 * ((mode & BA_LOCAL_START) ? 2 : 1) + 64;
 }
 
 // Allocate a handle's device state. Returns 0, or non-zero with the message in g_err (the caller decides whether that is fatal).

@@ -232,6 +232,12 @@ __global__ void __launch_bounds__(WALK_WAVES * 64) k_walk_l2(const ba::BatchPara
     ba::traceback_all<true>(bp, (uint32_t)ba::F_CIGAR_EQ, walk_lds + ((uint32_t)threadIdx.x >> 6) * ba::TB_LDS_BYTES_L2);
 }
 
+// ... of a LOCAL_START / FREE_QUERY_START_GAPS batch of k_small (the lanes' records also hold the cells' zero-mask bits)
+__global__ void __launch_bounds__(WALK_WAVES * 64) k_walk_loc(const ba::BatchParams bp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char walk_lds[];
+    ba::traceback_all<true, true>(bp, (uint32_t)ba::F_CIGAR_EQ, walk_lds + ((uint32_t)threadIdx.x >> 6) * ba::TB_LDS_BYTES_LOC);
+}
+
 __global__ void __launch_bounds__(256) k_compact_cigars(const uint32_t* __restrict__ ops, const uint64_t* __restrict__ cig_off,
                                                         const uint32_t* __restrict__ cig_len, const uint64_t* __restrict__ out_off,
                                                         uint32_t* __restrict__ out, uint32_t n) {
@@ -354,6 +360,10 @@ extern "C" hipError_t ba_launch_walk(hipStream_t s, const ba::BatchParams* bp, u
 }
 extern "C" hipError_t ba_launch_walk_l2(hipStream_t s, const ba::BatchParams* bp, uint32_t grid) {
     k_walk_l2<<<dim3(grid), dim3(WALK_WAVES * 64), WALK_WAVES * ba::TB_LDS_BYTES_L2, s>>>(*bp);
+    return hipGetLastError();
+}
+extern "C" hipError_t ba_launch_walk_loc(hipStream_t s, const ba::BatchParams* bp, uint32_t grid) {
+    k_walk_loc<<<dim3(grid), dim3(WALK_WAVES * 64), WALK_WAVES * ba::TB_LDS_BYTES_LOC, s>>>(*bp);
     return hipGetLastError();
 }
 extern "C" hipError_t ba_launch_traceback(hipStream_t s, const ba::BatchParams* bp) {

@@ -148,6 +148,10 @@ BA_HD constexpr uint32_t sm_wg_bytes_h(int kind, uint32_t max_size) { return lds
 // a 76-byte record (10 trace words + 16 query + 16 reference bytes; 19 dwords: conflict-free) and the 128-byte move table
 constexpr uint32_t TB_LANE_BYTES = 76, TB_LUT_BYTES = 128, TB_LDS_BYTES = 5120;
 constexpr uint32_t TB_LANE_BYTES_L2 = 100;   // k_multi's traceback waves (16 trace words per window): their records sit in the wave's own LDS region   // table first, then the records (a helper fill wave uses one)
+// LOCAL_START batches (round 5): the window also holds the cells' zero-mask bits -- 20 interleaved trace / mask words of a per-pair rectangle,
+// or a slot rectangle's 16 trace + 4 mask words --, then the sequence windows
+constexpr uint32_t TB_LANE_BYTES_LOC = 116, TB_LDS_BYTES_LOC = 7680;
+static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_LOC <= TB_LDS_BYTES_LOC, "k_walk LDS (LOCAL_START)");
 constexpr uint32_t TB_LDS_BYTES_L2 = 6656;   // k_walk over a k_small batch: the move table + 64 records of TB_LANE_BYTES_L2
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= TB_LDS_BYTES_L2, "k_walk LDS (slot rectangles)");
 static_assert(MQ_LDS_BYTES % 16 == 0 && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= MQ_LDS_BYTES, "k_multi LDS");

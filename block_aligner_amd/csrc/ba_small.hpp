@@ -291,8 +291,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
     const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave;
     const uint32_t max_size = bp.max_size;
     // a slot rectangle's words on the trace stack. LOCAL_START: the zero mask takes 8 words behind the 32 trace words, but the stack advances as the
-    // per-pair kernel's does (4 mask words per trace word, Aligner::add_block), so that a pair's trace words count its cells the same way on every path
-    constexpr uint32_t SM_TW = (STEP * SM_B / 8) * (SPM == 1 ? 5u : 1u);
+    // per-pair kernel's does (a mask word per trace word, Aligner::add_block), so that a pair's trace words count its cells the same way on every path
+    constexpr uint32_t SM_TW = (STEP * SM_B / 8) * (SPM == 1 ? 2u : 1u);
     const bool keep_pre = XDROP || (uint32_t)SM_B < max_size;   // a slot keeps the state before its last improving step
     char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * SM_WAVE_BYTES;
 

@@ -754,8 +754,8 @@ def test_special_modes_in_the_tiled_block_class(hip, oracle, mode, size):
     if "free_query_end_gaps" in mode:
         pairs = _substring_pairs(8, 3 + size[0], qlen=(40, size[0] - 20), rlen=(15000, 30000), edits=(0, 30))
     else:
-        # (LOCAL_START keeps a zero mask of 4 words per trace word: the reference's trace bound for a pair -- x 5 -- has to stay below the
-        # library's 2^30 words per pair, which at a maximum of 16384 cells means pairs of ~15 kbp)
+        # (LOCAL_START keeps a zero-mask word per trace word: the reference's trace bound for a pair -- x 2 -- has to stay below the
+        # library's 2^30 words per pair; these lengths also fit the earlier layout of 4 mask words per trace word)
         lens = (25000, 40000) if size[1] == 4096 else (11000, 15000)
         pairs = synth.make_pairs(5, lens, (1500, 3000), 300, synth.DNA, seed=size[1] + len(mode), indels=4, indel_len=(800, 5000), workers=4)
     res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 400, mode)

@@ -11,4 +11,4 @@ w = W.config3(n, workers=int(os.environ.get("BA_GEN_WORKERS", "8")), size=(128, 
 b = W.make_batch(H, w)
 ms = min(b.run() for _ in range(3))
 r = b.results(); cells = int(r["cells"].sum())
-print(f"{os.environ.get('BA_LIB', '')} c3 n={n} trace={trace} kernel {ms:.2f} ms {cells/ms/1e6:.1f} GCUPS bad {int((r['status']!=0).sum())}")
+print(f"{os.environ.get('BA_LIB', '')} c3 n={n} trace={trace} {b.info()['kernel']} grid {b.info().get('grid')} kernel {ms:.2f} ms {cells/ms/1e6:.1f} GCUPS bad {int((r['status']!=0).sum())}")
