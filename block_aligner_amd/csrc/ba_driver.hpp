@@ -277,7 +277,55 @@ __device__ __forceinline__ uint32_t walk_wave(const BlockRec* __restrict__ block
                 if (l2) { widx = (v >> 3) * 8u + (w >> 1) * 2u + ((v >> 2) & 1u); sh = (v & 3u) * 8u + (w & 1u) * 4u; }
                 else { widx = ((w >> 2) * nch + (v >> 7)) * nl + ((v & 127u) >> 1); sh = (v & 1u) * 16u + (w & 3u) * 4u; }
                 uint32_t word;
+                // ---- round 5: a run of diagonal moves at once. In state D a cell whose C and R flags both say "differs" is a match / mismatch and
+                // leaves the state D (OP_LUT, scan_block.rs:1532-1558): lane k looks at cell (v - k, w - k) of this rectangle, the number of leading
+                // lanes that agree is the length of the run; with CIGAR_EQ the lanes also compare their cells' bytes and the run is cut into = / X
+                // runs from the two masks. (A cell on wave-uniform values costs ~700 cycles -- ~75 scalar instructions at one issue per ~5 cycles and
+                // their branches --, the pass about as much as one cell.)
+                if (table == 0u && i > 0u && j > 0u && min(v, w) >= 1u) {
+                    const uint32_t lim = min(min(v, w), min(i, j) - 1u);   // cells 0 .. lim: inside the rectangle, and a diagonal move from them stays inside the matrix
+                    const bool valid = lane <= lim;
+                    const uint32_t vv = v - lane, ww = w - lane;
+                    uint32_t widx_k, sh_k;
+                    if (l2) { widx_k = (vv >> 3) * 8u + (ww >> 1) * 2u + ((vv >> 2) & 1u); sh_k = (vv & 3u) * 8u + (ww & 1u) * 4u; }
+                    else { widx_k = ((ww >> 2) * nch + (vv >> 7)) * nl + ((vv & 127u) >> 1); sh_k = (vv & 1u) * 16u + (ww & 3u) * 4u; }
+                    uint32_t word_k = 0;
+                    if (valid) { if constexpr (DIRECT) word_k = trace[off + widx_k]; else word_k = lds[off + widx_k]; }
+                    const unsigned long long cm = __ballot(valid && ((word_k >> sh_k) & 3u) == 3u);
+                    uint32_t n = cm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~cm);
+                    if (eq && n >= 2u) {   // the cells' bytes out of the sequence windows (256 bytes each, four per lane)
+                        if (i < qw0) load_q();
+                        if (j < rw0) load_r();
+                        n = min(n, min(i - qw0, j - rw0) + 1u);
+                    }
+                    if (n >= 2u) {
+                        bool fits = true;
+                        if (!eq) {
+                            if (run_op == 1u) run_len += n;
+                            else { fits = emit(); run_op = 1u; run_len = n; }
+                        } else {
+                            const uint32_t qa = i - lane - qw0, ra = j - lane - rw0;   // (lanes < n: inside the windows)
+                            const uint32_t qd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qa & ~3u), (int)qwin), rd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ra & ~3u), (int)rwin);
+                            const bool same = ((qd >> ((qa & 3u) * 8u)) & 255u) == ((rd >> ((ra & 3u) * 8u)) & 255u);
+                            unsigned long long bits = __ballot(lane < n && same);
+                            uint32_t rem = n;
+                            while (rem && fits) {
+                                const bool e = bits & 1ull;
+                                const unsigned long long x = e ? ~bits : bits;
+                                const uint32_t len = min(x ? (uint32_t)__builtin_ctzll(x) : 64u, rem), op2 = e ? 2u : 3u;
+                                if (op2 == run_op) run_len += len;
+                                else { fits = emit(); run_op = op2; run_len = len; }
+                                bits = len < 64u ? bits >> len : 0ull; rem -= len;
+                            }
+                        }
+                        if (!fits) { st = ST_CIGAR_OVERFLOW; ok = false; break; }
+                        i -= n; j -= n;   // (the state stays D)
+                        continue;
+                    }
+                    word = (uint32_t)__builtin_amdgcn_readlane((int)word_k, 0);   // (lane 0 looked at the current cell)
+                } else {
                 if constexpr (DIRECT) word = (uint32_t)uni((int)trace[off + widx]); else word = (uint32_t)uni((int)lds[off + widx]);
+                }
                 const uint32_t nib = ((word >> sh) ^ 15u) & 15u;                                // all four bits are stored as "differs"
                 table = tb_resolve(right, table, nib);
                 const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)lutr, (int)((table << 4) | nib));
