@@ -550,7 +550,10 @@ static int pipe_cut(BaBatch* b, const uint32_t* ql, const uint32_t* rl, size_t n
     (void)hipMemGetInfo(&free_b, &total_b);
     uint64_t forced = 0;   // (development / test switch, as for the ring slots)
     if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) forced = (uint64_t)v; }
-    for (uint64_t pct : {175ull, 140ull, 110ull}) {
+    // (LOCAL_START: pairs that start in unrelated sequence sit at the maximum block size until the alignment is found -- 1 kbp pairs behind 100..300
+    // unrelated bases, 50 k pairs: 2.2 % of them outgrew 175 % and were run again, 0.15 % outgrow 300 %)
+    const bool local = b->mode & BA_LOCAL_START;
+    for (uint64_t pct : {local ? 300ull : 175ull, local ? 175ull : 140ull, 110ull}) {
         if (forced) pct = forced;
         pipe_regions(b, ql, rl, n, pct, toff, boff);
         if (b->pipe_words) { if (toff[n] <= b->pipe_words && boff[n] <= b->pipe_recs) return 0; }
@@ -597,7 +600,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     b->adaptive = false;
     if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || dev_env("BA_ADAPTIVE_TRACE"))) {
         const uint64_t est = (maxlen2 * b->min_size / 8 + (uint64_t)max_size * max_size / 8 + 16ull * max_size) * zm;
-        uint64_t pct = 175;   // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT)
+        uint64_t pct = (mode & BA_LOCAL_START) ? 300 : 175;   // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT; LOCAL_START: see pipe_cut)
         if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
         const uint64_t want = est * pct / 100 + 4096;
         if (want < b->trace_full) { b->trace_stride = (want + 15) & ~15ull; b->adaptive = true; }   // (16-word multiples: LOCAL_START stores word pairs)
@@ -642,7 +645,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // better use of the machine once every wave has pairs waiting) -- 10 kbp pairs, block 128..1024, same box: 256 pairs 22.7 -> 12.6 ms,
     // 2048: 25.3 -> 13.2, 4096 (one per wave): 26.3 -> 19.3, 8192: 35.8 -> 33.5, 12000: 40.3 -> 48.1 (kept on the lanes).
     // (one pair per wave at most: in every block class; two: measured for the classes with large LDS regions only)
-    const bool few_pairs = !special_of(mode) && n <= (lds_class_cells(pc) >= 512 ? 2u : 1u) * (uint64_t)grid * ba::WAVES_PER_WG && !dev_env("BA_FORCE_TB");
+    uint64_t few_x = lds_class_cells(pc) >= 512 ? 2u : 1u;
+    if (const char* env = dev_env("BA_FEW_PAIRS_X")) { int v = atoi(env); if (v >= 0) few_x = (uint64_t)v; }   // (development)
+    const bool few_pairs = !special_of(mode) && n <= few_x * (uint64_t)grid * ba::WAVES_PER_WG && !dev_env("BA_FORCE_TB");
     if (trace && (b->grid >= 32 || (dev_env("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !few_pairs && !b->pipe && !dev_env("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD

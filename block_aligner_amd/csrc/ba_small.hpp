@@ -221,7 +221,10 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
             for (int k = 0; k < 4; k++) dsel[k] = fin_col == (uint32_t)j ? dn[k] : dsel[k];
         }
         if constexpr (TRACE && PROF) { if (j & 1) { tdef[2 * (j >> 1)] = tacc[0]; tdef[2 * (j >> 1) + 1] = tacc[1]; } }
-        else if (TRACE && (j & 1)) *(int2*)(tout + 2 * (j >> 1)) = int2{tacc[0], tacc[1]};   // (a column pair's two words: the accumulators do not live on; unpredicated: a slot without a step writes to the wave's sink)
+        // (two column pairs' four words per store: two accumulators live across two more columns, half the store instructions -- round 5, same box: 200 k
+        // 1 kbp pairs with traceback 14.47 -> 14.12 ms, 400 k protein pairs 9.74 -> 9.71; unpredicated: a slot without a step writes to the wave's sink)
+        else if (TRACE && (j & 3) == 1) { tdef[0] = tacc[0]; tdef[1] = tacc[1]; }
+        else if (TRACE && (j & 3) == 3) *(int4*)(tout + 4 * (j >> 2)) = int4{tdef[0], tdef[1], tacc[0], tacc[1]};   // (a column pair's two words: the accumulators do not live on; unpredicated: a slot without a step writes to the wave's sink)
         // the last cell of the column feeds the orthogonal border (scan_block.rs:1213-1214): two columns to a register
         if (j & 1) { nvD[j >> 1] = __builtin_amdgcn_perm(dn[3], holdD, 0x07060302); nvR[j >> 1] = __builtin_amdgcn_perm(r[3], holdR, 0x07060302); }
         else { holdD = dn[3]; holdR = r[3]; }
