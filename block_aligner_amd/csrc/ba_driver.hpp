@@ -145,8 +145,8 @@ __device__ __forceinline__ uint32_t traceback(const BlockRec* __restrict__ block
             }
             table = tb_resolve(right_blk, table, nib);
             if (local && table == 0) {                                                   // scan_block.rs:1604-1611
-                if (l2) {   // a slot's rectangle (32 cells x 8 columns, ba_small.hpp): a bit per cell, the columns of a cell in one byte, after the 32 trace words
-                    const uint32_t z = trace[tbase + 32 + (v >> 3) * 2 + ((v >> 2) & 1)];
+                if (l2) {   // a slot's rectangle (32 or 128 cells x 8 columns, ba_small.hpp / ba_multi.hpp): a bit per cell, the columns of a cell in one byte, after the trace words
+                    const uint32_t z = trace[tbase + (uint32_t)br.h * br.w / 8 + (v >> 3) * 2 + ((v >> 2) & 1)];
                     if ((z >> ((v & 3) * 8 + w)) & 1) { stop = true; break; }
                 } else {
                     const uint32_t z = trace[tbase + (((w >> 2) * nch + chunk) * nl + lane) * 2u + 1u];
@@ -469,9 +469,9 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
                 __builtin_memcpy(&a0, wp, 16); __builtin_memcpy(&a1, wp + 4, 16); __builtin_memcpy(&a2, wp + 8, 16); __builtin_memcpy(&a3, wp + 12, 16);
                 uint4* lw = (uint4*)lrec;
                 lw[0] = a0; lw[1] = a1; lw[2] = a2; lw[3] = a3;
-                if (local) {   // the two lanes' zero-mask words (k_small: two per lane behind the rectangle's 32 trace words), at record bytes 64 .. 79
+                if (local) {   // the two lanes' zero-mask words (two per lane behind the rectangle's trace words), at record bytes 64 .. 79
                     uint4 z;
-                    __builtin_memcpy(&z, t.trace + t.tbase + 32 + t.tw_lane0 * 2, 16);
+                    __builtin_memcpy(&z, t.trace + t.tbase + t.zoff + t.tw_lane0 * 2, 16);
                     lw[4] = z;
                 }
             }

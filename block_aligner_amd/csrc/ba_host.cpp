@@ -69,6 +69,16 @@ BA_DECL_M_KIND(0) BA_DECL_M_KIND(1) BA_DECL_M_KIND(2)
 #define BA_MOROW(K) {ba_occupancy_m_k##K##_p1, ba_occupancy_m_k##K##_p2, ba_occupancy_m_k##K##_p4, ba_occupancy_m_k##K##_p8, ba_occupancy_m_k##K##_p16}
 static const LaunchFn g_launch_m[3][5] = {BA_MROW(0), BA_MROW(1), BA_MROW(2)};
 static const OccFn g_occ_m[3][5] = {BA_MOROW(0), BA_MOROW(1), BA_MOROW(2)};
+// ... and its LOCAL_START / FREE_QUERY_START_GAPS instantiations (the batch's flags choose)
+#define BA_DECL_MS(K, P)                                                                                              \
+    extern "C" hipError_t ba_launch_ms_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
+    extern "C" hipError_t ba_occupancy_ms_k##K##_p##P(int, int, unsigned, int*);
+#define BA_DECL_MS_KIND(K) BA_DECL_MS(K, 1) BA_DECL_MS(K, 2) BA_DECL_MS(K, 4) BA_DECL_MS(K, 8) BA_DECL_MS(K, 16)
+BA_DECL_MS_KIND(0) BA_DECL_MS_KIND(1) BA_DECL_MS_KIND(2)
+#define BA_MSROW(K) {ba_launch_ms_k##K##_p1, ba_launch_ms_k##K##_p2, ba_launch_ms_k##K##_p4, ba_launch_ms_k##K##_p8, ba_launch_ms_k##K##_p16}
+#define BA_MSOROW(K) {ba_occupancy_ms_k##K##_p1, ba_occupancy_ms_k##K##_p2, ba_occupancy_ms_k##K##_p4, ba_occupancy_ms_k##K##_p8, ba_occupancy_ms_k##K##_p16}
+static const LaunchFn g_launch_ms[3][5] = {BA_MSROW(0), BA_MSROW(1), BA_MSROW(2)};
+static const OccFn g_occ_ms[3][5] = {BA_MSOROW(0), BA_MSOROW(1), BA_MSOROW(2)};
 // k_small (ba_small.hpp): sixteen pairs per wave at 32 cells; all four kinds (round 5: sequence-to-profile slots), block classes up to 1024 cells
 #define BA_DECL_SM(K, P)                                                                                              \
     extern "C" hipError_t ba_launch_sm_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
@@ -318,7 +328,7 @@ struct BaBatch {
         bp.work_chunk = work_chunk;
         bp.mq_drain = mq_drain;
         bp.mq_waves = grid * ba::WAVES_PER_WG;
-        bp.mq_donate = (multi && (mode & BA_TRACE) && donate.p && !dev_env("BA_NO_DONATE")) ? donate.as<uint32_t>() : nullptr;   // (the score-only kernels are compiled without the end-of-batch code)
+        bp.mq_donate = (multi && (mode & BA_TRACE) && !special_of(mode) && donate.p && !dev_env("BA_NO_DONATE")) ? donate.as<uint32_t>() : nullptr;   // (the special modes: no slot donation)   // (the score-only kernels are compiled without the end-of-batch code)
         bp.sm_excl_n = small ? sm_excl_n : 0; bp.sm_excl_first = 0;
         bp.prof = prof.as<unsigned long long>();
         return bp;
@@ -577,7 +587,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? g_occ_m[kind][pc] : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
@@ -600,7 +610,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     b->adaptive = false;
     if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || dev_env("BA_ADAPTIVE_TRACE"))) {
         const uint64_t est = (maxlen2 * b->min_size / 8 + (uint64_t)max_size * max_size / 8 + 16ull * max_size) * zm;
-        uint64_t pct = (mode & BA_LOCAL_START) ? 300 : 175;   // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT; LOCAL_START: see pipe_cut)
+        // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT). LOCAL_START, short pairs: see pipe_cut (long
+        // pairs: the flanks are a small part of the stack, and a slot of 3 x 2 x the plain size halves the number of resident waves)
+        uint64_t pct = ((mode & BA_LOCAL_START) && maxlen2 <= 4096) ? 300 : 175;
         if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
         const uint64_t want = est * pct / 100 + 4096;
         if (want < b->trace_full) { b->trace_stride = (want + 15) & ~15ull; b->adaptive = true; }   // (16-word multiples: LOCAL_START stores word pairs)
@@ -685,7 +697,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     }
     // (round 4: a quarter of the fill waves instead of all of them -- since waves that run out of pairs take over other waves' slots at the
     // end of the batch, fewer pairs need to be kept out of the slots: config 3 178.9 -> 176.7 ms, 25 k pairs 60.5 -> 58.0 ms; 0: the same)
-    b->mq_drain = b->multi ? ((dev_env("BA_NO_DONATE") || !trace) ? b->n_fill_waves : b->n_fill_waves / 4) : 0;
+    b->mq_drain = b->multi ? ((dev_env("BA_NO_DONATE") || !trace || special_of(mode)) ? b->n_fill_waves : b->n_fill_waves / 4) : 0;
     if (const char* env = dev_env("BA_MQ_DRAIN")) b->mq_drain = (uint32_t)std::max(0, atoi(env));
     if (b->multi && b->slots_per_wave < 4) b->slots_per_wave = 4;   // (without the hand-off ring: one trace slot per slot of the wave)
     b->slots = b->n_fill_waves * b->slots_per_wave;
@@ -830,7 +842,8 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (trace && !b->pipe) b->quad = b->small = false;   // with TRACE the pipeline needs every pair's trace stack resident until the end
     // Batches that start at 128 cells (the reference's nanopore set-up, examples/nanopore_bench.rs: 1 % .. 10 % of 10 kbp): four pairs
     // per wave while a pair's block is 128 cells (ba_multi.hpp), from the sizes at which every wave still finds four pairs.
-    b->multi = !profile && !special_of(mode) && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || n >= 16384);
+    // (round 5: LOCAL_START / FREE_QUERY_START_GAPS batches too -- k_multi's special instantiations; FREE_QUERY_END_GAPS stays per pair)
+    b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || n >= 16384);
     if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
     if (b->small && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->small = false;   // (e.g. LDS: falls back to the per-pair kernel)
     if (!b->multi && !b->small)
@@ -1009,7 +1022,7 @@ static int batch_launch(BaBatch* b) {
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->ev_l0) HIP_TRY(hipEventRecord(b->ev_l0, b->stream));   // (a re-run sub-batch: batch_retry re-uses ev0 for the merge)
-    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? g_launch_m[b->kind][b->pclass] : g_launch[special_of(b->mode)][b->kind][b->pclass]);
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
     if (b->quad && b->n <= b->cap_n) {
         // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
         // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a

@@ -122,10 +122,53 @@ extern "C" hipError_t BA_CAT(ba_occupancy_sm_k, BA_KIND, _p, BA_PMAX)(int trace,
 }
 #endif
 
-#if BA_SPECIAL && !BA_BIG && BA_PMAX <= 8 && BA_KIND != 3
-// ... and for LOCAL_START (spm 1) / FREE_QUERY_START_GAPS (spm 2) batches of the sequence kinds: the slots take these modes' plain steps too
+#if BA_SPECIAL && !BA_BIG && BA_KIND != 3
+// k_multi for LOCAL_START (spm 1) / FREE_QUERY_START_GAPS (spm 2) batches of the sequence kinds: the slots take these modes' plain steps too
 // (FREE_QUERY_END_GAPS batches stay with the per-pair kernel: the mode's running column maxima are not a slot's)
 #include "ba_multi.hpp"
+template <bool TRACE, bool XDROP, int SPM>
+static hipError_t launch_multi_s(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, SPM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, SPM><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP, int SPM>
+static hipError_t occ_multi_s(int* blocks_per_cu, unsigned lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, SPM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, SPM>, ba::WAVES_PER_WG * 64, lds);
+}
+template <int SPM>
+static hipError_t launch_multi_m(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (trace) return xdrop ? launch_multi_s<true, true, SPM>(grid, lds, s, bp) : launch_multi_s<true, false, SPM>(grid, lds, s, bp);
+    return xdrop ? launch_multi_s<false, true, SPM>(grid, lds, s, bp) : launch_multi_s<false, false, SPM>(grid, lds, s, bp);
+}
+template <int SPM>
+static hipError_t occ_multi_m(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    if (trace) return xdrop ? occ_multi_s<true, true, SPM>(blocks_per_cu, lds) : occ_multi_s<true, false, SPM>(blocks_per_cu, lds);
+    return xdrop ? occ_multi_s<false, true, SPM>(blocks_per_cu, lds) : occ_multi_s<false, false, SPM>(blocks_per_cu, lds);
+}
+// (the batch's flags choose the instantiation)
+extern "C" hipError_t BA_CAT(ba_launch_ms_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
+    return (bp->flags & ba::F_LOCAL) ? launch_multi_m<1>(trace, xdrop, grid, lds, s, *bp) : launch_multi_m<2>(trace, xdrop, grid, lds, s, *bp);
+}
+extern "C" hipError_t BA_CAT(ba_occupancy_ms_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    int a = 0, b = 0;   // (one launch geometry for both)
+    hipError_t e = occ_multi_m<1>(trace, xdrop, lds, &a);
+    if (e != hipSuccess) return e;
+    e = occ_multi_m<2>(trace, xdrop, lds, &b);
+    *blocks_per_cu = a < b ? a : b;
+    return e;
+}
+#endif
+
+#if BA_SPECIAL && !BA_BIG && BA_PMAX <= 8 && BA_KIND != 3
+// ... and k_small for the same two modes
 #include "ba_small.hpp"
 template <bool TRACE, bool XDROP, int SPM>
 static hipError_t launch_small_s(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {

@@ -61,10 +61,14 @@ struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
 // One 8-column shift step for the four slots of a wave, 8 cells per lane (scan_block.rs:147-246 with place_block 1083-1228 and
 // the border moves 1003-1061 folded in). (Ad, Ac): the border pair along the step's vector axis, (Pd, Pr) the orthogonal pair.
 // tout: this lane's eight trace words of the step.
-template <int KIND, bool TRACE>
+// SPM (round 5): the special alignment modes a slot takes, as in small_rect (ba_small.hpp) -- 1 = LOCAL_START (every cell's D is at least the relative
+// zero rz2; TRACE: a zero mask of one bit per cell, two words per lane -- cells 0 .. 3 / 4 .. 7, byte = cell, bit = column --, stored by the caller behind
+// the rectangle's 128 trace words), 2 = FREE_QUERY_START_GAPS (fqs_row0: row 0 of a right step starts from the relative zero in every column).
+template <int KIND, bool TRACE, int SPM = 0>
 __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& fc, const MultiConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
                                            int (&Pd)[4], int (&Pr)[4], uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add,
-                                           uint32_t* __restrict__ tout, bool store, MultiOut& o) {
+                                           uint32_t* __restrict__ tout, bool store, MultiOut& o, int rz2 = 0, bool fqs_row0 = false, int* zout = nullptr) {
+    uint32_t zacc[2] = {0, 0};   // LOCAL_START + TRACE: "D differs from the relative zero", inverted at the end
     const int offa = splat(off_add);
     int d[4], c[4], pd[4], pr[4];
 #pragma unroll
@@ -107,6 +111,8 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             d11[k] = adds(d00[k], sc[k]);
+            if (SPM == 2 && k == 0) d11[0] = fqs_row0 ? (int)(((uint32_t)d11[0] & 0xffff0000u) | ((uint32_t)rz2 & 0xffffu)) : d11[0];   // row 0 of a right step: a free start in every column (scan_block.rs:1130-1132)
+            if (SPM == 1) d11[k] = vmax(d11[k], rz2);   // a local alignment may start anywhere (scan_block.rs:1134-1136)
             copen[k] = adds(d[k], fc.go2);
             cn[k] = vmax(adds(c[k], fc.ge2), copen[k]);
             d11[k] = vmax(d11[k], cn[k]);
@@ -129,6 +135,13 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
             }
             dmax[k] = vmax(dmax[k], dn[k]);
             d[k] = dn[k]; c[k] = cn[k];
+        }
+        if (TRACE && SPM == 1) {   // zero mask (scan_block.rs:1184-1187): D >= the relative zero, so "differs" is the sign of rz - D
+#pragma unroll
+            for (int p2 = 0; p2 < 2; p2++) {
+                const uint32_t pZ = (uint32_t)__builtin_amdgcn_perm(subs(rz2, dn[2 * p2 + 1]), subs(rz2, dn[2 * p2]), 0x0b0a0908);
+                zacc[p2] |= pZ & (0x01010101u << j);
+            }
         }
         if (TRACE) {
             // Trace words of a slot's rectangle: 4 consecutive cells (the two registers of a pair) x 2 columns, a byte per cell, the even
@@ -174,6 +187,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
     const int mm = vmax(vmax(dmax[0], dmax[1]), vmax(dmax[2], dmax[3]));
     const int m32 = max(mm & 0xffff, (int)((uint32_t)mm >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
     o.mx = row_bcast<15>(wave_prefix_max16(m32));
+    if constexpr (TRACE && SPM == 1) { zout[0] = (int)~zacc[0]; zout[1] = (int)~zacc[1]; }
 }
 
 // Per wave and slot, in an L2-resident arena (BatchParams::big):
@@ -191,8 +205,14 @@ enum { MR_PAIR = 0, MR_BEST_I, MR_BEST_J, MR_CELLS_LO, MR_CELLS_HI, MR_BUDGET, M
        MR_BEST_MAX, MR_Y_DROP, MR_X_ITER, MR_D_CORNER, MR_NSTEPS, MR_TRACE_TOP, MR_NBLOCKS, MR_SEL, MR_WORDS };
 __device__ __forceinline__ int mq_load(const char* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }   // past the L1: the wave reads back its own stores
 
-template <int PMAX, int KIND, bool TRACE, bool XDROP>
+template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0>
 __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_multi(const BatchParams bp) {
+    // a slot rectangle's words on the trace stack (LOCAL_START: the zero mask takes 32 words behind the 128 trace words; the stack advances as the
+    // per-pair kernel's does -- a mask word per trace word, Aligner::add_block); the walkers' records and mode bits (the special modes: room for the
+    // zero-mask bits, the early stops of scan_block.rs:1597-1611)
+    constexpr uint32_t MQ_TW = (STEP * MQ_B / 8) * (SPM == 1 ? 2u : 1u);
+    constexpr int TB_LB = SPM ? (int)TB_LANE_BYTES_LOC : (int)TB_LANE_BYTES_L2;
+    constexpr uint32_t TB_MASK = SPM ? ~0u : (uint32_t)F_CIGAR_EQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), l = lane & 15, g = lane >> 4;
     const int wave = uni((int)threadIdx.x >> 6);
@@ -225,7 +245,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
 #endif
     if (batch_traceback && wave == 0 && blockIdx.x % stride == 0) {
         if (!(bp.flags & 0x800u))   // (development switch: as if the traceback waves were never resident)
-        traceback_consumer<(int)TB_LANE_BYTES_L2, 8, 3>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, 64u, true, 1);   // (8 cells per call: the window of a slot's rectangle is 16 rows x 8 columns; 4: -0.8 %, 12: -2 %. Three records fetched ahead: +0.8 % over two)   // (records in this wave's own region)
+        traceback_consumer<TB_LB, 8, 3>(bp, TB_MASK, (unsigned char*)base, 64u, true, 1);   // (8 cells per call: the window of a slot's rectangle is 16 rows x 8 columns; 4: -0.8 %, 12: -2 %. Three records fetched ahead: +0.8 % over two)   // (records in this wave's own region)
 #if defined(BA_TIMING) || defined(BA_ENDHIST)
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 42, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -391,7 +411,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 fc.vconst = pk(v[0], v[1]);
                 fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
             }
-            Aligner<PMAX, KIND, TRACE, XDROP, false, true> al(bp, L, fc);
+            Aligner<PMAX, KIND, TRACE, XDROP, SPM != 0, true> al(bp, L, fc);
             PairState st{};
             uint32_t s_pair, s_slot;
             char* smem_s = wave_mem + (uint32_t)solo * MQ_SLOT_BYTES;
@@ -418,7 +438,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                         if (head != seen) { seen = head; idle_n = 0; }
                         // nobody has taken a traceback for a few milliseconds: walk one here (see traceback_help_one; the wave's LDS region
                         // is free: the slots' buffers are in the arena while the wave is in solo mode)
-                        else if ((++idle_n & 2047u) == 0 && traceback_help_one<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base)) idle_n = 0;
+                        else if ((++idle_n & 2047u) == 0 && traceback_help_one<TB_LB>(bp, TB_MASK, (unsigned char*)base)) idle_n = 0;
                         __builtin_amdgcn_s_sleep(64);
                     }
 #ifdef BA_TIMING
@@ -449,7 +469,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 const int flag = BA_W(cv, 0);
                 const bool ck_pre = flag != 0;
                 st.ck_i = (uint32_t)BA_W(cv, 1); st.ck_j = (uint32_t)BA_W(cv, 2); st.ck_off = BA_W(cv, 3);
-                st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? STEP * MQ_B / 8 : 0u); st.ck_nb = (uint32_t)BA_W(cv, 5) + (flag ? 1u : 0u);
+                st.ck_tt = (uint32_t)BA_W(cv, 4) + (flag ? MQ_TW : 0u); st.ck_nb = (uint32_t)BA_W(cv, 5) + (flag ? 1u : 0u);
                 const int ck_dir = BA_W(cv, 6), ck_offadd = BA_W(cv, 7), ck_corner = BA_W(cv, 8);
 #undef BA_W
                 {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 15), into the canonical order D_col, C_col, D_row, R_row
@@ -462,7 +482,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                         reg[k] = mq_load(live_b + oAd + 4 * k); reg[4 + k] = mq_load(live_b + oAc + 4 * k); reg[8 + k] = mq_load(live_b + oPd + 4 * k); reg[12 + k] = mq_load(live_b + oPr + 4 * k);
                         ckr[k] = mq_load(ck_b + cAd + 4 * k); ckr[4 + k] = mq_load(ck_b + cAc + 4 * k); ckr[8 + k] = mq_load(ck_b + cPd + 4 * k); ckr[12 + k] = mq_load(ck_b + cPr + 4 * k);
                     }
-                    al.import_slot(reg, ckr, s_pair, ck_pre || MQ_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j);
+                    al.import_slot(reg, ckr, s_pair, ck_pre || MQ_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j, st.ck_off);
                 }
             }
             al.trace = bp.trace_arena + (uint64_t)s_slot * bp.trace_stride;
@@ -612,7 +632,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                 const bool q_out = si + MQ_B > qlen, r_out = sj + MQ_B > rlen;
                 // a step that could break early at the matrix edge (never with X-drop) or that the trace slot has no room for is not a slot's
                 bool elig = XDROP || ri + MQ_B <= lenV || rj + STEP <= lenC;
-                if (TRACE) elig = elig && nblocks < bcap && trace_top + (STEP * MQ_B / 8) + 64 <= tcap;
+                if (TRACE) elig = elig && nblocks < bcap && trace_top + MQ_TW + 64 <= tcap;
                 leave = live && !elig;
                 const bool run = live && !leave;
                 const int off_n = off_max;
@@ -667,7 +687,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     }
                 }
                 MultiOut o;
-                multi_rect<KIND, TRACE>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, tw, run, o);
+                int zw[2] = {0, 0};
+                multi_rect<KIND, TRACE, SPM>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, tw, run, o, SPM ? splat(sat16(ZERO - off_n)) : 0,
+                                             SPM == 2 && right && ri == 0u && l == 0, zw);
+                if (TRACE && SPM == 1 && run) *(int2*)(tw - 8 * l + 128 + 2 * l) = int2{zw[0], zw[1]};   // the rectangle's zero mask behind its 128 trace words
 
                 // ---- what does the step call for? (scan_block.rs:332-558; nothing is committed yet)
                 const int right_max = right ? o.act_max8 : o.pas_max8, down_max = right ? o.pas_max8 : o.act_max8;
@@ -687,7 +710,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
                     best_max = imp ? new_off_max : best_max;
                     off = commit ? off_n : off; off_max = commit ? new_off_max : off_max; y_drop = commit ? new_y : y_drop;
                     prev_dir = commit ? dir : prev_dir; D_corner = commit ? o.corner_new : D_corner;
-                    if (TRACE) { trace_top += commit ? (uint32_t)(STEP * MQ_B / 8) : 0u; nblocks += commit ? 1u : 0u; }
+                    if (TRACE) { trace_top += commit ? MQ_TW : 0u; nblocks += commit ? 1u : 0u; }
                     if (XDROP) x_iter = commit ? ((new_off_max < best_max - x_drop) ? x_iter + 1 : 0) : x_iter;
                     const bool go_down = r_out || (!q_out && down_max > right_max);   // forced at the matrix edge, else greedy (ties -> right)
                     si += (commit && go_down) ? (uint32_t)STEP : 0u; sj += (commit && !go_down) ? (uint32_t)STEP : 0u;
@@ -757,11 +780,14 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_mul
 #ifndef MQ_HELPER_LANES
 #define MQ_HELPER_LANES 0u   // 0: the emptied wave walks one path at a time with all its lanes (walk_wave); k > 0: k paths, one per lane (1 -> 4 lanes: +1.5 % at config 3; 4 lanes -> the whole wave: +3 %)
 #endif
+        if constexpr (SPM != 0) traceback_consumer<TB_LB>(bp, TB_MASK, (unsigned char*)base, 4u, false);   // (the whole-wave walk takes no mode bits: four lanes' walks instead)
+        else {
 #if MQ_HELPER_LANES == 0
         traceback_helper_wave<true>(bp, (uint32_t*)base, 2048u);
 #else
         traceback_consumer<(int)TB_LANE_BYTES_L2>(bp, (uint32_t)F_CIGAR_EQ, (unsigned char*)base, MQ_HELPER_LANES, false);
 #endif
+        }
 #if defined(BA_TIMING) || defined(BA_ENDHIST)
         if (bp.prof && is_lane(0)) atomicMax(bp.prof + 41, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

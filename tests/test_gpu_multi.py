@@ -47,6 +47,59 @@ def test_multi_protein(hip, oracle, force_multi, mode):
     compare(hip, oracle, pairs, S.BLOSUM62, (-11, -1), (128, 512), 50, mode)
 
 
+SPECIAL_MODES = [("trace", "local_start"), ("trace", "x_drop", "local_start"), ("local_start",), ("x_drop", "local_start"), ("trace", "free_query_start_gaps"),
+                 ("trace", "x_drop", "free_query_start_gaps"), ("free_query_start_gaps",)]
+
+
+def _flanked_pairs(n, seed, core=(300, 3000), flank=400):
+    """Related cores behind unrelated flanks (what LOCAL_START skips), queries cut out of longer references (what FREE_QUERY_START_GAPS skips),
+    ordinary related pairs."""
+    rng = np.random.default_rng(seed)
+    lists = []
+    for k in range(n):
+        c = synth.rand_str(rng, int(rng.integers(core[0], core[1])), synth.DNA)
+        other = synth.mutate(rng, c, int(rng.integers(0, 1 + len(c) // 10)), synth.DNA)
+        if k % 3 == 0:
+            q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, flank)), synth.DNA), c])
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, flank)), synth.DNA), other])
+        elif k % 3 == 1:
+            q = c
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 2 * flank)), synth.DNA), other, synth.rand_str(rng, int(rng.integers(0, flank)), synth.DNA)])
+        else:
+            q, r = c, other
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    return synth.PairSet.from_lists(lists)
+
+
+@pytest.mark.parametrize("mode", SPECIAL_MODES)
+@pytest.mark.parametrize("size", [(128, 128), (128, 1024)])
+def test_multi_local_and_free_start(hip, oracle, force_multi, mode, size):
+    """Round 5: the slots take LOCAL_START / FREE_QUERY_START_GAPS steps too (k_multi's special instantiations): every cell at least the relative
+    zero, a zero mask of one bit per cell behind a slot rectangle's trace words, the traceback lanes' early stops (scan_block.rs:1130-1136,
+    1184-1187, 1597-1611)."""
+    m = 0
+    for k in mode:
+        m |= {"trace": hip.TRACE, "x_drop": hip.X_DROP, "local_start": hip.LOCAL_START, "free_query_start_gaps": hip.FREE_QUERY_START_GAPS}[k]
+    pairs = _flanked_pairs(240, 50 + size[1])
+    b = hip.BatchAligner(NUC, (-5, -1), size, 100, m, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi"
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, mode)
+    pairs = synth.make_pairs(150, (800, 3000), (50, 300), 100, synth.DNA, seed=51 + size[1], indels=3, indel_len=(20, 200))
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, mode)
+    pairs = synth.make_pairs(150, (100, 1500), (0, 300), 0, synth.AMINO, seed=78)
+    compare(hip, oracle, pairs, S.BLOSUM62, (-11, -1), size, 50, mode)
+
+
+def test_multi_special_modes_with_traceback_waves(hip, oracle, force_multi, monkeypatch):
+    """... with the in-launch hand-off to traceback waves (records with the zero-mask bits) and recycled trace slots."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", "1")
+    pairs = _flanked_pairs(1500, 7, core=(1000, 4000), flank=600)
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, ("trace", "x_drop", "local_start"))
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, ("trace", "free_query_start_gaps"))
+
+
 def test_multi_bytes(hip, oracle, force_multi):
     pairs = synth.make_pairs(100, (100, 900), (0, 60), 5, np.frombuffer(b"abcdefghij\x01\xff", np.uint8), seed=5)
     compare(hip, oracle, pairs, S.BYTES1, (-2, -1), (128, 256), 0, ())

@@ -8,6 +8,8 @@ if os.environ.get("BA_LIB"):   # another build of the library (same-box A/B)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 trace = os.environ.get("C3_TRACE", "1") == "1"
 w = W.config3(n, workers=int(os.environ.get("BA_GEN_WORKERS", "8")), size=(128, 1024), trace=trace)
+if os.environ.get("C3_MODE"):   # e.g. local_start / free_query_start_gaps on top of the configuration's own modes
+    w.mode = tuple(w.mode) + tuple(os.environ["C3_MODE"].split(","))
 b = W.make_batch(H, w)
 ms = min(b.run() for _ in range(3))
 r = b.results(); cells = int(r["cells"].sum())
