@@ -302,10 +302,13 @@ struct FastOut { int mx, row, col; int act_max8, pas_max8, corner_new; };
 
 // LANES: 64 / 32 / 16 = the block is exactly 128 / 64 / 32 cells (lane count, activity tests, trace indices and the depth of
 // the scan are then compile-time); 0 = any single-chunk size (nl_in lanes).
-template <int KIND, bool TRACE, bool XDROP, int LANES, int PR_DIST>
+// SP (round 5): the instantiation of the special-mode kernels. rz2 = the relative zero in both halves for LOCAL_START (every cell's D is at least that,
+// scan_block.rs:1134-1136), MIN otherwise (no effect); local: LOCAL_START -- with TRACE every trace word is followed by its cells' zero-mask word, as
+// place_rect writes them. (FREE_QUERY_START_GAPS differs from the plain modes only in row 0 of the matrix: those steps are not taken here.)
+template <int KIND, bool TRACE, bool XDROP, int LANES, int PR_DIST, bool SP = false>
 __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& fc, int& Ad, int& Ac, int& Pd, int& Pr, short* Pl, short* sink,
                                           int vec_a, int vec_b, unsigned long long colbytes, int nl_in, int corner, int off_add, int loc_thr,
-                                          uint32_t* __restrict__ trace_out, FastOut& o) {
+                                          uint32_t* __restrict__ trace_out, FastOut& o, int rz2 = 0, bool local = false) {
     const int lane = lane_id();
     constexpr bool FULL128 = LANES == 64;
     constexpr int SCAN = LANES ? LANES : 64;
@@ -319,7 +322,7 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
     // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based (scan_block.rs:1042)
     o.corner_new = __builtin_amdgcn_readlane(pd, 3) >> 16;
     const ScoreKey<KIND> key = make_key<KIND>(vec_a, vec_b);
-    int dmax = 0, tacc = 0;
+    int dmax = 0, tacc = 0, zacc = 0;
     int dcol[STEP];                                  // X-drop: D of every column, kept for the (lazy) location of the maximum
     const bool last_lane = is_lane(nl - 1);          // owns the last cell of every column
     short* last_base = last_lane ? Pl + 2 * nl : sink + lane;
@@ -333,6 +336,7 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
         if (j == 0) prev = set_lane0(prev, (int)((uint32_t)corner << 16));
         const int d00 = __builtin_amdgcn_alignbit(d, prev, 16);
         int d11 = adds(d00, sc);
+        if (SP) d11 = vmax(d11, rz2);
         const int copen = adds(d, fc.go2);
         const int cn = vmax(adds(c, fc.ge2), copen);
         d11 = vmax(d11, cn);
@@ -355,9 +359,11 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
             const uint32_t hi2 = bfi(0x80008000u, sRo, sCo >> 1), lo2 = bfi(0x80008000u, sR, sC >> 1);   // bits 15, 14 of each half
             const uint32_t nib = bfi(0xC000C000u, hi2, lo2 >> 2);                                        // bits 15..12: nRo, nCo, nR, nC
             tacc = (int)(((uint32_t)tacc >> 4) | (nib & 0xF000F000u));                                   // column j ends up in bits 4j .. 4j+3
+            if (SP) zacc |= eq01(dn, rz2, fc.ones) << ((j & 3) * 4);                                     // zero mask (scan_block.rs:1184-1187): bit 0 of the cell's nibble position
             if ((j & 3) == 3) {   // (unpredicated: lanes beyond a small block write words that a later store covers, or the slot's slack)
-                trace_out[(uint32_t)((j >> 2) * nl + lane)] = (uint32_t)tacc;
-                tacc = 0;
+                if (SP && local) { if (active) *(uint2*)(trace_out + 2u * (uint32_t)((j >> 2) * nl + lane)) = uint2{(uint32_t)tacc, (uint32_t)zacc}; }   // (twice as far: predicated)
+                else trace_out[(uint32_t)((j >> 2) * nl + lane)] = (uint32_t)tacc;
+                tacc = 0; zacc = 0;
             }
         }
         dmax = vmax(dmax, dn);

@@ -1044,8 +1044,12 @@ struct Aligner {
             }
             uint32_t* tout = TRACE ? trace + tb : nullptr;
             const int loc_thr = best_max - off + ZERO;   // a rectangle maximum above this raises the best score: its location is needed
-#define BA_FAST(LANES) do { if (right) fast_rect<KIND, TRACE, XDROP, LANES, PR_DIST>(L.table, fc, Dcol, Ccol, Drow, Rrow, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, loc_thr, tout, fo); \
-                           else fast_rect<KIND, TRACE, XDROP, LANES, PR_DIST>(L.table, fc, Drow, Rrow, Dcol, Ccol, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, loc_thr, tout, fo); } while (0)
+            // (the special-mode kernels: LOCAL_START's floor -- the relative zero of this step's offset -- and zero mask; FREE_QUERY_START_GAPS steps get here
+            // only below row 0 of the matrix, where they are plain steps: see run())
+            const bool sp_local = SPECIAL && (h_flags & F_LOCAL);
+            const int rz2 = SPECIAL ? (sp_local ? splat(clamp16(-off + ZERO)) : (int)0x80008000u) : 0;
+#define BA_FAST(LANES) do { if (right) fast_rect<KIND, TRACE, XDROP, LANES, PR_DIST, SPECIAL>(L.table, fc, Dcol, Ccol, Drow, Rrow, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, loc_thr, tout, fo, rz2, sp_local); \
+                           else fast_rect<KIND, TRACE, XDROP, LANES, PR_DIST, SPECIAL>(L.table, fc, Drow, Rrow, Dcol, Ccol, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, nl, corner, off_add, loc_thr, tout, fo, rz2, sp_local); } while (0)
             if (B == 128) BA_FAST(64); else if (B == 32) BA_FAST(16); else if (B == 64) BA_FAST(32); else BA_FAST(0);
 #undef BA_FAST
             cells += (unsigned long long)(STEP * B);
@@ -1380,8 +1384,11 @@ struct Aligner {
             BA_TSTAMP(tsa);
             // (plain: a shift step of a single-chunk block that cannot break early -- what the register path and a slot of the multi-pair kernels take)
             // (LOCAL_START / FREE_QUERY_START_GAPS steps are a slot's too -- k_small's special instantiations --, FREE_QUERY_END_GAPS ones are not; none takes the register path)
-            const bool plain = !kBig && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !(special & F_FQE) && (!special || MULTI) && fast_eligible(ri, rh, lenV, rj, lenC);
-            const bool fast = plain && KIND != KIND_PROFILE && !special;
+            // (round 5, later: the register path takes LOCAL_START steps -- fast_rect<.., SP> -- and FREE_QUERY_START_GAPS steps below row 0 of the matrix,
+            // which are plain steps; FREE_QUERY_END_GAPS keeps the generic code)
+            const bool plain0 = !kBig && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !(special & F_FQE) && fast_eligible(ri, rh, lenV, rj, lenC);
+            const bool plain = plain0 && (!special || MULTI);
+            const bool fast = plain0 && KIND != KIND_PROFILE && !((special & F_FQS) && si == 0);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
             if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && plain && !forced && block_size == SLOT_B && min_size == SLOT_B && !chain && !no_spec) {
                 // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
