@@ -818,12 +818,12 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (profile) small_from = 10000u;   // (round 5: 11 k PSSM pairs 131 against 128 GCUPS, 20 k 227 against 208, 80 k 641 against 459; below: the round-2 pipeline)
     // (round 5: LOCAL_START / FREE_QUERY_START_GAPS batches of the sequence kinds too -- k_small's special instantiations; FREE_QUERY_END_GAPS stays per pair)
     // Same-box sweep (tools/dev/local_sweep.py: 1 kbp DNA pairs behind 100..300 unrelated bases, X-drop 50, block 32..256; GCUPS k_small / per-pair
-    // kernel): LOCAL_START with traceback 50 k pairs 311 / 367, 150 k 529 / 478 (before the zero mask became one word per trace word: 253 / 254 and
-    // 440 / 327; 100 k 378 / 301, 250 k 503 / 352); without 50 k 610 / 836, 100 k 833 / 851, 150 k 917 / 848, 250 k 1009 / 857.
-    // FREE_QUERY_START_GAPS on the same pairs stays behind the per-pair kernel up to 250 k pairs (with traceback 100 k 581 / 682, 250 k 740 / 763;
-    // without 100 k 896 / 1144, 250 k 1090 / 1167): those batches take k_small only when forced.
+    // kernel), since the per-pair kernel's register path takes these modes' steps: LOCAL_START with traceback 50 k pairs 367 / 470, 150 k 629 / 614,
+    // 300 k 714 / 643; without 150 k 1077 / 1183, 300 k 1222 / 1187. (Before: with traceback 150 k 529 / 478, without 250 k 1009 / 857; with the zero
+    // mask at four words per trace word 150 k 440 / 327.) FREE_QUERY_START_GAPS on the same pairs stays behind the per-pair kernel (150 k pairs with
+    // traceback 662 / 782, without 1034 / 1294): those batches take k_small only when forced.
     const bool small_mode = !special_of(mode) || (!profile && !(mode & BA_FREE_QUERY_END_GAPS));
-    if (mode & BA_LOCAL_START) small_from = trace_mode ? 98304u : 131072u;
+    if (mode & BA_LOCAL_START) small_from = trace_mode ? 196608u : 262144u;
     if ((mode & BA_FREE_QUERY_START_GAPS) && !dev_env("BA_FORCE_SMALL")) small_from = ~(size_t)0;
     b->small = small_mode && pc <= 3 && min_size == ba::SM_B_HOST && !dev_env("BA_NO_SMALL") && (dev_env("BA_FORCE_SMALL") || (n >= small_from && !dev_env("BA_FORCE_QUAD")));
     if (b->small) b->quad = false;

@@ -154,10 +154,10 @@ def test_small_dna_at_production_threshold(hip, oracle, mode):
 
 @pytest.mark.parametrize("mode", [("trace", "x_drop", "local_start"), ("x_drop", "local_start")])
 def test_small_local_start_at_production_threshold(hip, oracle, mode):
-    """No forcing, the release library: LOCAL_START batches take k_small from 98304 pairs with traceback, 131072 without; FREE_QUERY_START_GAPS batches
+    """No forcing, the release library: LOCAL_START batches take k_small from 196608 pairs with traceback, 262144 without; FREE_QUERY_START_GAPS batches
     stay with the per-pair kernel (ba_host.cpp: measured)."""
     assert hip.lib().ba_dev_build() == 0
-    n = 100000 if "trace" in mode else 135000
+    n = 200000 if "trace" in mode else 265000
     pairs = _flanked_pairs(n, 5)
     assert kernel_of(hip, NUC, (-5, -1), (32, 256), 50, mode_bits(hip, mode, True), pairs) == "k_small"
     assert kernel_of(hip, NUC, (-5, -1), (32, 256), 50, mode_bits(hip, ("trace", "x_drop", "free_query_start_gaps"), True), pairs) != "k_small"
