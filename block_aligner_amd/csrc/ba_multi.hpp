@@ -206,7 +206,10 @@ enum { MR_PAIR = 0, MR_BEST_I, MR_BEST_J, MR_CELLS_LO, MR_CELLS_HI, MR_BUDGET, M
 __device__ __forceinline__ int mq_load(const char* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }   // past the L1: the wave reads back its own stores
 
 template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0>
-__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : 4)) k_multi(const BatchParams bp) {
+#ifndef MQ_WAVES_EU
+#define MQ_WAVES_EU 4   // (waves per SIMD the kernel is compiled for. Tried, round 5: 2 = 256 registers, no spills -- config 3 163.6 -> 205.1 ms, 25 k pairs 55.6 -> 64.1: two waves do not fill the vector unit)
+#endif
+__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_EU)) k_multi(const BatchParams bp) {
     // a slot rectangle's words on the trace stack (LOCAL_START: the zero mask takes 32 words behind the 128 trace words; the stack advances as the
     // per-pair kernel's does -- a mask word per trace word, Aligner::add_block); the walkers' records and mode bits (the special modes: room for the
     // zero-mask bits, the early stops of scan_block.rs:1597-1611)
