@@ -988,6 +988,16 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     size_t cnt = 0;
     while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
     b->sm_excl_n = (uint32_t)cnt;
+    // k_walk behind the fill: those pairs are walked by their own waves, so the paths it walks one to a wave (plan_walks: the leading pairs of the
+    // batch order) are counted from the first pair that is NOT among them -- round 5: until then every pair k_walk saw went to a lane, and the launch
+    // was as long as one lane's walk of the longest of them (400 k protein pairs: 2.08 ms for paths of up to ~2400 cells)
+    if ((b->mode & BA_TRACE) && cnt && !special_of(b->mode) && !dev_env("BA_NO_WALK_AFTER_EXCL")) {
+        const uint64_t first = (uint64_t)ql[cnt < n ? cnt : n - 1] + rl[cnt < n ? cnt : n - 1];
+        const uint64_t from = std::max<uint64_t>(first / 3, 512);
+        size_t w = cnt;
+        while (w < n && w - cnt < 1024 && (uint64_t)ql[w] + rl[w] >= from) w++;
+        b->walk_wave_n = (uint32_t)w;
+    }
     // TRACE: the longest of them -- at least half the longest pair's length, at most one wave in thirty-two -- get a launch of their own
     // beside the main one (batch_launch): their fill + walk is a serial chain that outlasts the rest of the batch (400 k protein pairs with
     // traceback: the 8881-residue pair alone takes 8.6 ms, everything else 6 ms), and the walks of all other pairs need not wait for it

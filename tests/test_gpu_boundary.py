@@ -184,3 +184,48 @@ def test_handle_cigars_from_the_end_and_from_interior_cells(hip, oracle, size):
         a.trace().cigar_eq(pq, pr, ci, cj, part)
         assert consumed(part)[-1] == (ci, cj)
         assert str(cg).startswith(str(part))      # the path below a cell of the path is the path's own prefix
+
+
+@pytest.mark.parametrize("size", [(32, 32), (128, 128), (32, 1024), (2048, 2048)])
+def test_whole_wave_walk_takes_diagonal_runs(hip, oracle, size):
+    """Round 5: in state D the lanes of the whole-wave walk look at one cell each of the diagonal below the current one and a run of plain
+    match / mismatch cells is taken in one step, cut into = / X runs from two lane masks (ba_driver.hpp walk_wave). Shapes that stress it:
+    identical sequences (runs as long as a rectangle is wide: 64 lanes at (2048, 2048)), a mismatch every k-th base (= / X runs of every
+    length 1 .. 17), single-base gaps between long runs, runs that end at the matrix edge; with and without = / X; walked from the end and
+    from interior cells."""
+    rng = np.random.default_rng(size[0] + size[1])
+    base = synth.rand_str(rng, 1500, synth.DNA)
+    cases = [(base, base.copy())]
+    for k in (2, 3, 5, 17):
+        other = base.copy()
+        other[::k] = (np.searchsorted(synth.DNA, other[::k]) + 1) % 4
+        other[::k] = synth.DNA[other[::k]]
+        cases.append((base, other))
+    gapped = np.concatenate([base[:400], base[401:900], synth.DNA[:1], base[900:]])   # one deletion, one insertion, long runs between
+    cases.append((base, gapped))
+    cases.append((base[:700], np.concatenate([base[:700], synth.rand_str(rng, 300, synth.DNA)])))   # the path ends on the matrix edge
+    m = S.NucMatrix.new_simple(2, -3)
+    for q, r in cases:
+        qb, rb = q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()
+        pq = hip.PaddedBytes.from_bytes(qb, size[1], S.NucMatrix); pr = hip.PaddedBytes.from_bytes(rb, size[1], S.NucMatrix)
+        a = hip.Block(len(qb), len(rb), size[1], trace=True)
+        a.align(pq, pr, m, S.Gaps(-5, -1), size, 0)
+        res = a.res()
+        for eq in (True, False):
+            ref = oracle.align(m, qb, rb, (-5, -1), size, 0, ("trace",), cigar_eq=eq)
+            assert (res.score, res.query_idx, res.reference_idx) == (ref["score"], ref["query_idx"], ref["reference_idx"])
+            cg = hip.Cigar(res.query_idx, res.reference_idx)
+            if eq:
+                a.trace().cigar_eq(pq, pr, res.query_idx, res.reference_idx, cg)
+            else:
+                a.trace().cigar(res.query_idx, res.reference_idx, cg)
+            assert str(cg) == ref["cigar"], (size, eq, str(cg)[:120], ref["cigar"][:120])
+        # interior cells on the main diagonal: whatever the walk finds from there consumes exactly (i, i)
+        for i in (1, 63, 64, 65, 511, 600):
+            part = hip.Cigar(i, i)
+            a.trace().cigar_eq(pq, pr, i, i, part)
+            ci = cj = 0
+            for op, ln in part.to_vec():
+                if op:
+                    ci += ln * (hip.OP_CHARS[op] in "M=XI"); cj += ln * (hip.OP_CHARS[op] in "M=XD")
+            assert (ci, cj) == (i, i)
