@@ -15,6 +15,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -1183,10 +1184,30 @@ static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx, float* retr
     }
     return 0;
 }
+// The kernels wait for each other without a give-up (a fill wave for a trace slot, a traceback lane for a ring entry: round 4), so a hand-off that
+// were ever lost would hang the launch: the host side bounds the wait instead (round-4 advisor finding) -- the launch is polled, and after
+// g_wait_limit_ms (ba_set_wait_limit_ms; default 10 minutes, 0 = wait for ever) the call fails with a message instead of never returning.
+static std::atomic<uint64_t> g_wait_limit_ms{600000};
+void ba_set_wait_limit_ms(uint64_t ms) { g_wait_limit_ms.store(ms); }
+static int stream_wait_bounded(hipStream_t s, const char* what) {
+    const uint64_t limit = g_wait_limit_ms.load();
+    if (!limit) { HIP_TRY(hipStreamSynchronize(s)); return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail("%s: %s", what, hipGetErrorString(e));
+        if (spins < 4096) continue;                                  // (short launches: the first polls back to back)
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(dt).count() > (long long)limit)
+            return fail("%s: the launch did not finish within %llu ms (ba_set_wait_limit_ms); the device may be hung", what, (unsigned long long)limit);
+        if (dt > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
 static int batch_wait(BaBatch* b, float* kernel_ms) {
     if (!b->in_flight) return fail("nothing was launched on this batch");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (stream_wait_bounded(b->stream, "ba_batch_wait")) return 1;
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));
     b->in_flight = false;
     b->retried = 0;

@@ -121,6 +121,7 @@ def lib() -> C.CDLL:
         L.ba_batch_run.argtypes = [vp, C.POINTER(C.c_float)]
         L.ba_batch_launch.argtypes = [vp]
         L.ba_batch_wait.argtypes = [vp, C.POINTER(C.c_float)]
+        L.ba_set_wait_limit_ms.argtypes = [C.c_uint64]; L.ba_set_wait_limit_ms.restype = None
         L.ba_batch_results.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.ba_batch_cigars.argtypes = [vp, vp, C.c_uint64]
         L.ba_batch_compact_cigars.argtypes = [vp, vp, C.c_uint64]

@@ -227,6 +227,9 @@ int ba_batch_run(BaBatch* batch, float* kernel_ms);
  * batches overlap on the device; results, cigars and reload are valid after the wait. */
 int ba_batch_launch(BaBatch* batch);
 int ba_batch_wait(BaBatch* batch, float* kernel_ms);
+/* Upper bound on a ba_batch_wait / ba_batch_run (milliseconds; default 600000; 0 = none): the kernels of a launch wait for each other without a
+ * give-up, so the host bounds the wait -- past it the call fails (ba_last_error) instead of never returning. Process-wide. */
+void ba_set_wait_limit_ms(uint64_t ms);
 /* Copy results to host arrays of n_pairs elements; any pointer may be NULL. status: 0 = ok, else BA_ST_* bits. */
 int ba_batch_results(BaBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells,
                      uint32_t* cigar_len, uint32_t* status);

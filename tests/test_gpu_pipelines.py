@@ -180,3 +180,26 @@ def test_whole_wave_walks_for_every_path_of_a_pipeline_batch(hip, oracle, devlib
     else:
         pairs = synth.make_pairs(3000, (100, 1200), (0, 250), 0, synth.AMINO, seed=32, indels=1, indel_len=(3, 40))
         run_and_compare(hip, oracle, pairs, S.BLOSUM62, (-11, -1), (32, 256), 0, ("trace",), False, ("wave walks", kind))
+
+
+def test_wait_is_bounded_on_the_host(hip, oracle):
+    """The kernels of a launch wait for each other without a give-up (round 4), so the host bounds ba_batch_wait (round-4 advisor finding):
+    with a limit shorter than the launch the call fails with a message instead of blocking; the launch itself is not disturbed -- waiting
+    again with the default limit returns its results."""
+    pairs = synth.make_pairs(20000, 3000, 300, 100, synth.DNA, seed=99, workers=1)
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 100, mode_bits(hip, ("trace", "x_drop"), True), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    try:
+        hip.lib().ba_set_wait_limit_ms(1)
+        b.launch()
+        with pytest.raises(RuntimeError, match="did not finish within 1 ms"):
+            b.wait()
+    finally:
+        hip.lib().ba_set_wait_limit_ms(600000)
+    ms = b.wait()
+    assert ms > 1.0
+    res = b.results()
+    assert not res["status"].any()
+    sub = pairs.subset(np.arange(0, 20000, 200))
+    ref = oracle.batch_align(NUC, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, (-5, -1), (128, 512), 100, ("trace", "x_drop"), cigar_eq=True, threads=8)
+    assert np.array_equal(res["score"][::200], ref["scores"])
+    b.close()
