@@ -93,6 +93,28 @@ def test_dna_128_cell_start_at_threshold(hip, oracle, mode):
     run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 80, mode, True, ("dna 128..512", mode))
 
 
+@pytest.mark.parametrize("mode", [("trace", "x_drop", "local_start"), ("local_start",), ("trace", "free_query_start_gaps"), ("x_drop", "free_query_start_gaps")])
+def test_special_modes_128_cell_start_at_threshold(hip, oracle, mode):
+    """Round 5, no forcing, the release library: LOCAL_START / FREE_QUERY_START_GAPS batches that start at 128 cells take k_multi from 16384 pairs
+    like the plain modes (its special instantiations, the traceback waves' records with the zero-mask bits)."""
+    assert hip.lib().ba_dev_build() == 0
+    rng = np.random.default_rng(77)
+    base = synth.make_pairs(20000, (300, 1500), (20, 150), 80, synth.DNA, seed=2026, indels=1, indel_len=(10, 120))
+    lists = []
+    for p in range(len(base)):   # every third pair behind unrelated heads, every third a query inside a longer reference
+        q, r = np.frombuffer(base.query(p), np.uint8), np.frombuffer(base.reference(p), np.uint8)
+        if p % 3 == 0:
+            q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 300)), synth.DNA), q]); r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 300)), synth.DNA), r])
+        elif p % 3 == 1:
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 500)), synth.DNA), r])
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    pairs = synth.PairSet.from_lists(lists)
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 80, mode_bits(hip, mode, True), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi"
+    b.close()
+    run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 80, mode, True, ("dna special 128..512 k_multi", mode))
+
+
 def test_four_pipeline_batches_in_flight_round_after_round(hip, oracle):
     """Four small-block batches launched together, 20 rounds: queue hand-offs, the launch beside k_quad and k_walk of different
     batches overlap on the device; every round of every batch must equal the oracle."""
