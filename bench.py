@@ -166,6 +166,50 @@ def secondary_line(np, H, W, o, w, cores):
             "full_matrix_equiv_gcups": round(w.full_matrix_cells() / (ms * 1e-3) / 1e9, 1), "parity_checked_pairs": checked, "retried": retried}
 
 
+def secondary_sized(np, H, W, o, cores, n=20000):
+    """Every pair with its own block range (ba_sized_batch_*: percent_len 1 % .. 10 % of the pair's length, examples/nanopore_bench_global.rs:144-171)
+    on a mixed-length read set: the pairs are binned by range, the bins run one after the other; `gcups` counts all of them. EVERY pair is compared
+    with the oracle run with its own range (bin by bin)."""
+    from block_aligner_amd import scores as S
+    pairs = W.mixed_reads(n)
+    m = S.NucMatrix.new_simple(2, -3)
+    b = H.SizedBatchAligner(m, (-5, -1), 100, H.TRACE | H.X_DROP | H.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, percent=(0.01, 0.1))
+    b.run()
+    times = sorted(b.run() for _ in range(3))
+    ms = times[0]
+    res = b.results()
+    if res["status"].any():
+        raise RuntimeError("bench.py: sized batch: pairs failed on the device")
+    runs, off = b.cigars(res["cigar_len"])
+    classes = b.classes()
+    checked = 0
+    if o is not None:
+        ln = np.maximum(pairs.q_len, pairs.r_len)
+        lo = np.array([H.percent_len(int(x), 0.01) for x in ln]); hi = np.array([H.percent_len(int(x), 0.1) for x in ln])
+        for key in sorted(set(zip(lo.tolist(), hi.tolist()))):
+            idx = np.nonzero((lo == key[0]) & (hi == key[1]))[0]
+            sub = pairs.subset(idx)
+            ref = o.batch_align(m, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, (-5, -1), key, 100, ("trace", "x_drop"), cigar_eq=True, threads=cores)
+            ok = (np.array_equal(ref["scores"], res["score"][idx]) and np.array_equal(ref["query_idx"], res["query_idx"][idx])
+                  and np.array_equal(ref["reference_idx"], res["reference_idx"][idx]) and int(res["cells"][idx].sum()) == ref["cells"]
+                  and np.array_equal(ref["cig_len"], res["cigar_len"][idx]))
+            if ok:
+                for kk in range(0, len(idx), max(1, len(idx) // 64)):   # (the runs of a spread of every bin's pairs; all lengths were compared above)
+                    p = int(idx[kk])
+                    want = ref["cig_ops"][int(ref["cig_off"][kk]): int(ref["cig_off"][kk]) + int(ref["cig_len"][kk])]
+                    ok = ok and np.array_equal(want, runs[int(off[p]): int(off[p + 1])])
+            if not ok:
+                raise RuntimeError(f"bench.py: GPU results differ from the oracle on the sized batch, block range {key}; number is invalid")
+            checked += len(idx)
+    b.close()
+    cells = int(res["cells"].sum())
+    gc = cells / (ms * 1e-3) / 1e9
+    return {"config": f"per-pair block ranges: {n} reads of 1..40 kbp (log-uniform), 10 % edits, percent_len 1 %..10 % per pair, X-drop 100, traceback",
+            "kernel": "ba_sized_batch: " + ", ".join(f"{c[0]}..{c[1]} x{c[2]}" for c in classes), "gcups": round(gc, 1),
+            "valu_frac": round(gc * 1e9 * 20 / 1e12 / VALU_PEAK_INT16_TOPS, 4), "ops_per_cell": 20, "kernel_ms": round(ms, 3), "launches": 3, "pairs": n,
+            "parity_checked_pairs": checked, "ranges": len(classes)}
+
+
 def measure_e2e(np, H, W, w, sets=4):
     """PCIe-inclusive rate (never `value`): `sets` sets of the batch stream from host memory through two batch objects -- while one
     set is aligned the host reloads the other object with the next set; scores, end positions and the gathered CIGAR runs (written by
@@ -487,6 +531,8 @@ def main():
                 # the special alignment modes (scan_block.rs:89: LOCAL_START, FREE_QUERY_END_GAPS), on the per-pair kernel
                 secondary.append(secondary_line(np, H, W, o, W.config_local(50000), cores))
                 secondary.append(secondary_line(np, H, W, o, W.config_free_end(50000), cores))
+                # every pair with its own block range (round 5: ba_sized_batch_*)
+                secondary.append(secondary_sized(np, H, W, o, cores))
                 # ... and the same configurations at the batch sizes of the reference's own harnesses (BASELINE.json: 10 k pairs,
                 # examples/nanopore_bench.rs:73-95; 7 k protein pairs, examples/uc_bench.rs:79-104; 11 k PSSMs, examples/pssm_bench.rs:94-100):
                 # a few pairs per wave, bound by the longest pair's chain of steps rather than by the machine

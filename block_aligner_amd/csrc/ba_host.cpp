@@ -556,9 +556,17 @@ static void pipe_regions(const BaBatch* b, const uint32_t* ql, const uint32_t* r
 }
 // Cut the arenas for the pairs (ql, rl). cap_words / cap_recs = 0: choose the margin by the free device memory (the caller
 // allocates pipe_words / pipe_recs afterwards); otherwise the regions must fit the existing arenas. Returns 1 if they cannot.
+// Device memory a batch may plan with: what is free, or -- while ba_sized_batch_create builds one batch per block range -- this batch's share of it
+// (the ranges' batches are alive together and launched one after the other: each sized as if it were alone, the first ones took everything)
+static thread_local uint64_t g_mem_cap = ~0ull;
+static void mem_info(size_t* free_b, size_t* total_b) {
+    *free_b = 0; *total_b = 0;
+    (void)hipMemGetInfo(free_b, total_b);
+    if ((uint64_t)*free_b > g_mem_cap) *free_b = (size_t)g_mem_cap;
+}
 static int pipe_cut(BaBatch* b, const uint32_t* ql, const uint32_t* rl, size_t n, uint64_t fixed_bytes, std::vector<uint64_t>& toff, std::vector<uint64_t>& boff) {
     size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
+    mem_info(&free_b, &total_b);
     uint64_t forced = 0;   // (development / test switch, as for the ring slots)
     if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) forced = (uint64_t)v; }
     // (LOCAL_START: pairs that start in unrelated sequence sit at the maximum block size until the alignment is found -- 1 kbp pairs behind 100..300
@@ -609,7 +617,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // size, one full grow sequence to the maximum, a few steps there -- times a margin; the few pairs that outgrow
     // their slot report BA_ST_TRACE_OVERFLOW on the device and are re-run with full-size slots by batch_wait.
     b->adaptive = false;
-    if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || dev_env("BA_ADAPTIVE_TRACE"))) {
+    // (... and the batches of a sized batch's block ranges, which share the device memory: full-size slots of long pairs at large blocks -- 140 MB
+    // each -- left a range's batch a few dozen resident waves)
+    if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || g_mem_cap != ~0ull || dev_env("BA_ADAPTIVE_TRACE"))) {
         const uint64_t est = (maxlen2 * b->min_size / 8 + (uint64_t)max_size * max_size / 8 + 16ull * max_size) * zm;
         // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT). LOCAL_START, short pairs: see pipe_cut (long
         // pairs: the flanks are a small part of the stack, and a slot of 3 x 2 x the plain size halves the number of resident waves)
@@ -624,7 +634,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // very long pairs: a trace slot can be hundreds of MB, so fewer waves may be resident than the chip could hold --
         // shrink the launch until one slot per wave fits in device memory (a long pair keeps its wave busy for long anyway)
         size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
+        mem_info(&free_b, &total_b);
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         const uint64_t budget = free_b * 9 / 10 > fixed ? free_b * 9 / 10 - fixed : 0;
@@ -676,7 +686,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
         size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
+        mem_info(&free_b, &total_b);
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
@@ -1796,7 +1806,22 @@ BaSizedBatch* ba_sized_batch_create(int kind, const void* matrix, Gaps gaps, con
         m->idx[it->second].push_back((uint32_t)p);
     }
     m->part.resize(m->idx.size());
+    // every range's batch gets a share of the free device memory in proportion to what its trace stacks ask for (residues x maximum block size)
+    std::vector<double> weight(m->idx.size(), 0.0);
+    double weight_left = 0;
     for (size_t k = 0; k < m->idx.size(); k++) {
+        for (uint32_t p : m->idx[k]) weight[k] += ((double)q_len[p] + r_len[p] + 64.0) * (double)m->range[k].max;
+        weight_left += weight[k];
+    }
+    struct CapReset { ~CapReset() { g_mem_cap = ~0ull; } } cap_reset;
+    for (size_t k = 0; k < m->idx.size(); k++) {
+        {
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            g_mem_cap = m->idx.size() > 1 ? (uint64_t)((double)free_b * 0.95 * (weight[k] / std::max(weight_left, 1.0))) : ~0ull;
+            g_mem_cap = std::max<uint64_t>(g_mem_cap, 3ull << 30);   // (batch_plan keeps 1 GB aside; a range of a few pairs still needs its scratch)
+            weight_left -= weight[k];
+        }
         const auto& ix = m->idx[k];
         std::vector<uint64_t> qo(ix.size()), ro(ix.size());
         std::vector<uint32_t> ql(ix.size()), rl(ix.size());

@@ -127,6 +127,21 @@ def config_free_end(n: int = 50000, seed: int = 32) -> Workload:
                     synth.PairSet.from_lists(lists), S.NucMatrix.new_simple(2, -3), (-5, -1), (128, 512), 0, ("free_query_end_gaps", "trace"))
 
 
+def mixed_reads(n: int = 20000, lo: int = 1000, hi: int = 40000, seed: int = 7) -> synth.PairSet:
+    """A mixed-length read set (lengths log-uniform in lo .. hi, 10 % edits, tails of 0..500 bases): the input of
+    examples/nanopore_bench_global.rs:144-171, where every pair gets its own block range percent_len(len, 1 %) ..= percent_len(len, 10 %)."""
+    rng = np.random.default_rng(seed)
+    lens = np.exp(rng.uniform(np.log(lo), np.log(hi), n)).astype(int)
+    lists = []
+    for L in lens:
+        r = synth.rand_str(rng, int(L), synth.DNA)
+        q = synth.mutate(rng, r, int(L) // 10, synth.DNA)
+        t = int(rng.integers(0, 500))
+        lists.append((np.concatenate([q, synth.rand_str(rng, t, synth.DNA)]).astype(np.uint8).tobytes(),
+                      np.concatenate([r, synth.rand_str(rng, t, synth.DNA)]).astype(np.uint8).tobytes()))
+    return synth.PairSet.from_lists(lists)
+
+
 def make_batch(H, w: Workload):
     """The HIP batch object for a workload (block_aligner_amd.hip.BatchAligner / ProfileBatchAligner)."""
     mode = (H.TRACE if "trace" in w.mode else 0) | (H.X_DROP if "x_drop" in w.mode else 0)
