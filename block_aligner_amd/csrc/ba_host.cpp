@@ -1788,6 +1788,7 @@ struct BaSizedBatch {
     std::vector<SizeRange> range;                 // part k's block range
     std::vector<std::vector<uint32_t>> idx;       // part k's pairs (caller indices, ascending)
     std::vector<float> last_ms;
+    std::vector<double> work;                     // part k's share of the work (residues x maximum block size): launch order, memory share
     size_t n = 0;
     uint32_t mode = 0;
 };
@@ -1813,6 +1814,7 @@ BaSizedBatch* ba_sized_batch_create(int kind, const void* matrix, Gaps gaps, con
         for (uint32_t p : m->idx[k]) weight[k] += ((double)q_len[p] + r_len[p] + 64.0) * (double)m->range[k].max;
         weight_left += weight[k];
     }
+    m->work = weight;
     struct CapReset { ~CapReset() { g_mem_cap = ~0ull; } } cap_reset;
     for (size_t k = 0; k < m->idx.size(); k++) {
         {
@@ -1844,15 +1846,30 @@ BaSizedBatch* ba_sized_batch_create_percent(int kind, const void* matrix, Gaps g
 }
 int ba_sized_batch_run(BaSizedBatch* m, float* kernel_ms) {
     if (!m) return fail("null batch");
-    // (one bin after the other: every launch is a persistent kernel sized for the whole device)
-    float total = 0;
+    // Round 5: all ranges' launches at once, each on its batch's own stream, the ones with the most work first: a range of a few thousand pairs
+    // does not fill the device (its grid is what its pairs need), and the long ranges' launches end with a few long pairs. kernel_ms: the host's
+    // clock from the first launch to the last completion (the device is idle before: the previous run was waited for). BA_SIZED_SERIAL (development):
+    // one after the other, kernel_ms the sum of the launches' event times.
     m->last_ms.assign(m->part.size(), 0.f);
-    for (size_t k = 0; k < m->part.size(); k++) {
-        float ms = 0;
-        if (ba_batch_run(m->part[k].get(), &ms)) return 1;
-        m->last_ms[k] = ms; total += ms;
+    if (dev_env("BA_SIZED_SERIAL")) {
+        float total = 0;
+        for (size_t k = 0; k < m->part.size(); k++) {
+            float ms = 0;
+            if (ba_batch_run(m->part[k].get(), &ms)) return 1;
+            m->last_ms[k] = ms; total += ms;
+        }
+        if (kernel_ms) *kernel_ms = total;
+        return 0;
     }
-    if (kernel_ms) *kernel_ms = total;
+    std::vector<size_t> order(m->part.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return m->work[a] > m->work[b]; });
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t k : order) if (ba_batch_launch(m->part[k].get())) return 1;
+    int rc = 0;
+    for (size_t k : order) { float ms = 0; if (ba_batch_wait(m->part[k].get(), &ms)) rc = 1; m->last_ms[k] = ms; }
+    if (rc) return 1;
+    if (kernel_ms) *kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 int ba_sized_batch_results(BaSizedBatch* m, int32_t* score, uint32_t* qi, uint32_t* ri, uint64_t* cells, uint32_t* cigar_len, uint32_t* status) {

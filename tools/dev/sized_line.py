@@ -4,6 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from block_aligner_amd import hip as H, scores as S, synth
+H.use_library(H.DEV_LIB_PATH)   # the build that reads the BA_* development switches
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 rng = np.random.default_rng(7)
 lens = np.exp(rng.uniform(np.log(1000), np.log(40000), n)).astype(int)
