@@ -1865,10 +1865,17 @@ int ba_sized_batch_run(BaSizedBatch* m, float* kernel_ms) {
     for (size_t k = 0; k < order.size(); k++) order[k] = k;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return m->work[a] > m->work[b]; });
     const auto t0 = std::chrono::steady_clock::now();
-    for (size_t k : order) if (ba_batch_launch(m->part[k].get())) return 1;
     int rc = 0;
-    for (size_t k : order) { float ms = 0; if (ba_batch_wait(m->part[k].get(), &ms)) rc = 1; m->last_ms[k] = ms; }
-    if (rc) return 1;
+    std::string first_err;
+    size_t launched = 0;
+    for (size_t k : order) { if (ba_batch_launch(m->part[k].get())) { rc = 1; first_err = g_err; break; } launched++; }
+    for (size_t i = 0; i < launched; i++) {   // (also after a failed launch: nothing is left in flight behind the caller's back)
+        const size_t k = order[i];
+        float ms = 0;
+        if (ba_batch_wait(m->part[k].get(), &ms) && !rc) { rc = 1; first_err = g_err; }
+        m->last_ms[k] = ms;
+    }
+    if (rc) return fail("%s", first_err.c_str());
     if (kernel_ms) *kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
