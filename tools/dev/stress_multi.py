@@ -17,6 +17,8 @@ for seed in range(seed0, seed0 + count):
     tails = int(rng.integers(0, 300))
     x_drop = int(rng.integers(20, 200))
     mode = [(), ("x_drop",), ("trace",), ("trace", "x_drop")][int(rng.integers(0, 4))]
+    if os.environ.get("STRESS_SPECIAL"):   # round 5: the special modes the multi-pair kernels take, on pairs with unrelated heads
+        mode = mode + (("local_start",) if rng.random() < 0.6 else ("free_query_start_gaps",))
     kind = int(rng.integers(0, 3))
     ext = -int(rng.integers(1, 4)); opn = ext - int(rng.integers(2, 12))
     if kind == 0:
@@ -27,6 +29,16 @@ for seed in range(seed0, seed0 + count):
         alpha, matrix = np.frombuffer(b"abcdefgh", np.uint8), S.BYTES1
         mode = tuple(m for m in mode if m != "x_drop"); opn, ext = -2, -1
     pairs = synth.make_pairs(17000, (lo_len, hi_len), edits, tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 150))
+    if os.environ.get("STRESS_SPECIAL"):
+        lists = []
+        for p in range(len(pairs)):
+            q, r = np.frombuffer(pairs.query(p), np.uint8), np.frombuffer(pairs.reference(p), np.uint8)
+            if p % 3 == 0:
+                q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 200)), alpha), q]); r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 200)), alpha), r])
+            elif p % 3 == 1:
+                r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 400)), alpha), r])
+            lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+        pairs = synth.PairSet.from_lists(lists)
     what = (seed, kind, (128, hi), (opn, ext), x_drop, mode)
     try:
         run_and_compare(H, o, pairs, matrix, (opn, ext), (128, hi), x_drop if "x_drop" in mode else 0, mode, kind == 0, what)

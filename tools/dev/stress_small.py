@@ -5,6 +5,7 @@ os.environ["BA_FORCE_SMALL"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from block_aligner_amd import hip as H, scores as S, synth
+H.use_library(H.DEV_LIB_PATH)   # the build that reads BA_FORCE_SMALL
 from oracle.oracle_py import Oracle
 from tests.test_gpu_pipelines import run_and_compare
 o = Oracle("avx2")
@@ -19,6 +20,8 @@ for seed in range(seed0, seed0 + count):
     tails = int(rng.integers(0, 200))
     x_drop = int(rng.integers(15, 150))
     mode = [(), ("x_drop",), ("trace",), ("trace", "x_drop")][int(rng.integers(0, 4))]
+    if os.environ.get("STRESS_SPECIAL"):   # round 5: the special modes the multi-pair kernels take, on pairs with unrelated heads
+        mode = mode + (("local_start",) if rng.random() < 0.6 else ("free_query_start_gaps",))
     kind = int(rng.integers(0, 3))
     ext = -int(rng.integers(1, 4)); opn = ext - int(rng.integers(2, 12))
     if kind == 0:
@@ -30,6 +33,16 @@ for seed in range(seed0, seed0 + count):
         mode = tuple(m for m in mode if m != "x_drop"); opn, ext = -2, -1
     n = int(rng.integers(3000, 40000))
     pairs = synth.make_pairs(n, (lo_len, hi_len), edits, tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 150))
+    if os.environ.get("STRESS_SPECIAL"):
+        lists = []
+        for p in range(len(pairs)):
+            q, r = np.frombuffer(pairs.query(p), np.uint8), np.frombuffer(pairs.reference(p), np.uint8)
+            if p % 3 == 0:
+                q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 200)), alpha), q]); r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 200)), alpha), r])
+            elif p % 3 == 1:
+                r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 400)), alpha), r])
+            lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+        pairs = synth.PairSet.from_lists(lists)
     what = (seed, n, kind, (32, hi), (opn, ext), x_drop, mode)
     try:
         run_and_compare(H, o, pairs, matrix, (opn, ext), (32, hi), x_drop if "x_drop" in mode else 0, mode, kind == 0, what)
