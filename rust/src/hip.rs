@@ -98,6 +98,17 @@ extern "C" {
     pub fn ba_multibatch_destroy(batch: *mut c_void);
     pub fn ba_device_count() -> i32;
     pub fn ba_set_device(device: i32) -> i32;      // per calling thread
+    // every pair with its own block range (examples/nanopore_bench_global.rs:144-171: percent_len per pair); results in the caller's order
+    pub fn ba_sized_batch_create(kind: i32, matrix: *const c_void, gaps: Gaps, size_per_pair: *const SizeRange, x_drop: i32, mode: u32,
+                                 pool: *const u8, q_off: *const u64, q_len: *const u32, r_off: *const u64, r_len: *const u32, n_pairs: usize) -> *mut c_void;
+    pub fn ba_sized_batch_create_percent(kind: i32, matrix: *const c_void, gaps: Gaps, min_percent: f32, max_percent: f32, x_drop: i32, mode: u32,
+                                         pool: *const u8, q_off: *const u64, q_len: *const u32, r_off: *const u64, r_len: *const u32, n_pairs: usize) -> *mut c_void;
+    pub fn ba_sized_batch_run(batch: *mut c_void, kernel_ms: *mut f32) -> i32;
+    pub fn ba_sized_batch_results(batch: *mut c_void, score: *mut i32, query_idx: *mut u32, reference_idx: *mut u32, cells: *mut u64, cigar_len: *mut u32, status: *mut u32) -> i32;
+    pub fn ba_sized_batch_cigars(batch: *mut c_void, runs: *mut u32, capacity: u64) -> i32;
+    pub fn ba_sized_batch_destroy(batch: *mut c_void);
+    // upper bound of a ba_batch_wait / ba_batch_run on the host (milliseconds; 0 = none): past it the call fails instead of blocking
+    pub fn ba_set_wait_limit_ms(ms: u64);
     pub fn block_percent_len(len: usize, p: f32) -> usize;
     pub fn ba_last_error() -> *const c_char;
 }
@@ -164,3 +175,32 @@ impl HipBatch {
     }
 }
 impl Drop for HipBatch { fn drop(&mut self) { unsafe { ba_batch_destroy(self.h) } } }
+
+/// Many pairs, each with its own block range `percent_len(len, min_percent) ..= percent_len(len, max_percent)` of its longer sequence
+/// (lib.rs:109-111, as examples/nanopore_bench_global.rs:144-171 aligns its reads): the library bins the pairs by range, runs every bin as an
+/// ordinary batch and returns the results in the caller's order.
+pub struct HipSizedBatch { h: *mut c_void, n: usize }
+
+impl HipSizedBatch {
+    pub fn with_percent_len<M: Matrix>(matrix: &M, gaps: Gaps, min_percent: f32, max_percent: f32, x_drop: i32, mode: u32,
+                                       pool: &[u8], q: &[(u64, u32)], r: &[(u64, u32)]) -> Result<Self, String> {
+        assert_eq!(q.len(), r.len());
+        let (q_off, q_len): (Vec<u64>, Vec<u32>) = q.iter().cloned().unzip();
+        let (r_off, r_len): (Vec<u64>, Vec<u32>) = r.iter().cloned().unzip();
+        let marg = MatrixArg::of(matrix);
+        let h = unsafe { ba_sized_batch_create_percent(M::HIP_KIND, marg.ptr(), gaps, min_percent, max_percent, x_drop, mode,
+                                                       pool.as_ptr(), q_off.as_ptr(), q_len.as_ptr(), r_off.as_ptr(), r_len.as_ptr(), q.len()) };
+        if h.is_null() { Err(last_error()) } else { Ok(HipSizedBatch { h, n: q.len() }) }
+    }
+    pub fn run(&mut self) -> Result<f32, String> {
+        let mut ms = 0f32;
+        if unsafe { ba_sized_batch_run(self.h, &mut ms) } != 0 { Err(last_error()) } else { Ok(ms) }
+    }
+    pub fn results(&self) -> Result<Vec<AlignResult>, String> {
+        let (mut s, mut qi, mut ri, mut st) = (vec![0i32; self.n], vec![0u32; self.n], vec![0u32; self.n], vec![0u32; self.n]);
+        if unsafe { ba_sized_batch_results(self.h, s.as_mut_ptr(), qi.as_mut_ptr(), ri.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(), st.as_mut_ptr()) } != 0 { return Err(last_error()); }
+        if let Some(p) = st.iter().position(|&x| x != 0) { return Err(format!("pair {} failed on the device (status {:#x})", p, st[p])); }
+        Ok((0..self.n).map(|p| AlignResult { score: s[p], query_idx: qi[p] as usize, reference_idx: ri[p] as usize }).collect())
+    }
+}
+impl Drop for HipSizedBatch { fn drop(&mut self) { unsafe { ba_sized_batch_destroy(self.h) } } }
