@@ -624,6 +624,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT). LOCAL_START, short pairs: see pipe_cut (long
         // pairs: the flanks are a small part of the stack, and a slot of 3 x 2 x the plain size halves the number of resident waves)
         uint64_t pct = ((mode & BA_LOCAL_START) && maxlen2 <= 4096) ? 300 : 175;
+        // (k_multi, round 5: nine smaller slots per wave instead of eight -- config 3, same box: 8 x 175 % 163.1 ms / 104.9 GB, 9 x 150 % 161.5 / 101.2,
+        // 10 x 125 % 161.9 / 93.8, 9 x 125 % 161.6 / 84.4; its stacks reach 93 % of the expected size, and a pair that outgrows its slot is run again)
+        if (b->multi && !(mode & BA_LOCAL_START)) pct = 125;
         if (const char* env = dev_env("BA_TRACE_MARGIN_PCT")) { int v = atoi(env); if (v > 0) pct = (uint64_t)v; }
         const uint64_t want = est * pct / 100 + 4096;
         if (want < b->trace_full) { b->trace_stride = (want + 15) & ~15ull; b->adaptive = true; }   // (16-word multiples: LOCAL_START stores word pairs)
@@ -690,7 +693,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
-        if (b->multi) spw = 8;   // four pairs being filled + pending walks (round 4: 8 instead of 10 -- 105 instead of 131 GB at config 3 for -0.7 %, same box: 179.8 against 178.6 ms)
+        if (b->multi) spw = 9;   // four pairs being filled + pending walks (round 4: 8 instead of 10 -- 105 instead of 131 GB at config 3 for -0.7 %; round 5: 9, smaller -- see the margin above; 7: 190 ms, 6: 208)
         if (const char* env = dev_env("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
         if (b->multi && spw < 6) return fail("device memory: the multi-pair kernel needs six trace slots per wave");   // (batch_build falls back to the per-pair kernel)

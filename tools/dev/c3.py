@@ -13,4 +13,4 @@ if os.environ.get("C3_MODE"):   # e.g. local_start / free_query_start_gaps on to
 b = W.make_batch(H, w)
 ms = min(b.run() for _ in range(3))
 r = b.results(); cells = int(r["cells"].sum())
-print(f"{os.environ.get('BA_LIB', '')} c3 n={n} trace={trace} {b.info()['kernel']} grid {b.info().get('grid')} kernel {ms:.2f} ms {cells/ms/1e6:.1f} GCUPS bad {int((r['status']!=0).sum())}")
+print(f"{os.environ.get('BA_LIB', '')} c3 n={n} trace={trace} {b.info()['kernel']} grid {b.info().get('grid')} kernel {ms:.2f} ms {cells/ms/1e6:.1f} GCUPS bad {int((r['status']!=0).sum())} retried {b.retried()} arena {b.info().get('trace_arena_bytes', 0) / 1e9:.1f} GB")
