@@ -44,6 +44,73 @@ def _gotoh_rows(sub, nq: int, nr: int, gap_open: int, gap_extend: int) -> int:
     return int(H[nr])
 
 
+def last_row_scores(q: bytes, r: bytes, matrix, gaps, local_start: bool = False, free_reference_start: bool = False) -> np.ndarray:
+    """H[|q|][0 .. |r|] of the full-matrix affine-gap DP, for the reference's start modes (scan_block.rs:1130-1136): local_start -- an
+    alignment may start at any cell (every H floored at 0) --, free_reference_start (FREE_QUERY_START_GAPS) -- row 0 is 0 in every column:
+    reference bases before the alignment are free. FREE_QUERY_END_GAPS reads its answer off this row: max over j (the query consumed, the
+    rest of the reference free). Own code, textbook recurrences, no oracle/."""
+    tab = score_table(matrix)
+    qa = np.frombuffer(q, np.uint8).astype(np.int64)
+    ra = np.frombuffer(r, np.uint8).astype(np.int64)
+    nq, nr = len(qa), len(ra)
+    o, e = int(gaps[0]), int(gaps[1])
+    j = np.arange(nr + 1, dtype=np.int64)
+    H = np.empty(nr + 1, np.int64)
+    H[0] = 0
+    if nr:
+        H[1:] = 0 if (local_start or free_reference_start) else o + (j[1:] - 1) * e
+    F = np.full(nr + 1, NEG, np.int64)
+    for i in range(1, nq + 1):
+        F = np.maximum(F + e, H + o)
+        T = np.empty(nr + 1, np.int64)
+        T[0] = 0 if local_start else o + (i - 1) * e
+        if nr:
+            T[1:] = np.maximum(H[:-1] + tab[qa[i - 1], ra], F[1:])
+        if local_start:
+            T = np.maximum(T, 0)
+        pm = np.maximum.accumulate(T - j * e)
+        Hn = T.copy()
+        if nr:
+            Hn[1:] = np.maximum(T[1:], pm[:-1] + o + (j[1:] - 1) * e)
+        H = Hn
+        F[0] = NEG
+    return H
+
+
+def free_query_end_score(q: bytes, r: bytes, matrix, gaps, block: int, pad: int) -> int:
+    """What Block::<.., FREE_QUERY_END_GAPS>::align returns as its score when ONE block of `block` cells covers the whole matrix -- read off
+    the reference, not off oracle/: the best score is taken from lane |q| % 16 of a 16-lane running maximum over EVERY vector of every column
+    of the block (scan_block.rs:332-337 `simd_slow_extract_i16(D_max, query.len() % L)`, D_max = max over all D11 of place_block,
+    scan_block.rs:1189), i.e. over all rows i = |q| mod 16 of the block -- the last query row, but also the rows 16, 32, ... above and below
+    it, the padded ones included -- and it starts at 0 (cell (0, 0)). Only its POSITION bookkeeping is restricted to the last vectors
+    (scan_block.rs:1191-1199). Both sequences are padded to the block with the matrix's NULL byte as PaddedBytes does."""
+    tab = score_table(matrix)
+    qa = np.concatenate([np.frombuffer(q, np.uint8), np.full(block - 1 - len(q), pad, np.uint8)]).astype(np.int64)
+    ra = np.concatenate([np.frombuffer(r, np.uint8), np.full(block - 1 - len(r), pad, np.uint8)]).astype(np.int64)
+    nq, nr = len(qa), len(ra)
+    o, e = int(gaps[0]), int(gaps[1])
+    j = np.arange(nr + 1, dtype=np.int64)
+    H = np.empty(nr + 1, np.int64)
+    H[0] = 0
+    H[1:] = o + (j[1:] - 1) * e
+    F = np.full(nr + 1, NEG, np.int64)
+    k = len(q) % 16
+    best = int(H.max()) if k == 0 else NEG
+    for i in range(1, nq + 1):
+        F = np.maximum(F + e, H + o)
+        T = np.empty(nr + 1, np.int64)
+        T[0] = o + (i - 1) * e
+        T[1:] = np.maximum(H[:-1] + tab[qa[i - 1], ra], F[1:])
+        pm = np.maximum.accumulate(T - j * e)
+        Hn = T.copy()
+        Hn[1:] = np.maximum(T[1:], pm[:-1] + o + (j[1:] - 1) * e)
+        H = Hn
+        F[0] = NEG
+        if i % 16 == k:
+            best = max(best, int(H.max()))
+    return max(best, 0)
+
+
 def global_score(q: bytes, r: bytes, matrix, gaps) -> int:
     """Optimal global affine-gap score of q vs r (gaps = (open, extend), open includes the first extend)."""
     tab = score_table(matrix)

@@ -7,7 +7,7 @@ import pytest
 from block_aligner_amd import scores as S
 from block_aligner_amd import synth
 from tests.common import kat_matrix, kat_profile, parse_cigar
-from tests.gotoh import check_cigar, global_score, global_score_profile
+from tests.gotoh import check_cigar, free_query_end_score, global_score, global_score_profile, last_row_scores
 
 AA20 = b"ACDEFGHIKLMNPQRSTVWY"
 
@@ -57,6 +57,68 @@ def test_oracle_full_block_equals_full_dp(oracle, kind):
         res = oracle.align(m, q.tobytes(), r.tobytes(), (go, ge), (B, B), 0, ("trace",), cigar_eq=True)
         assert res["score"] == global_score(q.tobytes(), r.tobytes(), m, (go, ge)), (it, len(q), len(r), B)
         check_cigar(parse_cigar(res["cigar"]), q.tobytes(), r.tobytes(), m, (go, ge), res["score"], res["query_idx"], res["reference_idx"])
+
+
+SPECIAL = [("local_start",), ("free_query_start_gaps",), ("free_query_end_gaps",)]
+
+
+def special_optimum(q: bytes, r: bytes, m, gaps, mode, block=None):
+    """(score, the end positions at which it may be reported -- None: not modelled) of the start / end modes, from the full-matrix DP
+    (tests/gotoh.py)."""
+    if "free_query_end_gaps" in mode:
+        # the query consumed, the rest of the reference free -- as the reference computes it: see free_query_end_score. For queries shorter
+        # than 16 (one vector, what the reference's own tests use) that is the best cell of the last query row, or 0 at (0, 0).
+        row = last_row_scores(q, r, m, gaps)
+        if len(q) < 16 and block is None:
+            best = int(row.max())
+            ends = {(len(q), int(j)) for j in np.nonzero(row == best)[0]} if best >= 0 else set()
+            if best <= 0:
+                ends.add((0, 0))
+            return max(best, 0), ends
+        return free_query_end_score(q, r, m, gaps, block, m.NULL), None
+    row = last_row_scores(q, r, m, gaps, local_start="local_start" in mode, free_reference_start="free_query_start_gaps" in mode)
+    return int(row[len(r)]), {(len(q), len(r))}
+
+
+def test_start_end_mode_dp_reproduces_reference_kats(kats):
+    """The reference's own known answers for LOCAL_START / FREE_QUERY_START_GAPS / FREE_QUERY_END_GAPS (scan_block.rs:2181-2229) pin the
+    independent DP's reading of those modes."""
+    n = 0
+    for k in kats["align"]:
+        mode = tuple(x for x in k["mode"] if x != "trace")
+        if mode not in SPECIAL:
+            continue
+        score, ends = special_optimum(k["q"].encode(), k["r"].encode(), kat_matrix(k), tuple(k["gaps"]), mode)
+        assert score == k["expect"]["score"] and (k["expect"]["query_idx"], k["expect"]["reference_idx"]) in ends, (k["name"], score, ends)
+        n += 1
+    assert n == 5
+
+
+@pytest.mark.parametrize("mode", SPECIAL)
+def test_oracle_full_block_special_modes_equal_full_dp(oracle, mode):
+    """Round 5 (the round-4 review: FREE_QUERY_END_GAPS was left with the oracle alone): with the block covering the whole matrix the oracle's
+    score in each start / end mode is the optimum of the full-matrix DP for that mode, and its end position attains it."""
+    rng = np.random.default_rng(21 + len(mode[0]))
+    for it in range(60):
+        L = int(rng.integers(1, [14, 30, 60, 120, 250, 500][it % 6]))
+        r = synth.rand_str(rng, L, synth.DNA)
+        if it % 3 == 0:     # a query inside the reference (what the free-gap modes are for)
+            a = int(rng.integers(0, L)); b = int(rng.integers(a, L)) + 1
+            q = synth.mutate(rng, r[a:b], int(rng.integers(0, (b - a) // 5 + 1)), synth.DNA)
+        elif it % 3 == 1:   # unrelated heads on both (what LOCAL_START skips)
+            q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 20)), synth.DNA), synth.mutate(rng, r, int(rng.integers(0, L // 6 + 1)), synth.DNA)])
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 20)), synth.DNA), r])
+        else:
+            q = synth.mutate(rng, r, int(rng.integers(0, L // 4 + 1)), synth.DNA)
+        if len(q) == 0:
+            continue
+        m = S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5)))
+        ge = -int(rng.integers(1, 4)); go = ge - int(rng.integers(1, 12))
+        B = _pow2_above(max(len(q), len(r)))
+        res = oracle.align(m, q.tobytes(), r.tobytes(), (go, ge), (B, B), 0, mode + ("trace",), cigar_eq=True)
+        score, ends = special_optimum(q.tobytes(), r.tobytes(), m, (go, ge), mode, block=B)
+        assert res["score"] == score, (mode, it, len(q), len(r), B, res["score"], score)
+        assert ends is None or (res["query_idx"], res["reference_idx"]) in ends, (mode, it, res["query_idx"], res["reference_idx"], sorted(ends)[:5])
 
 
 def test_oracle_profile_full_block_equals_full_dp(oracle):

@@ -7,7 +7,7 @@ import pytest
 
 from block_aligner_amd import scores as S
 from block_aligner_amd import synth
-from tests.gotoh import check_cigar, global_score, global_score_profile
+from tests.gotoh import check_cigar, free_query_end_score, global_score, global_score_profile, last_row_scores
 
 pytestmark = pytest.mark.gpu
 AA20 = b"ACDEFGHIKLMNPQRSTVWY"
@@ -123,4 +123,49 @@ def test_config3_cigars_rescore(hip):
     for p in range(len(pairs)):
         check_cigar(runs[int(off[p]): int(off[p + 1])], pairs.query(p), pairs.reference(p), m, (-5, -1), int(res["score"][p]),
                     int(res["query_idx"][p]), int(res["reference_idx"][p]), ("x_drop",), what=p)
+    b.close()
+
+
+@pytest.mark.parametrize("B", [32, 64, 256])
+@pytest.mark.parametrize("mode", [("local_start",), ("free_query_start_gaps",), ("free_query_end_gaps",)])
+def test_full_block_start_and_end_modes_against_the_full_dp(hip, mode, B):
+    """Round 5 (the round-4 review: FREE_QUERY_END_GAPS was left with the oracle alone): with one block covering the matrix, the HIP score
+    in each start / end mode equals a from-scratch full-matrix DP of that mode -- LOCAL_START: every cell floored at 0, global end;
+    FREE_QUERY_START_GAPS: row 0 free; FREE_QUERY_END_GAPS: as the reference computes it, lane |q| % 16 of a maximum over all vectors
+    (tests/gotoh.py free_query_end_score, read off scan_block.rs:332-337, 1189) -- and the CIGAR of the start modes re-scores to it."""
+    rng = np.random.default_rng(300 + B + len(mode[0]))
+    lists = []
+    for k in range(60):
+        L = int(rng.integers(1, B))
+        r = synth.rand_str(rng, L, synth.DNA)
+        if k % 3 == 0:
+            a = int(rng.integers(0, L)); b = int(rng.integers(a, L)) + 1
+            q = synth.mutate(rng, r[a:b], int(rng.integers(0, (b - a) // 5 + 1)), synth.DNA)
+        elif k % 3 == 1:
+            q = np.concatenate([synth.rand_str(rng, int(rng.integers(0, B // 4)), synth.DNA), synth.mutate(rng, r, int(rng.integers(0, L // 6 + 1)), synth.DNA)])
+            r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, B // 4)), synth.DNA), r])
+        else:
+            q = synth.mutate(rng, r, int(rng.integers(0, L // 4 + 1)), synth.DNA)
+        q, r = q[: B - 1], r[: B - 1]
+        if len(q) == 0:
+            q = synth.rand_str(rng, 1, synth.DNA)
+        lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
+    pairs = synth.PairSet.from_lists(lists)
+    m = S.NucMatrix.new_simple(2, -3)
+    gaps = (-5, -1)
+    bits = hip.TRACE | hip.CIGAR_EQ | {"local_start": hip.LOCAL_START, "free_query_start_gaps": hip.FREE_QUERY_START_GAPS, "free_query_end_gaps": hip.FREE_QUERY_END_GAPS}[mode[0]]
+    b = hip.BatchAligner(m, gaps, (B, B), 0, bits, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    b.run()
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"])
+    for p in range(len(pairs)):
+        q, r = pairs.query(p), pairs.reference(p)
+        got = (int(res["score"][p]), int(res["query_idx"][p]), int(res["reference_idx"][p]))
+        if mode[0] == "free_query_end_gaps":
+            assert got[0] == free_query_end_score(q, r, m, gaps, B, m.NULL), (mode, B, p, len(q), len(r), got)
+        else:
+            row = last_row_scores(q, r, m, gaps, local_start=mode[0] == "local_start", free_reference_start=mode[0] == "free_query_start_gaps")
+            assert got == (int(row[len(r)]), len(q), len(r)), (mode, B, p, len(q), len(r), got, int(row[len(r)]))
+            check_cigar(runs[int(off[p]): int(off[p + 1])], q, r, m, gaps, got[0], got[1], got[2], mode, what=(mode, B, p))
     b.close()
