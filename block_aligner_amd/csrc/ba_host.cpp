@@ -994,7 +994,9 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     for (size_t p = 0; p < n; p++) total += (uint64_t)ql[p] + rl[p];
     const uint64_t slots = (uint64_t)b->grid * ba::WAVES_PER_WG * ba::SM_SLOTS;
     uint64_t thr = std::max<uint64_t>(total / std::max<uint64_t>(slots, 1) / 2, 1024);
-    thr = std::max<uint64_t>(thr, 4 * (total / std::max<size_t>(n, 1)));   // ... and many times the batch's average length: a batch of equal pairs has none
+    // ... and many times the batch's average length: a batch of equal pairs has none. (Score only: six times (~4000 for the protein set) -- same box, threshold
+    // 2400 / 3600 / 4800 / 6000: 3.86 / 3.75 / 3.71 / 4.08 ms; with traceback the pairs' walks are part of the chain: 9.68 / 9.95 / - / 10.06 ms)
+    thr = std::max<uint64_t>(thr, ((b->mode & BA_TRACE) ? 4 : 6) * (total / std::max<size_t>(n, 1)));
     // (no "the run did not end inside the cap" rule as in plan_walks: the protein set's 2048 longest of 400 k pairs fill the cap and are exactly the pairs
     // meant -- with that rule none ran alone and the launch took 8.05 instead of 3.8 ms)
     if (const char* e = dev_env("BA_EXCL_LEN2")) thr = (uint64_t)std::max(0, atoi(e));
