@@ -706,9 +706,9 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // 1000 and 2500, 0.6 % slower at 3000, more below 500); fewer than all of them, so the fill waves can never all be
         // waiting for trace slots whose walks are reserved for helpers that do not exist yet.
         b->tb_reserve = b->n_fill_waves / 2;
-        // (k_multi, large batches, round 5: the emptied waves' whole-wave walks take runs of diagonal moves at once -- one per fill wave; config 3, same
-        // box: 164.7 -> 163.3 ms; twice as many: 169.0)
-        if (b->multi && n >= 16ull * b->n_fill_waves) b->tb_reserve = b->n_fill_waves;
+        // (k_multi, round 5: the emptied waves' whole-wave walks take runs of diagonal moves at once -- one per fill wave; config 3, same box:
+        // 164.7 -> 163.3 ms, twice as many: 169.0; 50 k pairs 92.1 -> 91.0, 25 k 55.4 -> 53.5; at 16 k pairs, four per wave, half stays better: 42.7 / 43.1)
+        if (b->multi && n >= 5ull * b->n_fill_waves) b->tb_reserve = b->n_fill_waves;
         // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
         // less of the batch to walkers that only exist once the first wave has run out of pairs
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;

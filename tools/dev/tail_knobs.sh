@@ -1,2 +1,2 @@
-# the per-pair kernel at a medium batch (12.5 k config-3 pairs): trace slots per wave and their size, traceback-wave density (same box)
-for e in "X=1" "BA_SLOTS_PER_WAVE=3" "BA_SLOTS_PER_WAVE=6" "BA_SLOTS_PER_WAVE=8" "BA_TB_STRIDE=2" "BA_TB_STRIDE=8" "X=2"; do echo -n "[$e] "; env $e python tools/dev/c3.py 12500 2>&1 | tail -1; done
+# k_multi at its smallest batches: hand-offs reserved for the emptied waves' whole-wave walks (BA_TB_RESERVE; fill waves = 4096), same box
+for n in 16384 25000 50000; do for v in 2048 4096 6144 8192; do echo -n "[$n reserve $v] "; BA_TB_RESERVE=$v python tools/dev/c3.py $n 2>&1 | tail -1; done; done
