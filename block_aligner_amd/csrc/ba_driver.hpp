@@ -1235,7 +1235,9 @@ struct Aligner {
             if (!null_task) coldp()->slot_info[slot] = SlotInfo{pair, nblocks, end_i, end_j};
             coldp()->status[pair] = status;
         }
+#ifndef BA_X_NOFENCE   // (development, results invalid: what the release costs)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (is_lane(0)) {
             const uint32_t tpos = __hip_atomic_fetch_add(coldp()->tb_ctrl, 1u, BA_RLX_AGENT) & coldp()->tb_qmask;

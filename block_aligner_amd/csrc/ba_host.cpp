@@ -862,7 +862,14 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // Batches that start at 128 cells (the reference's nanopore set-up, examples/nanopore_bench.rs: 1 % .. 10 % of 10 kbp): four pairs
     // per wave while a pair's block is 128 cells (ba_multi.hpp), from the sizes at which every wave still finds four pairs.
     // (round 5: LOCAL_START / FREE_QUERY_START_GAPS batches too -- k_multi's special instantiations; FREE_QUERY_END_GAPS stays per pair)
-    b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || n >= 16384);
+    // Round 5 (tools/dev/multi_from.py, tools/dev/tail_knobs.sh; GCUPS k_multi / per-pair kernel, block 128..512, same box): the pairs must be long enough
+    // -- a pair's first block and its end game are the solo driver's, whose traced instantiation spills (section 4): with traceback, 30 k pairs of
+    // 1000 bases 1040 / 1105, 1500 bases 1181 / 1085, 2000 bases 1257 / 1075; 300..1500 bases with a 10..120-base indel each 415 / 1014 at 20 k
+    // pairs, 667 / 1112 at 200 k (before this rule those batches took k_multi); score-only 1361 / 1808 at 20 k, 2109 / 1925 at 60 k. Long pairs from
+    // 12 288 pairs on (config 3's pairs: 10 k 1005 / 975, 12.5 k 1107 / 1054, 14 k 1198 / 1119).
+    const uint64_t avg_len2 = n ? sum_len2 / n : 0;
+    const bool multi_fits = avg_len2 >= 3000 ? n >= 12288 : (!trace_mode && n >= 49152);
+    b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || multi_fits);
     if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
     if (b->small && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->small = false;   // (e.g. LDS: falls back to the per-pair kernel)
     if (!b->multi && !b->small)

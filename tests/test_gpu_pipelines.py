@@ -88,18 +88,27 @@ def test_pssm_small_blocks_at_threshold(hip, oracle, trace):
 
 @pytest.mark.parametrize("mode", MODES)
 def test_dna_128_cell_start_at_threshold(hip, oracle, mode):
-    """20 k pairs that start at 128 cells (threshold 16384): four pairs per wave with in-kernel solo mode (k_multi)."""
-    pairs = synth.make_pairs(20000, (300, 1500), (20, 150), 80, synth.DNA, seed=2025, indels=1, indel_len=(10, 120))
+    """13 k pairs of 1500..3000 bases that start at 128 cells: four pairs per wave with in-kernel solo mode (k_multi: from 12288 pairs of 3000
+    residues and more per pair); 20 k shorter ones (300..1500): the per-pair kernel (round 5: k_multi's traced solo driver loses there)."""
+    pairs = synth.make_pairs(13000, (1500, 3000), (60, 300), 80, synth.DNA, seed=2025, indels=1, indel_len=(10, 120))
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 80, mode_bits(hip, mode, True), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi"
+    b.close()
     run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 80, mode, True, ("dna 128..512", mode))
+    pairs = synth.make_pairs(20000, (300, 1500), (20, 150), 80, synth.DNA, seed=2025, indels=1, indel_len=(10, 120))
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 80, mode_bits(hip, mode, True), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_align"
+    b.close()
+    run_and_compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 80, mode, True, ("dna 128..512 short", mode))
 
 
 @pytest.mark.parametrize("mode", [("trace", "x_drop", "local_start"), ("local_start",), ("trace", "free_query_start_gaps"), ("x_drop", "free_query_start_gaps")])
 def test_special_modes_128_cell_start_at_threshold(hip, oracle, mode):
-    """Round 5, no forcing, the release library: LOCAL_START / FREE_QUERY_START_GAPS batches that start at 128 cells take k_multi from 16384 pairs
-    like the plain modes (its special instantiations, the traceback waves' records with the zero-mask bits)."""
+    """Round 5, no forcing, the release library: LOCAL_START / FREE_QUERY_START_GAPS batches that start at 128 cells take k_multi from 12288 long
+    pairs like the plain modes (its special instantiations, the traceback waves' records with the zero-mask bits)."""
     assert hip.lib().ba_dev_build() == 0
     rng = np.random.default_rng(77)
-    base = synth.make_pairs(20000, (300, 1500), (20, 150), 80, synth.DNA, seed=2026, indels=1, indel_len=(10, 120))
+    base = synth.make_pairs(14000, (1500, 3000), (60, 300), 80, synth.DNA, seed=2026, indels=1, indel_len=(10, 120))   # (k_multi: from 12288 pairs of 3000 residues and more per pair)
     lists = []
     for p in range(len(base)):   # every third pair behind unrelated heads, every third a query inside a longer reference
         q, r = np.frombuffer(base.query(p), np.uint8), np.frombuffer(base.reference(p), np.uint8)

@@ -1,2 +1,2 @@
-# k_multi at its smallest batches: hand-offs reserved for the emptied waves' whole-wave walks (BA_TB_RESERVE; fill waves = 4096), same box
-for n in 16384 25000 50000; do for v in 2048 4096 6144 8192; do echo -n "[$n reserve $v] "; BA_TB_RESERVE=$v python tools/dev/c3.py $n 2>&1 | tail -1; done; done
+# k_multi against the per-pair kernel by pair length (pairs of MF_LEN bases, ~9 % edits, 100-base tails, block 128..512, 30 k pairs), same box
+for L in 600 1000 1500; do echo "== length $L"; MF_LEN=$L python tools/dev/multi_from.py 30000 2>&1 | grep "n="; done
