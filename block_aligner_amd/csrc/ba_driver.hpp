@@ -374,6 +374,9 @@ struct TbLane {
     uint4 nrec[4]; uint32_t nq;   // the next nq records of the stack (below bidx), fetched ahead
     uint32_t tw_chunk, tw_g, tw_lane0; bool tw_ok;
     uint32_t qw0, rw0;
+    // tb_step_fast (round 6): finished runs wait here for the next call's loads to be issued (bit s of pmask: site s of the call produced
+    // one; pv = the run, po = its place in dwords from the pair's first)
+    uint32_t pv[6], po[6], pmask;
 };
 
 __device__ __forceinline__ void tb_emit(TbLane& t, uint32_t* __restrict__ out) {
@@ -595,6 +598,305 @@ __device__ __forceinline__ void tb_step(TbLane& t, uint32_t flags, uint32_t* __r
     }
 }
 
+// ------------------------------------------------------------------ round 6: tb_step_fast
+// What a lane's walk cost in round 5 (tb_step above, 8 cells per call): ~1270 vector + ~780 scalar instructions per call on the wave's
+// instruction stream (k_multi's traceback waves; ~130 per cell, and ~270 in the loop over the records fetched ahead), up to three memory
+// round trips one after the other (trace window, then the query bytes, then the reference bytes -- each load waited for before the next was
+// issued), and a store per finished run wherever it finished. Nine cells in ten of a path are matches / mismatches, so:
+//  * tb_diag: in state D a cell whose C and R flags both say "differs" is a diagonal move that leaves the state D (OP_LUT,
+//    scan_block.rs:1532-1558). The (up to) eight cells of the diagonal below the current one inside the lane's window are read with eight
+//    byte reads at addresses out of two small tables, their "is a diagonal move" bits come from a handful of packed operations, the cells'
+//    sequence bytes are compared (CIGAR_EQ: scan_block.rs:1620-1628) and the = / X runs appended to the lane's run state in BA_TB_DIAG_RUNS
+//    straight-line rounds. A call is [tb_diag] [BA_TB_FCELLS cells of the general code: a gap] [tb_diag].
+//  * the rectangle that holds the cell: compares and selects over the DEPTH records fetched ahead, the queue shifted by selects, only the
+//    records that were passed fetched again.
+//  * ONE memory round trip per call: records, trace window and both sequence windows are issued together, then waited for.
+//  * no store behind the call's loads: gfx9 counts loads and stores in one in-order counter (vmcnt), and the compiler must wait for
+//    everything when a store may or may not have been issued after the load it waits for. A finished run therefore stays in the lane's
+//    registers (TbLane::pv / po, one slot per place of the call that can finish one) and is stored in the NEXT call, right behind that call's
+//    loads -- the wait for those covers it, and nothing younger than a load is outstanding when the loop comes round.
+// (BA_TB_FAST = 0: the round-5 walk, for same-box A/B. First version of this round -- tb_diag inside tb_step, stores where the runs
+// ended, every record fetched again in every call: 27 % fewer instructions per call and config 3 at 176 instead of 162 ms, the 12 500-pair
+// batch at 53 instead of 41 ms: the stores of a call's last runs were waited for at the top of the next call, a full round trip each.)
+#ifndef BA_TB_FAST
+#define BA_TB_FAST 1
+#endif
+#ifndef BA_TB_FCELLS
+#define BA_TB_FCELLS 1
+#endif
+#ifndef BA_TB_DIAG_RUNS
+#define BA_TB_DIAG_RUNS 2
+#endif
+#ifndef BA_TB_DIAG2
+#define BA_TB_DIAG2 1   // the second tb_diag of a call (behind the general cells)
+#endif
+#ifndef BA_TB_FDEPTH
+#define BA_TB_FDEPTH 3  // records fetched ahead
+#endif
+// sixteen bytes at a 4-byte aligned address, as one load (values, not a copy through memory: the registers stay registers)
+typedef uint32_t tb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 tb_ld16(const void* p) {
+    typedef tb_u32x4 __attribute__((aligned(4))) V;
+    const tb_u32x4 v = *(const V*)p;
+    return uint4{v.x, v.y, v.z, v.w};
+}
+// v_ffbl_b32: the position of the lowest set bit, 0xffffffff for 0
+__device__ __forceinline__ uint32_t ffbl_u32(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// the walk's first records, fetched when the lane takes the walk (tb_step_fast only looks at records fetched ahead)
+__device__ __forceinline__ void tb_prefetch2(TbLane& t) {
+    if (t.bidx > 0u) t.nrec[0] = *(const uint4*)(t.blocks + t.bidx - 1);
+    if (t.bidx > 1u) t.nrec[1] = *(const uint4*)(t.blocks + t.bidx - 2);
+    t.nq = min(2u, t.bidx);
+}
+// Tables of tb_diag behind the lanes' records (8-byte aligned): per (position, k) the byte offset of the cell k steps up the diagonal.
+//   slot rectangles (records of TB_LANE_BYTES_L2: a window of 16 rows x 8 columns, byte = (row >> 3) * 32 + (column >> 1) * 8 + (row & 7)):
+//     F[u][k], u = row in the window (16 x 8 bytes), then G[w][k], w = column (8 x 8 bytes)
+//   per-pair rectangles (records of TB_LANE_BYTES: 5 lanes x 2 column groups, byte = (newer group ? 0 : 20) + row * 2 + ((column & 3) >> 1)):
+//     C[x][k], x = column in the window's 8 columns (8 x 8 bytes); the row term is arithmetic
+template <bool L2W>
+__device__ __forceinline__ void tb_diag_lut_fill(unsigned char* dlut) {
+    if constexpr (L2W) {
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const uint32_t idx = (uint32_t)lane_id() + 64u * e;   // 0 .. 191
+            const uint32_t k = idx & 7u, p = idx >> 3;              // p < 16: F, else G
+            const uint32_t x = (p - k) & 15u, c = ((p - 16u) - k) & 7u;
+            dlut[idx] = (unsigned char)(p < 16u ? (((x & 8u) << 2) | (x & 7u)) : ((c >> 1) << 3));
+        }
+    }
+    {   // C: alone (records of TB_LANE_BYTES) or behind F and G (a kernel of slot rectangles also walks the rectangles its solo driver wrote)
+        const uint32_t idx = (uint32_t)lane_id(), k = idx & 7u, x = ((idx >> 3) - k) & 7u;
+        dlut[(L2W ? TB_DIAG_LUT_L2 - TB_DIAG_LUT_STD : 0u) + idx] = (unsigned char)((x < 4u ? 20u : 0u) + ((x & 3u) >> 1));
+    }
+}
+// a finished run into slot S of the lane's deferred stores (tb_flush); ovf: the pair's range is full
+template <int S>
+__device__ __forceinline__ void tb_push(TbLane& t, const bool cond, const uint32_t val, bool& ovf) {
+    const bool room = t.wp != t.lo, go = cond && room;
+    t.wp -= go ? 1u : 0u;
+    t.pv[S] = go ? val : t.pv[S];
+    t.po[S] = go ? (uint32_t)t.wp - (uint32_t)t.lo : t.po[S];
+    t.pmask |= go ? (1u << S) : 0u;
+    ovf = ovf || (cond && !room);
+}
+__device__ __forceinline__ void tb_flush(TbLane& t, uint32_t* __restrict__ out) {
+#pragma unroll
+    for (int s = 0; s < 6; s++) if ((t.pmask >> s) & 1u) out[t.lo + t.po[s]] = t.pv[s];
+    t.pmask = 0;
+}
+
+// (see above) t: the lane's walk; dlut: the tables; lrec: the lane's record; S0: the first of this call site's two slots. Every lane of the
+// wave executes this; a lane that cannot use it (another state, no window, a rectangle of the other layout) commits nothing.
+template <bool L2W, int SEQ_Q, int SEQ_R, int S0>
+__device__ __forceinline__ void tb_diag(TbLane& t, const bool eq, const unsigned char* lrec, const unsigned char* dlut, bool& ovf) {
+    static_assert(BA_TB_DIAG_RUNS >= 1 && BA_TB_DIAG_RUNS <= 2, "two slots per call site");
+    const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
+    const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
+    bool ok = t.in_rect && t.tw_ok && t.i >= t.bi && t.j >= t.bj && (t.table == 0u || t.table == TB_PENDING);
+    uint32_t K = min(min(t.i, t.j), min(v, w) + 1u);   // cells 0 .. K - 1 of the diagonal: inside the rectangle, and a diagonal move from them stays inside the matrix
+    uint32_t alo, ahi;                                 // the eight cells' byte offsets in the record, packed
+    {
+        // a per-pair rectangle's window (5 lanes x 2 column groups): row u / column x inside it (x: + 4 = the newer group; w <= 4 tw_g + 3)
+        const uint32_t u = (v & 127u) - 2u * t.tw_lane0, x = w + 4u - 4u * t.tw_g;
+        const bool ok_s = !t.l2 && (v >> 7) == t.tw_chunk && u < 10u && x < 8u;
+        const uint32_t K_s = min(u, x) + 1u;
+        const uint2 C = *(const uint2*)(dlut + (L2W ? TB_DIAG_LUT_L2 - TB_DIAG_LUT_STD : 0u) + (x & 7u) * 8u);
+        const uint32_t r2 = (2u * (u & 15u)) * 0x01010101u;   // (a borrow out of a byte only reaches cells further up, which are then outside the window too)
+        alo = ((r2 - 0x06040200u) + C.x) & 0x3f3f3f3fu; ahi = ((r2 - 0x0e0c0a08u) + C.y) & 0x3f3f3f3fu;
+        if constexpr (L2W) {
+            // a slot rectangle's window (16 rows x 8 columns)
+            const uint32_t u2 = v - 8u * t.tw_lane0;
+            const bool ok_2 = t.l2 && t.tw_chunk == 0xffffu && u2 < 16u;
+            const uint2 F = *(const uint2*)(dlut + (u2 & 15u) * 8u), G = *(const uint2*)(dlut + 128u + (w & 7u) * 8u);
+            alo = t.l2 ? F.x + G.x : alo; ahi = t.l2 ? F.y + G.y : ahi;
+            ok = ok && (ok_2 || ok_s);
+            K = min(K, t.l2 ? u2 + 1u : K_s);
+        } else {
+            ok = ok && ok_s;
+            K = min(K, K_s);
+        }
+    }
+    const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
+    if (eq) { ok = ok && qo <= 15u && ro <= 15u; K = min(K, min(qo, ro) + 1u); }
+    K = ok ? min(K, 8u) : 0u;
+    uint32_t b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) b[k] = lrec[((k < 4 ? alo : ahi) >> (8 * (k & 3))) & 0xffu];
+    // "both low flags of the cell's nibble set" for the eight cells: the nibble alternates with the column's parity
+    const uint32_t sh0 = (w & 1u) * 4u;
+    const uint32_t e4 = (b[0] | (b[2] << 8) | (b[4] << 16) | (b[6] << 24)) >> sh0, o4 = (b[1] | (b[3] << 8) | (b[5] << 16) | (b[7] << 24)) >> (4u - sh0);
+    const uint32_t z = ((e4 & (e4 >> 1)) & 0x01010101u) | (((o4 & (o4 >> 1)) & 0x01010101u) << 4);   // bit 4k: cell k is a match / mismatch in state D
+    uint32_t n = ffbl_u32(~z & 0x11111111u) >> 2;   // (every cell is one: ffbl = -1; K <= 8 bounds it below)
+    // a pending scan-direction gap ends at this cell if it was opened here (tb_resolve: stored bit 3 clear), else the general code goes on with the gap
+    const bool d_state = t.table == 0u || !((e4 >> 3) & 1u);
+    n = d_state ? min(n, K) : 0u;
+    uint32_t ne = 0;   // bit 4k: the bytes of cell k differ
+    if (eq) {
+        const unsigned char* qb = lrec + SEQ_Q + (ok ? qo : 7u) - 7u; const unsigned char* rb = lrec + SEQ_R + (ok ? ro : 7u) - 7u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) ne |= min((uint32_t)qb[7 - k] ^ (uint32_t)rb[7 - k], 1u) << (4 * k);
+    }
+    uint32_t pos = 0;
+#pragma unroll
+    for (int it = 0; it < (BA_TB_DIAG_RUNS); it++) {
+        if (it > 0 && !eq) break;   // (without CIGAR_EQ the cells are one run of M)
+        const uint32_t rem = n - pos;
+        const uint32_t cur = ne >> ((4u * pos) & 31u);
+        const uint32_t is_x = cur & 1u;
+        const uint32_t y = (cur ^ (0u - is_x)) & 0x11111111u;     // bit 4k: cell pos + k is of the other kind
+        const uint32_t len = min(ffbl_u32(y) >> 2, rem);           // (no such cell: ffbl = -1, more than any rem; rem = 0: nothing happens below)
+        const uint32_t op = eq ? 2u + is_x : 1u;
+        const bool same = op == t.run_op;
+        if (it == 0) tb_push<S0>(t, rem > 0u && !same && t.run_len != 0u, (t.run_len << 4) | t.run_op, ovf);
+        else tb_push<S0 + 1>(t, rem > 0u && !same && t.run_len != 0u, (t.run_len << 4) | t.run_op, ovf);
+        t.run_len = same ? t.run_len + len : (rem > 0u ? len : t.run_len);
+        t.run_op = rem > 0u ? op : t.run_op;
+        pos += len;
+    }
+    t.i -= pos; t.j -= pos;
+    t.table = pos ? 0u : t.table;
+}
+
+// One call of a lane's walk (CIGAR_EQ is the only mode bit: LOCAL_START / FREE_QUERY_START_GAPS walks keep tb_step). LB: TB_LANE_BYTES
+// (per-pair rectangles only) or TB_LANE_BYTES_L2 (slot rectangles too; tb_diag then takes only those).
+template <int DEPTH, int LB>
+__device__ __forceinline__ void tb_step_fast(TbLane& t, const bool eq, uint32_t* __restrict__ out, unsigned char* lrec, const unsigned char* lut, const unsigned char* dlut) {
+    static_assert(DEPTH >= 2 && DEPTH <= 4 && (BA_TB_FCELLS) >= 1 && (BA_TB_FCELLS) <= 2, "");
+    constexpr bool L2OK = LB == (int)TB_LANE_BYTES_L2;
+    constexpr int SEQ_Q = L2OK ? 64 : 40, SEQ_R = SEQ_Q + 16;   // byte offsets of the sequence windows in the record
+    // ---- 1. the rectangle that holds the cell (scan_block.rs:1578-1590): the first of the records fetched ahead that does
+    if (!t.in_rect || !(t.i >= t.bi && t.j >= t.bj)) {
+        if (t.bidx == 0) { tb_fail(t); return; }
+        bool found = false;
+        uint32_t take = t.nq;                    // none of them: all are passed
+        uint4 rec = t.nrec[0];
+#pragma unroll
+        for (int a = DEPTH - 1; a >= 0; a--) {   // (last to first: the first record that holds the cell wins)
+            const bool c = (uint32_t)a < t.nq && t.i >= (t.nrec[a].x & 0x7fffffffu) && t.j >= t.nrec[a].y;
+            rec.x = c ? t.nrec[a].x : rec.x; rec.y = c ? t.nrec[a].y : rec.y; rec.z = c ? t.nrec[a].z : rec.z; rec.w = c ? t.nrec[a].w : rec.w;
+            take = c ? (uint32_t)a + 1u : take;
+            found = found || c;
+        }
+        // the queue moves up by `take`; what it lacks then is fetched (for the next call)
+        const uint32_t nq_old = t.nq;
+        t.bidx -= take;
+        uint4 nn[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            nn[k] = t.nrec[k];
+            bool have = false;
+#pragma unroll
+            for (int sft = 1; k + sft < DEPTH; sft++) {
+                const bool m = take == (uint32_t)sft && (uint32_t)(k + sft) < nq_old;
+                nn[k].x = m ? t.nrec[k + sft].x : nn[k].x; nn[k].y = m ? t.nrec[k + sft].y : nn[k].y; nn[k].z = m ? t.nrec[k + sft].z : nn[k].z; nn[k].w = m ? t.nrec[k + sft].w : nn[k].w;
+                have = have || m;
+            }
+            if (!have && t.bidx > (uint32_t)k) nn[k] = *(const uint4*)(t.blocks + t.bidx - 1 - k);
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) t.nrec[k] = nn[k];
+        t.nq = min((uint32_t)DEPTH, t.bidx);
+        t.in_rect = found;
+        t.l2 = L2OK && (rec.x >> 31); t.bi = rec.x & 0x7fffffffu; t.bj = rec.y;
+        t.right = rec.w >> 31;
+        t.tbase = rec.w & 0x3fffffffu;
+        const uint32_t Hv = t.right ? (rec.z & 0xffffu) : (rec.z >> 16);
+        t.nch = Hv > 128 ? Hv / 128 : 1; t.nl = Hv > 128 ? 64 : Hv / 2;
+        t.tw_ok = false;
+        if (!found) return;
+        if (rec.w & 0x40000000u) { tb_fail(t); return; }   // a speculative grow that was never materialised: must not be on a path
+    }
+    // ---- 2. what the cell's neighbourhood needs from memory: the trace window and the sequence windows, all loads issued before any is waited for
+    const uint32_t ci0 = t.i - t.bi, cj0 = t.j - t.bj;
+    const uint32_t v0 = t.right ? ci0 : cj0, w0 = t.right ? cj0 : ci0;
+    const bool is_l2 = L2OK && t.l2;
+    bool ld_l2 = false, ld_std = false;
+    if constexpr (L2OK) {
+        // a slot's rectangle (128 or 32 x 8 cells, one chunk): a lane's 8 cells x 8 columns are 32 contiguous bytes (word lane8 * 8 + (column >> 1) * 2 + cell quad);
+        // the window is the two 8-cell lanes ending at the cell's: 64 contiguous bytes. tw_lane0: the first lane8
+        const uint32_t L8 = v0 >> 3;
+        ld_l2 = is_l2 && !(t.tw_ok && t.tw_chunk == 0xffffu && L8 - t.tw_lane0 < 2u);
+        if (ld_l2) { t.tw_chunk = 0xffffu; t.tw_g = 0; t.tw_lane0 = L8 ? L8 - 1 : 0u; t.tw_ok = true; }
+    }
+    {
+        // per-pair rectangles: the two column groups ending at the cell's and the five lanes ending at the cell's (five consecutive words per group)
+        const uint32_t chunk = v0 >> 7, lc = (v0 & 127) >> 1, g = w0 >> 2;
+        ld_std = !is_l2 && !(t.tw_ok && chunk == t.tw_chunk && t.tw_g - g < 2u && lc - t.tw_lane0 < 5u);
+        if (ld_std) { t.tw_chunk = chunk; t.tw_g = g; t.tw_lane0 = min(lc >= 4 ? lc - 4 : 0u, t.nl - 5u); t.tw_ok = true; }   // (nl >= 8)
+    }
+    // four 16-byte loads either way (one region of straight-line loads: registers shared between two regions would make the second wait for the
+    // first's loads): slot rectangle -- the window's 64 bytes; per-pair rectangle -- the newer group's words 0..3, the older group's, then words 4.. of
+    // each (of which only the first is used; a rectangle's words are followed by 64 words of slack at the end of the slot)
+    uint4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0}, wc = {0, 0, 0, 0}, wd = {0, 0, 0, 0};
+    {
+        const uint32_t* tb0 = t.trace + t.tbase;
+        const uint32_t o_hi = (t.tw_g * t.nch + t.tw_chunk) * t.nl + t.tw_lane0, o_lo = t.tw_g ? o_hi - t.nch * t.nl : o_hi;
+        const uint32_t o_l2 = t.tw_lane0 * 8;
+        const uint32_t o0 = is_l2 ? o_l2 : o_hi, o1 = is_l2 ? o_l2 + 4 : o_lo, o2 = is_l2 ? o_l2 + 8 : o_hi + 4, o3 = is_l2 ? o_l2 + 12 : o_lo + 4;
+        if (ld_l2 || ld_std) { wa = tb_ld16(tb0 + o0); wb = tb_ld16(tb0 + o1); wc = tb_ld16(tb0 + o2); wd = tb_ld16(tb0 + o3); }
+    }
+    uint4 qv = {0, 0, 0, 0}, rv = {0, 0, 0, 0};
+    const bool ld_q = eq && (t.qw0 == 0xffffffffu || t.i < t.qw0 + 8 || t.i >= t.qw0 + 16);   // fewer than 8 positions left below the current one
+    const bool ld_r = eq && (t.rw0 == 0xffffffffu || t.j < t.rw0 + 8 || t.j >= t.rw0 + 16);
+    if (ld_q) { t.qw0 = t.i >= 12 ? (t.i - 12) & ~3u : 0; qv = tb_ld16(t.q + t.qw0); }
+    if (ld_r) { t.rw0 = t.j >= 12 ? (t.j - 12) & ~3u : 0; rv = tb_ld16(t.r + t.rw0); }
+    // ---- 3. the runs the previous call finished: stored behind this call's loads
+    tb_flush(t, out);
+    // ---- 4. into the lane's record
+    if constexpr (L2OK) if (ld_l2) { uint4* lw = (uint4*)lrec; lw[0] = wa; lw[1] = wb; lw[2] = wc; lw[3] = wd; }
+    if (ld_std) {
+        uint32_t* lw = (uint32_t*)lrec;
+        lw[0] = wa.x; lw[1] = wa.y; lw[2] = wa.z; lw[3] = wa.w; lw[4] = wc.x; lw[5] = wb.x; lw[6] = wb.y; lw[7] = wb.z; lw[8] = wb.w; lw[9] = wd.x;
+    }
+    if (ld_q) { uint32_t* lw = (uint32_t*)lrec + SEQ_Q / 4; lw[0] = qv.x; lw[1] = qv.y; lw[2] = qv.z; lw[3] = qv.w; }
+    if (ld_r) { uint32_t* lw = (uint32_t*)lrec + SEQ_R / 4; lw[0] = rv.x; lw[1] = rv.y; lw[2] = rv.z; lw[3] = rv.w; }
+    // ---- 5. the walk: runs of diagonal moves, a gap cell (the general code: tb_step's), runs of diagonal moves
+    bool ovf = false;
+    tb_diag<L2OK, SEQ_Q, SEQ_R, 0>(t, eq, lrec, dlut, ovf);
+    {
+        bool alive = true;
+#pragma unroll
+        for (int s = 0; s < (BA_TB_FCELLS); s++) {
+            alive = alive && (t.i > 0 || t.j > 0) && t.i >= t.bi && t.j >= t.bj;
+            const uint32_t ci = t.i - t.bi, cj = t.j - t.bj;
+            const uint32_t v = t.right ? ci : cj, w = t.right ? cj : ci;
+            const uint32_t lc = (v & 127) >> 1;
+            const uint32_t gi = t.tw_g - (w >> 2);
+            uint32_t baddr;
+            if (L2OK && t.l2) {
+                const uint32_t k8 = (v >> 3) - t.tw_lane0;
+                alive = alive && t.tw_chunk == 0xffffu && k8 <= 1u;
+                baddr = k8 * 32 + (w >> 1) * 8 + ((v >> 2) & 1) * 4 + (v & 3);
+            } else {
+                const uint32_t k = lc - t.tw_lane0;
+                alive = alive && (v >> 7) == t.tw_chunk && gi <= 1u && k <= 4u;             // else: left the window, the next call reloads it
+                baddr = gi * 20 + k * 4 + (v & 1) * 2 + ((w & 3) >> 1);
+            }
+            const uint32_t qo = t.i - t.qw0, ro = t.j - t.rw0;
+            const uint32_t byte = lrec[alive ? baddr : 0u];
+            const uint32_t qb = lrec[SEQ_Q + (qo & 15u)], rb = lrec[SEQ_R + (ro & 15u)];    // for a match at this cell (read alongside, used if needed)
+            const uint32_t nib = ((byte >> ((w & 1) * 4)) ^ 15u) & 15u;                      // all four bits stored as "differs"
+            const uint32_t table = tb_resolve(t.right, t.table, nib);
+            const uint32_t m = lut[((uint32_t)t.right << 6) | (table << 4) | nib];          // op | di << 3 | dj << 4 | next << 5
+            uint32_t op = m & 7u;
+            const uint32_t di = (m >> 3) & 1u, dj = (m >> 4) & 1u;
+            const bool is_match = eq && op == 1;
+            alive = alive && !(is_match && (qo > 15u || ro > 15u));                         // the next call refills the sequence windows
+            if (is_match) op = qb == rb ? 2u : 3u;
+            if (alive && (di > t.i || dj > t.j)) { tb_fail(t); alive = false; }             // would leave the matrix: corrupt trace
+            const bool same = op == t.run_op;
+            if (s == 0) tb_push<2>(t, alive && !same && t.run_len != 0u, (t.run_len << 4) | t.run_op, ovf);
+            else tb_push<3>(t, alive && !same && t.run_len != 0u, (t.run_len << 4) | t.run_op, ovf);
+            t.i -= alive ? di : 0u; t.j -= alive ? dj : 0u;
+            t.table = alive ? tb_next(t.right, m >> 5, v) : t.table;
+            t.run_len = alive ? (same ? t.run_len + 1 : 1u) : t.run_len;
+            t.run_op = alive ? op : t.run_op;
+        }
+    }
+    if constexpr ((BA_TB_DIAG2) != 0) tb_diag<L2OK, SEQ_Q, SEQ_R, 4>(t, eq, lrec, dlut, ovf);
+    if (ovf) { t.status |= ST_CIGAR_OVERFLOW; t.i = t.j = 0; }
+}
+
 // `nlanes` lanes of the wave take part. dedicated: a traceback wave proper. Otherwise a fill wave that found the work
 // counter exhausted: the batch ends with one full walk latency after the last fill, and a walk is a chain of ~2 500
 // dependent iterations whose length grows with the number of lanes walking in lockstep, so the last `tb_reserve`
@@ -612,12 +914,16 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
     // this lane's LDS record and the move table (scan_block.rs:1532-1558), two entries built per lane
     unsigned char* lut = tb_lds;
     unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * (uint32_t)LB;
+    // round 6: tb_step_fast for every walk that needs no mode bit but CIGAR_EQ; tb_diag's tables sit behind the records of the lanes that take part
+    constexpr bool FASTP = (BA_TB_FAST) != 0 && LB != (int)TB_LANE_BYTES_LOC;
+    unsigned char* dlut = tb_lds + ((TB_LUT_BYTES + nlanes * (uint32_t)LB + 7u) & ~7u);
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const uint32_t idx = (uint32_t)lane_id() + 64u * e;
         const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);   // (bit 3 of the cell's nibble is resolved before the lookup)
         lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
     }
+    if constexpr (FASTP) tb_diag_lut_fill<LB == (int)TB_LANE_BYTES_L2>(dlut);
     lds_sync();
     // A walk is a long dependent chain of short instructions sharing its SIMD with VALU-saturating fill waves; without
     // priority it gets a quarter of the issue slots and every pending walk pins a whole trace slot meanwhile.
@@ -669,23 +975,30 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
                 t.lo = bp.cig_off[t.pair]; t.wp = bp.cig_off[t.pair + 1];
                 t.status = bp.status[t.pair];
                 if (t.status || (bp.flags & 0x200u)) t.i = t.j = 0;          // the fill failed (or development switch: skip the walk)
+                if constexpr (FASTP) tb_prefetch2(t);
                 phase = WALK;
             }
         }
         if (walking) {
 #ifdef BA_TIMING
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-            if (t.i > 0 || t.j > 0) tb_step<CELLS, DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut, c_sec);
+            if (t.i > 0 || t.j > 0) {
+                if constexpr (FASTP) tb_step_fast<BA_TB_FDEPTH, LB>(t, eq != 0u, bp.cig_ops, lrec, lut, dlut);
+                else tb_step<CELLS, DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut, c_sec);
+            }
             c_sec[2] += __builtin_amdgcn_s_memtime() - tq0;
 #else
             // (an emptied fill wave's few lanes -- the batch's last walks, each a chain of memory round trips that ends the launch --
             // take more cells per call and look further ahead; dedicated waves share their SIMD with fill waves: see tb_step)
             if (t.i > 0 || t.j > 0) {
+                if constexpr (FASTP) tb_step_fast<BA_TB_FDEPTH, LB>(t, eq != 0u, bp.cig_ops, lrec, lut, dlut);
+                else
                 if (BA_HELPER_CELLS != CELLS && !dedicated) tb_step<BA_HELPER_CELLS, BA_WALK_DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
                 else tb_step<CELLS, DEPTH, LB>(t, eq, bp.cig_ops, lrec, lut);
             }
 #endif
             if (!(t.i > 0 || t.j > 0)) {
+                if constexpr (FASTP) tb_flush(t, bp.cig_ops);
                 tb_emit(t, bp.cig_ops);
                 bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
                 if (t.status) bp.status[t.pair] = t.status;
@@ -817,12 +1130,16 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
     const uint32_t eq = bp.flags & flag_mask;
     unsigned char* lut = tb_lds;
     unsigned char* lrec = tb_lds + TB_LUT_BYTES + (uint32_t)lane_id() * (uint32_t)LB;
+    constexpr bool FASTP = (BA_TB_FAST) != 0 && !LOC;   // (round 6: tb_step_fast; tb_diag's tables behind the records)
+    unsigned char* dlut = tb_lds + ((TB_LUT_BYTES + 64u * (uint32_t)LB + 7u) & ~7u);
+    static_assert(LOC || ((TB_LUT_BYTES + 64u * (uint32_t)LB + 7u) & ~7u) + (L2OK ? TB_DIAG_LUT_L2 : TB_DIAG_LUT_STD) <= WAVE_LDS, "k_walk LDS: tb_diag's tables");
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         const uint32_t idx = (uint32_t)lane_id() + 64u * e;
         const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);
         lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
     }
+    if constexpr (FASTP) tb_diag_lut_fill<L2OK>(dlut);
     lds_sync();
     TbLane t{};
     bool walking = false, more = true;
@@ -860,6 +1177,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             const Move mv = tb_lut(idx >> 6, idx & 3, (idx >> 2) & 1, (idx >> 4) & 3);
             lut[idx] = (unsigned char)(mv.op | (mv.di << 3) | (mv.dj << 4) | (mv.next << 5));
         }
+        if constexpr (FASTP) tb_diag_lut_fill<L2OK>(dlut);
         lds_sync();
     }
     uint32_t w_next = 0, w_end = 0;   // this wave's share of the batch order: 64 pairs per atomic (a returning atomic is a full memory
@@ -892,6 +1210,7 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
                 t.lo = bp.cig_off[p]; t.wp = bp.cig_off[p + 1];
                 t.status = bp.status[p];
                 if (t.status || (bp.flags & 0x200u)) t.i = t.j = 0;   // the fill failed (or development switch: skip the walk)
+                if constexpr (FASTP) tb_prefetch2(t);
                 walking = true;
             }
         }
@@ -902,11 +1221,13 @@ __device__ __forceinline__ void traceback_all(const BatchParams& bp, uint32_t fl
             if (t.i > 0 || t.j > 0) {
                 // (k_small's LOCAL_START / FREE_QUERY_START_GAPS batches: the early stops, scan_block.rs:1597-1611)
                 if constexpr (LOC) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, spec_flags | (eq ? (uint32_t)F_CIGAR_EQ : 0u), bp.cig_ops, lrec, lut);
+                else if constexpr (FASTP) { if (eq) tb_step_fast<BA_TB_FDEPTH, LB>(t, true, bp.cig_ops, lrec, lut, dlut); else tb_step_fast<BA_TB_FDEPTH, LB>(t, false, bp.cig_ops, lrec, lut, dlut); }
                 else
                 if (eq) tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, (uint32_t)F_CIGAR_EQ, bp.cig_ops, lrec, lut);
                 else tb_step<BA_WALK_CELLS, BA_WALK_DEPTH, LB>(t, 0u, bp.cig_ops, lrec, lut);
             }
             if (!(t.i > 0 || t.j > 0)) {
+                if constexpr (FASTP) tb_flush(t, bp.cig_ops);
                 tb_emit(t, bp.cig_ops);
                 bp.cig_len[t.pair] = t.status ? 0u : (uint32_t)(bp.cig_off[t.pair + 1] - t.wp);
                 if (t.status) bp.status[t.pair] = t.status;

@@ -152,9 +152,15 @@ constexpr uint32_t TB_LANE_BYTES_L2 = 100;   // k_multi's traceback waves (16 tr
 // or a slot rectangle's 16 trace + 4 mask words --, then the sequence windows
 constexpr uint32_t TB_LANE_BYTES_LOC = 116, TB_LDS_BYTES_LOC = 7680;
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_LOC <= TB_LDS_BYTES_LOC, "k_walk LDS (LOCAL_START)");
-constexpr uint32_t TB_LDS_BYTES_L2 = 6656;   // k_walk over a k_small batch: the move table + 64 records of TB_LANE_BYTES_L2
+constexpr uint32_t TB_LDS_BYTES_L2 = 6784;   // k_walk over a k_small batch: the move table + 64 records of TB_LANE_BYTES_L2
 static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= TB_LDS_BYTES_L2, "k_walk LDS (slot rectangles)");
 static_assert(MQ_LDS_BYTES % 16 == 0 && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 <= MQ_LDS_BYTES, "k_multi LDS");
-static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES <= lds_wave_bytes_h(128), "traceback LDS regions");
+// round 6: behind the records the tables of tb_diag (ba_driver.hpp: runs of diagonal moves at once), 8-byte aligned
+constexpr uint32_t TB_DIAG_LUT_L2 = 256, TB_DIAG_LUT_STD = 64;   // (L2: F 128 + G 64 + C 64 bytes)
+static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES + TB_DIAG_LUT_STD <= TB_LDS_BYTES && TB_LUT_BYTES + TB_LANE_BYTES + 8 + TB_DIAG_LUT_STD <= lds_wave_bytes_h(128), "traceback LDS regions");
+static_assert((TB_LUT_BYTES + 64 * TB_LANE_BYTES) % 8 == 0 && (TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2) % 8 == 0, "tb_diag's tables are read 8 bytes at a time");
+static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 + TB_DIAG_LUT_L2 <= TB_LDS_BYTES_L2 && TB_LUT_BYTES + 64 * TB_LANE_BYTES_L2 + TB_DIAG_LUT_L2 <= MQ_LDS_BYTES, "tb_diag's tables (slot rectangles)");
+// the special-mode instantiations of k_multi / k_small put TB_LANE_BYTES_LOC records into a wave's own region
+static_assert(TB_LUT_BYTES + 64 * TB_LANE_BYTES_LOC <= MQ_LDS_BYTES && TB_LUT_BYTES + 64 * TB_LANE_BYTES_LOC <= SM_LDS_BYTES, "special-mode walk records in a wave's region");
 
 }  // namespace ba

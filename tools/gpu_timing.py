@@ -5,7 +5,7 @@ import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from block_aligner_amd import hip as H, scores as S, synth
-H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), "libblock_aligner_hip_timing.so")
+H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), os.environ.get("BA_TIMING_LIB", "libblock_aligner_hip_timing.so"))
 n, trace = int(sys.argv[1]), int(sys.argv[2])
 maxb = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 pairs = synth.make_pairs(n, 10000, 1000, 500, synth.DNA, seed=1234)
