@@ -168,7 +168,7 @@ def secondary_line(np, H, W, o, w, cores):
 
 def secondary_sized(np, H, W, o, cores, n=20000):
     """Every pair with its own block range (ba_sized_batch_*: percent_len 1 % .. 10 % of the pair's length, examples/nanopore_bench_global.rs:144-171)
-    on a mixed-length read set: the pairs are binned by range, the bins run one after the other; `gcups` counts all of them. EVERY pair is compared
+    on a mixed-length read set: the pairs are binned by range, the bins are launched together (the reported time is the host's wall clock from the first launch to the last completion, not a sum of HIP-event times); `gcups` counts all of them. EVERY pair is compared
     with the oracle run with its own range (bin by bin)."""
     from block_aligner_amd import scores as S
     pairs = W.mixed_reads(n)
@@ -533,6 +533,14 @@ def main():
                 secondary.append(secondary_line(np, H, W, o, W.config_free_end(50000), cores))
                 # every pair with its own block range (round 5: ba_sized_batch_*)
                 secondary.append(secondary_sized(np, H, W, o, cores))
+                # the headline workload at the batch sizes 8 and 4 GPUs get of the north-star's 100 000 pairs (BASELINE.json configs[2]: "1 -> 8 GPUs";
+                # the first pairs of the same seeded set): what strong scaling would start from -- a launch of one or two rounds of the machine's
+                # 15 360 slots, bound by a pair's chain of steps and one path's walk rather than by issue slots (round 6)
+                if trace and not a.strong:
+                    for n_part in (12500, 25000):
+                        wp = W.config3(n_part, a.len, a.edits, a.tail, seed=1234, trace=True, workers=min(8, usable_cpus()), size=size)
+                        wp.name += " (%d of the north-star's 100 000: the share of %d GPUs)" % (n_part, 100000 // n_part)
+                        secondary.append(secondary_line(np, H, W, o, wp, cores))
                 # ... and the same configurations at the batch sizes of the reference's own harnesses (BASELINE.json: 10 k pairs,
                 # examples/nanopore_bench.rs:73-95; 7 k protein pairs, examples/uc_bench.rs:79-104; 11 k PSSMs, examples/pssm_bench.rs:94-100):
                 # a few pairs per wave, bound by the longest pair's chain of steps rather than by the machine

@@ -209,6 +209,29 @@ struct FillConsts {
     int gap_extend;
 };
 
+// The scan constants of a lane that owns cells 2 lane, 2 lane + 1 of a 128-cell chunk (every kernel's two-cells-per-lane code; `lane` is the
+// lane inside the chunk -- the row lane of k_quad). One definition: the kernels and the device-side known-answer test of the lane
+// primitives (k_lane_kat, ba_kernels.hip) build the same values.
+__device__ __forceinline__ FillConsts make_fill_consts(int lane, int gap_open, int g) {
+    FillConsts fc;
+    fc.gap_extend = g;
+    fc.go2 = splat(gap_open); fc.ge2 = splat(g); fc.ome2 = splat(clamp16(gap_open - g));   // (scalar arithmetic: stays in an SGPR)
+    fc.g12 = pk(g, 2 * g);
+    fc.ones = 0x00010001;
+    fc.laneKG = lane * 2 * g; fc.lanem1KG = lane ? (lane - 1) * 2 * g : -32768;
+    // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 of each
+    // 16-cell vector see a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
+    int v[2];
+    for (int h = 0; h < 2; h++) {
+        const int k = (2 * lane + h) & 15;
+        const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
+        v[h] = mult ? max(-32768, mult * g) : -32768;
+    }
+    fc.vconst = pk(v[0], v[1]);
+    fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * g)), max(v[1], max(-32768, (2 * lane + 2) * g)));
+    return fc;
+}
+
 // one pair's AAProfile image (layout in ba_params.h)
 struct ProfileView {
     const signed char* pos_aa; const short* aa_pos; const short* goC; const short* clC; const short* goR;
@@ -300,6 +323,19 @@ __device__ __forceinline__ int load_pair_i16(const short* p) { int v; __builtin_
 // column's last cell unpredicated; only the last lane's address is the real one).
 struct FastOut { int mx, row, col; int act_max8, pas_max8, corner_new; };
 
+// R11 of a single-chunk column, two cells per lane (avx2.rs:297-338 per 16-cell vector + the carry from vector to vector,
+// scan_block.rs:1144-1150; the column's R starts from MIN = 0 above its first cell), from x = D11_open (scan_block.rs:1143): the step inside the
+// register, a SCAN-lane max-plus scan on values re-based by lane * 2g, the lanes above applied, the zero-shift-in artefact with the MIN carry
+// folded in (FillConsts::vconst_top). No clamp: lane l >= 1 receives pm[l-1] + (l-1) 2g >= R(lane l-1) >= -32768, lane 0 the filler -32768.
+template <int SCAN>
+__device__ __forceinline__ int fast_scan(int x, const FillConsts& fc) {
+    const s16x2 t2 = as_s(adds(x, fc.ge2));
+    int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
+    const int pm = prefix_max_lanes<SCAN>((int)as_s(r).y - fc.laneKG);
+    const s16x2 cs = as_s(add_shr1(pm, fc.lanem1KG));
+    return vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst_top);
+}
+
 // LANES: 64 / 32 / 16 = the block is exactly 128 / 64 / 32 cells (lane count, activity tests, trace indices and the depth of
 // the scan are then compile-time); 0 = any single-chunk size (nl_in lanes).
 // SP (round 5): the instantiation of the special-mode kernels. rz2 = the relative zero in both halves for LOCAL_START (every cell's D is at least that,
@@ -341,13 +377,7 @@ __device__ __forceinline__ void fast_rect(const char* table, const FillConsts& f
         const int cn = vmax(adds(c, fc.ge2), copen);
         d11 = vmax(d11, cn);
         const int x = adds(d11, fc.ome2);            // D11_open
-        const s16x2 t2 = as_s(adds(x, fc.ge2));
-        int r = vmax(x, as_i(s16x2{t2.x, t2.x}));
-        const int pm = prefix_max_lanes<SCAN>((int)as_s(r).y - fc.laneKG);
-        // what the lanes above contribute. No clamp: lane l >= 1 receives pm[l-1] + (l-1) 2g >= R(lane l-1) >= -32768, lane 0 the
-        // filler -32768; the carry from above the column (MIN = 0, decaying by g per cell) is folded into the per-cell constant
-        const s16x2 cs = as_s(add_shr1(pm, fc.lanem1KG));
-        r = vmax(vmax(r, adds(as_i(s16x2{cs.x, cs.x}), fc.g12)), fc.vconst_top);
+        const int r = fast_scan<SCAN>(x, fc);        // (the in-lane step, the scan over the lanes, the artefact constant: see fast_scan)
         const int dn = vmax(d11, r);
         if (TRACE) {
             // the four flags of a cell (D != C, D != R, C != C_open, R != D_open): each is "left side greater", i.e. the sign of

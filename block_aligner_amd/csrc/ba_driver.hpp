@@ -2165,25 +2165,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : (PMAX <= 
     L.D_row = (short*)(base + 2 * ab); L.R_row = (short*)(base + 3 * ab);
     L.misc = (short*)(base + 4 * ab);
     L.table = smem;
-    FillConsts fc;
-    {
-        const int g = bp.gap_extend;
-        fc.gap_extend = g;
-        fc.go2 = splat(bp.gap_open); fc.ge2 = splat(g); fc.ome2 = splat(clamp16(bp.gap_open - g));   // (scalar arithmetic: stays in an SGPR)
-        fc.g12 = pk(g, 2 * g);
-        fc.ones = 0x00010001;
-        fc.laneKG = lane * 2 * g; fc.lanem1KG = lane ? (lane - 1) * 2 * g : -32768;
-        // zero shift-in artefacts of the reference's in-vector scan (avx2.rs:315-338): lanes 0..6 and 8..14 of each
-        // 16-cell vector see a virtual 0 at distance k%8+1, lane 7 sees 12g, lane 15 none
-        int v[2];
-        for (int h = 0; h < 2; h++) {
-            const int k = (2 * lane + h) & 15;
-            const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
-            v[h] = mult ? max(-32768, mult * g) : -32768;
-        }
-        fc.vconst = pk(v[0], v[1]);
-        fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * g)), max(v[1], max(-32768, (2 * lane + 2) * g)));
-    }
+    const FillConsts fc = make_fill_consts(lane, bp.gap_open, bp.gap_extend);
     const uint32_t stride = bp.tb_stride;
     const bool batch_traceback = TRACE && stride > 0;
 #ifdef BA_TIMING

@@ -46,6 +46,7 @@ extern "C" hipError_t ba_launch_compact_cigars(hipStream_t, const uint32_t*, con
 extern "C" hipError_t ba_launch_cigar_offsets_and_compact(hipStream_t, const uint32_t*, const uint64_t*, const uint32_t*, const uint32_t*, uint64_t*, uint32_t*,
                                                           unsigned long long*, unsigned long long, uint32_t);
 extern "C" hipError_t ba_launch_traceback(hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_lane_kat(hipStream_t, int, const short*, short*, int, unsigned);
 extern "C" hipError_t ba_launch_walk(hipStream_t, const BatchParams*, uint32_t grid);
 extern "C" hipError_t ba_launch_merge_retry(hipStream_t, const uint32_t*, uint32_t, const BatchParams*, const BatchParams*, const uint32_t*, uint32_t*);
 extern "C" hipError_t ba_launch_pack_sequences(hipStream_t, int, const uint8_t*, const uint64_t*, const uint64_t*, const uint64_t*, const uint32_t*,
@@ -708,11 +709,17 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         b->tb_reserve = b->n_fill_waves / 2;
         // (k_multi, round 5: the emptied waves' whole-wave walks take runs of diagonal moves at once -- one per fill wave; config 3, same box:
         // 164.7 -> 163.3 ms, twice as many: 169.0; 50 k pairs 92.1 -> 91.0, 25 k 55.4 -> 53.5; at 16 k pairs, four per wave, half stays better: 42.7 / 43.1)
-        if (b->multi && n >= 5ull * b->n_fill_waves) b->tb_reserve = b->n_fill_waves;
+        // (why all of them is safe here although the rule above says "fewer than all": a k_multi fill wave only waits when every one of its trace
+        // slots is taken -- four by its live pairs, the other spw - 4 >= 2 by pending walks --, so if EVERY fill wave waited there would be at
+        // least 2 n_fill_waves hand-offs pending, more than the n_fill_waves reserved ones: some of them are the dedicated lanes', which are
+        // resident and walking; and a wave that waits long walks a pending hand-off itself, traceback_help_one. Enforced below: spw >= 6.)
+        if (b->multi && n >= 5ull * b->n_fill_waves && spw >= 6) b->tb_reserve = b->n_fill_waves;
         // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
         // less of the batch to walkers that only exist once the first wave has run out of pairs
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
         if (const char* env = dev_env("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
+        // (whatever the switches say: the reserved hand-offs stay below what the fill waves' spare slots can hold pending)
+        if (b->multi) b->tb_reserve = std::min<uint32_t>(b->tb_reserve, b->n_fill_waves * (spw > 4 ? spw - 4 : 1) - 1);
     }
     // (round 4: a quarter of the fill waves instead of all of them -- since waves that run out of pairs take over other waves' slots at the
     // end of the batch, fewer pairs need to be kept out of the slots: config 3 178.9 -> 176.7 ms, 25 k pairs 60.5 -> 58.0 ms; 0: the same)
@@ -1010,8 +1017,12 @@ static void plan_exclusive(BaBatch* b, const std::vector<uint32_t>& ql, const st
     // meant -- with that rule none ran alone and the launch took 8.05 instead of 3.8 ms)
     if (const char* e = dev_env("BA_EXCL_LEN2")) thr = (uint64_t)std::max(0, atoi(e));
     const size_t cap = (size_t)b->grid * ba::WAVES_PER_WG / 2;
+    // (as in plan_walks: the leading pairs are the longest only when the device order is sorted -- it is not under BA_CALLER_ORDER --; an unsorted order
+    // singles out no pair rather than an arbitrary prefix: round-5 advisor finding)
+    bool sorted = true;
+    for (size_t p = 1; p < n && sorted; p++) sorted = (uint64_t)ql[p] + rl[p] <= (uint64_t)ql[p - 1] + rl[p - 1] + 64;
     size_t cnt = 0;
-    while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
+    if (sorted) while (cnt < n && cnt < cap && (uint64_t)ql[cnt] + rl[cnt] > thr) cnt++;   // (device order: longest first)
     b->sm_excl_n = (uint32_t)cnt;
     // k_walk behind the fill: those pairs are walked by their own waves, so the paths it walks one to a wave (plan_walks: the leading pairs of the
     // batch order) are counted from the first pair that is NOT among them -- round 5: until then every pair k_walk saw went to a lane, and the launch
@@ -1213,6 +1224,9 @@ static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx, float* retr
 // g_wait_limit_ms (ba_set_wait_limit_ms; default 10 minutes, 0 = wait for ever) the call fails with a message instead of never returning.
 static std::atomic<uint64_t> g_wait_limit_ms{600000};
 void ba_set_wait_limit_ms(uint64_t ms) { g_wait_limit_ms.store(ms); }
+// Returns 0 = done, 1 = the stream reported an error, 2 = the limit passed and the launch is STILL RUNNING (round-5 advisor finding: a timeout is not a
+// failed launch -- the batch stays "in flight": results and a relaunch are refused until a later wait succeeds; ba_batch_destroy blocks in hipFree
+// until the device lets go).
 static int stream_wait_bounded(hipStream_t s, const char* what) {
     const uint64_t limit = g_wait_limit_ms.load();
     if (!limit) { HIP_TRY(hipStreamSynchronize(s)); return 0; }
@@ -1221,17 +1235,22 @@ static int stream_wait_bounded(hipStream_t s, const char* what) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return 0;
         if (e != hipErrorNotReady) return fail("%s: %s", what, hipGetErrorString(e));
-        if (spins < 4096) continue;                                  // (short launches: the first polls back to back)
+        if (spins < 256) continue;                                   // (short launches: the first polls back to back)
         const auto dt = std::chrono::steady_clock::now() - t0;
-        if (std::chrono::duration_cast<std::chrono::milliseconds>(dt).count() > (long long)limit)
-            return fail("%s: the launch did not finish within %llu ms (ba_set_wait_limit_ms); the device may be hung", what, (unsigned long long)limit);
-        if (dt > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(dt).count() > (long long)limit) {
+            fail("%s: the launch did not finish within %llu ms (ba_set_wait_limit_ms) and is still running: wait again, or the device may be hung", what, (unsigned long long)limit);
+            return 2;
+        }
+        if (dt > std::chrono::microseconds(200)) std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
 }
 static int batch_wait(BaBatch* b, float* kernel_ms) {
     if (!b->in_flight) return fail("nothing was launched on this batch");
     HIP_TRY(hipSetDevice(b->device));
-    if (stream_wait_bounded(b->stream, "ba_batch_wait")) return 1;
+    if (const int w = stream_wait_bounded(b->stream, "ba_batch_wait")) {
+        if (w != 2) b->in_flight = false;   // (a stream error ends the launch; a timeout does not: the batch stays in flight)
+        return 1;
+    }
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev0, b->ev1));
     b->in_flight = false;
     b->retried = 0;
@@ -1445,6 +1464,24 @@ int ba_batch_cigars(BaBatch* b, uint32_t* runs, uint64_t capacity) {
     HIP_TRY(hipMemcpy(runs, d_out.p, total * 4, hipMemcpyDeviceToHost));
     return 0;
 }
+#ifdef BA_DEV
+// Development library only: the device-side known-answer test of the lane primitives (k_lane_kat, ba_kernels.hip). x: n_cells int16 values of
+// D11_open, whole columns one after the other (form 0: 128 cells per column, four columns per wave; 1: 32 cells, sixteen per wave; 2 / 3 / 4: one
+// column of 128 / 64 / 32 cells per wave); out: the columns' R11.
+int ba_dev_lane_scan(int form, const int16_t* x, uint32_t n_cells, int gap_extend, int16_t* out) {
+    if (form < 0 || form > 4 || !x || !out) return fail("ba_dev_lane_scan: bad arguments");
+    const uint32_t per_wave = form <= 1 ? 512u : (form == 2 ? 128u : (form == 3 ? 64u : 32u));
+    if (n_cells == 0 || n_cells % per_wave) return fail("ba_dev_lane_scan: %u cells are not whole waves of %u", n_cells, per_wave);
+    if (gap_extend > 0 || gap_extend < -128) return fail("ba_dev_lane_scan: gap_extend %d", gap_extend);
+    DevBuf dx, dout;
+    if (dx.alloc((size_t)n_cells * 2) || dout.alloc((size_t)n_cells * 2)) return 1;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n_cells * 2, hipMemcpyHostToDevice));
+    HIP_TRY(ba_launch_lane_kat(nullptr, form, dx.as<short>(), dout.as<short>(), gap_extend, n_cells / per_wave));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n_cells * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 int ba_batch_prof(BaBatch* b, uint64_t out[128]) {   // development: phase timers of a -DBA_TIMING build (all per-pair launches of a batch add up)
     if (!b) return fail("null batch");
     HIP_TRY(hipMemcpy(out, b->prof.p, 1024, hipMemcpyDeviceToHost));
@@ -1760,7 +1797,7 @@ int ba_multibatch_run(BaMultiBatch* m, float* kernel_ms) {
         auto& b = m->part[k];
         if (!b || !b->in_flight) continue;
         float ms = 0;
-        if (batch_wait(b.get(), &ms)) { if (first_err.empty()) first_err = g_err; b->in_flight = false; continue; }
+        if (batch_wait(b.get(), &ms)) { if (first_err.empty()) first_err = g_err; continue; }   // (batch_wait itself says whether the part is still in flight: a timeout leaves it so)
         m->last_ms[k] = ms;
         worst = std::max(worst, ms);
     }

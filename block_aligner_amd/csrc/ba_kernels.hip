@@ -262,6 +262,55 @@ __global__ void __launch_bounds__(64) k_traceback(const ba::BatchParams bp) {
     if (lane_id() == 0) { bp.cig_len[0] = n; bp.status[0] = st; }
 }
 
+// Device-side known-answer test of the lane primitives (round 6; the reference's own: avx2.rs:469-489, plus the carry from vector to vector of
+// scan_block.rs:1144-1150): columns of x = D11_open in, R11 out, through the very functions the fill kernels call -- the scan constants
+// (make_fill_consts / make_multi_consts / make_small_consts) included. One wave per workgroup; a column starts from MIN = 0 above its first cell.
+//   form 0: k_multi's eight cells per lane, 16 lanes to a slot (four 128-cell columns per wave): scan8_* + multi_carry (wave_prefix_max16, G / w0)
+//   form 1: k_small's eight cells per lane, 4 lanes to a slot (sixteen 32-cell columns per wave): scan8_* + small_carry (quad_prefix_max)
+//   form 2 / 3 / 4: two cells per lane, 64 / 32 / 16 lanes (one 128- / 64- / 32-cell column per wave): fast_scan (k_align, k_quad, the solo drivers)
+// Reached only through the development library (ba_dev_lane_scan, ba_host.cpp).
+__global__ void __launch_bounds__(64) k_lane_kat(int form, const short* __restrict__ x, short* __restrict__ out, int gap_extend) {
+    using namespace ba;
+    const int lane = lane_id();
+    if (form <= 1) {
+        const short* xi = x + (size_t)blockIdx.x * 512 + lane * 8;
+        int xr[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) xr[k] = pk((int)xi[2 * k], (int)xi[2 * k + 1]);
+        const int ge2 = splat(gap_extend);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = scan8_inreg(xr[k], ge2);
+        int G[4], cs;
+        if (form == 0) {
+            const MultiConsts mc = make_multi_consts(lane & 15, gap_extend);
+#pragma unroll
+            for (int k = 0; k < 4; k++) G[k] = mc.G[k];
+            scan8_chain(r, G[0]);
+            cs = multi_carry(r[3], mc);
+        } else {
+            const SmallConsts mc = make_small_consts(lane & 3, gap_extend);
+#pragma unroll
+            for (int k = 0; k < 4; k++) G[k] = mc.G[k];
+            scan8_chain(r, G[0]);
+            cs = small_carry(r[3], mc, lane & 3);
+        }
+        short* oi = out + (size_t)blockIdx.x * 512 + lane * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int v = scan8_apply(r[k], cs, G[k], k == 3); oi[2 * k] = as_s(v).x; oi[2 * k + 1] = as_s(v).y; }
+    } else {
+        const int nl = form == 2 ? 64 : (form == 3 ? 32 : 16);
+        const size_t base = (size_t)blockIdx.x * (size_t)(2 * nl);
+        const int xv = lane < nl ? pk((int)x[base + 2 * lane], (int)x[base + 2 * lane + 1]) : 0;
+        const FillConsts fc = make_fill_consts(lane, 0, gap_extend);
+        const int v = form == 2 ? fast_scan<64>(xv, fc) : (form == 3 ? fast_scan<32>(xv, fc) : fast_scan<16>(xv, fc));
+        if (lane < nl) { out[base + 2 * lane] = as_s(v).x; out[base + 2 * lane + 1] = as_s(v).y; }
+    }
+}
+extern "C" hipError_t ba_launch_lane_kat(hipStream_t s, int form, const short* x, short* out, int gap_extend, unsigned waves) {
+    k_lane_kat<<<dim3(waves), dim3(64), 0, s>>>(form, x, out, gap_extend);
+    return hipGetLastError();
+}
+
 // Pair-slot batches: all tracebacks of the batch, one pair per lane (ba_driver.hpp traceback_all).
 constexpr int WALK_WAVES = 4;
 __global__ void __launch_bounds__(WALK_WAVES * 64) k_walk(const ba::BatchParams bp) {

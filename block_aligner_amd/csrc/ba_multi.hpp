@@ -56,6 +56,22 @@ struct MultiConsts {
                           // {0, W}) replaces the four per-register maxima with V
 };
 
+// (one definition for the kernels and k_lane_kat) l: the lane inside its slot's sixteen
+__device__ __forceinline__ MultiConsts make_multi_consts(int l, int gx) {
+    MultiConsts mc;
+    mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : -32768;
+#pragma unroll
+    for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+    mc.w0 = pk(0, l == 0 ? 0 : ((l & 1) ? max(-32768, 8 * l * gx) : 4 * gx));   // (see MultiConsts)
+    return mc;
+}
+// R of the lane above's last cell, from the lane's own last R (high half of its fourth register): one 16-lane scan on values re-based by l * 8g
+// serves the wave's four slots (no clamp: see fast_scan), floored at {0, W} (MultiConsts::w0)
+__device__ __forceinline__ int multi_carry(int r3, const MultiConsts& mc) {
+    const int pm = wave_prefix_max16((int)as_s(r3).y - mc.laneKG);
+    return vmax(scan8_splat_lo(add_row_shr1(pm, mc.lanem1KG)), mc.w0);
+}
+
 struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
 
 // One 8-column shift step for the four slots of a wave, 8 cells per lane (scan_block.rs:147-246 with place_block 1083-1228 and
@@ -117,18 +133,16 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
             cn[k] = vmax(adds(c[k], fc.ge2), copen[k]);
             d11[k] = vmax(d11[k], cn[k]);
             x[k] = adds(d11[k], fc.ome2);                                  // D11_open
-            r[k] = vmax(x[k], splat_lo(adds(x[k], fc.ge2)));               // inside the register
+            r[k] = scan8_inreg(x[k], fc.ge2);                              // inside the register
         }
         // R11: the chain over the lane's registers, then one 16-lane scan on values re-based by l * 8g
-#pragma unroll
-        for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(splat_hi(r[k - 1]), mc.G[0]));
-        const int pm = wave_prefix_max16((int)as_s(r[3]).y - mc.laneKG);
-        const int cs = vmax(splat_lo(add_row_shr1(pm, mc.lanem1KG)), mc.w0);    // R of the lane above's last cell (no clamp: see fast_rect), floored: see MultiConsts::w0
+        scan8_chain(r, mc.G[0]);
+        const int cs = multi_carry(r[3], mc);    // R of the lane above's last cell (no clamp: see fast_scan), floored: see MultiConsts::w0
         int dn[4];
         uint32_t sC[4], sR[4], sCo[4], sRo[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            r[k] = vmax(r[k], adds(k < 3 ? splat_lo(cs) : cs, mc.G[k]));
+            r[k] = scan8_apply(r[k], cs, mc.G[k], k == 3);
             dn[k] = vmax(d11[k], r[k]);
             if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect); packed below, two registers at a time
                 sC[k] = (uint32_t)subs(cn[k], dn[k]); sR[k] = (uint32_t)subs(r[k], dn[k]); sCo[k] = (uint32_t)subs(copen[k], cn[k]); sRo[k] = (uint32_t)subs(x[k], r[k]);
@@ -398,22 +412,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             else break;
 
             BA_TSTAMP(ts_a);
-            FillConsts fc;   // two cells per lane (as k_align)
-            {
-                fc.gap_extend = gx;
-                fc.go2 = splat(bp.gap_open); fc.ge2 = splat(gx); fc.ome2 = splat(clamp16(bp.gap_open - gx));
-                fc.g12 = pk(gx, 2 * gx);
-                fc.ones = 0x00010001;
-                fc.laneKG = lane * 2 * gx; fc.lanem1KG = lane ? (lane - 1) * 2 * gx : -32768;
-                int v[2];
-                for (int h = 0; h < 2; h++) {
-                    const int k = (2 * lane + h) & 15;
-                    const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
-                    v[h] = mult ? max(-32768, mult * gx) : -32768;
-                }
-                fc.vconst = pk(v[0], v[1]);
-                fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
-            }
+            const FillConsts fc = make_fill_consts(lane, bp.gap_open, gx);   // two cells per lane (as k_align)
             Aligner<PMAX, KIND, TRACE, XDROP, SPM != 0, true> al(bp, L, fc);
             PairState st{};
             uint32_t s_pair, s_slot;
@@ -557,11 +556,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             const int x_drop = bp.x_drop;
             FillConsts fq;   // only the three gap constants (wave-uniform)
             fq.go2 = splat(bp.gap_open); fq.ge2 = splat(gx); fq.ome2 = splat(clamp16(bp.gap_open - gx));
-            MultiConsts mc;  // eight cells per lane
-            mc.laneKG = l * 8 * gx; mc.lanem1KG = l ? (l - 1) * 8 * gx : -32768;
-#pragma unroll
-            for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
-            mc.w0 = pk(0, l == 0 ? 0 : ((l & 1) ? max(-32768, 8 * l * gx) : 4 * gx));   // (see MultiConsts)
+            MultiConsts mc = make_multi_consts(l, gx);  // eight cells per lane
             const uint64_t tcap64 = bp.trace_stride, bcap64 = bp.blocks_stride;
             const uint32_t tcap = (uint32_t)(tcap64 < 0x7fffffffull ? tcap64 : 0x7fffffffull), bcap = (uint32_t)(bcap64 < 0x7fffffffull ? bcap64 : 0x7fffffffull);
             // ---- slot state (row-uniform, replicated over the slot's lanes)

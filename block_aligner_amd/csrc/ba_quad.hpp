@@ -31,6 +31,22 @@ __device__ __forceinline__ int add_row_shr1(int a, int b) {   // a[l-1] + b[l] i
     asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(t) : "v"(a), "v"(b));
     return t;
 }
+
+// ---- eight cells per lane (k_multi, k_small, place_rect8): the pieces of a column's R11 (avx2.rs:297-338 per 16-cell vector + the carry from
+// vector to vector, scan_block.rs:1144-1150), named so that the kernels and the device-side known-answer test of the lane primitives
+// (k_lane_kat, ba_kernels.hip) run the same code. x = D11_open (scan_block.rs:1143) of the lane's cells 2k, 2k + 1 in register k.
+__device__ __forceinline__ int scan8_splat_lo(int x) { const s16x2 t = as_s(x); return as_i(s16x2{t.x, t.x}); }
+__device__ __forceinline__ int scan8_splat_hi(int x) { const s16x2 t = as_s(x); return as_i(s16x2{t.y, t.y}); }
+// inside a register: the second cell against the first's gap
+__device__ __forceinline__ int scan8_inreg(int x, int ge2) { return vmax(x, scan8_splat_lo(adds(x, ge2))); }
+// the chain over the lane's four registers; G0 = {g, 2g}
+__device__ __forceinline__ void scan8_chain(int (&r)[4], int G0) {
+#pragma unroll
+    for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(scan8_splat_hi(r[k - 1]), G0));
+}
+// what entered the lane from above (cs: see multi_carry / small_carry), into register k; last = the lane's fourth register, whose second cell has its
+// own floor in the high half of cs
+__device__ __forceinline__ int scan8_apply(int rk, int cs, int Gk, bool last) { return vmax(rk, adds(last ? cs : scan8_splat_lo(cs), Gk)); }
 __device__ __forceinline__ int sat16(int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); }
 
 struct QuadOut { int mx, row, col, act_max8, pas_max8, corner_new; };
@@ -165,22 +181,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, 4) k_quad(const BatchParams
     short* Pl = (short*)sl;
     short* sink = (short*)(sl + 256) + l;
     FillConsts fc;
-    {
-        const int gx = bp.gap_extend;
-        fc.gap_extend = gx;
-        fc.go2 = splat(bp.gap_open); fc.ge2 = splat(gx); fc.ome2 = splat(clamp16(bp.gap_open - gx));
-        fc.g12 = pk(gx, 2 * gx);
-        fc.ones = 0x00010001;
-        fc.laneKG = l * 2 * gx; fc.lanem1KG = l ? (l - 1) * 2 * gx : -32768;
-        int v[2];
-        for (int h = 0; h < 2; h++) {
-            const int k = (2 * l + h) & 15;
-            const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
-            v[h] = mult ? max(-32768, mult * gx) : -32768;
-        }
-        fc.vconst = pk(v[0], v[1]);
-        fc.vconst_top = pk(max(v[0], max(-32768, (2 * l + 1) * gx)), max(v[1], max(-32768, (2 * l + 2) * gx)));
-    }
+    fc = make_fill_consts(l, bp.gap_open, bp.gap_extend);
     const uint32_t total = bp.n;
     const uint32_t max_size = bp.max_size;
     const int x_drop = bp.x_drop;

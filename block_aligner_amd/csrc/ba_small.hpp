@@ -77,6 +77,23 @@ struct SmallConsts {
     // lane above is floored ONCE per column -- at {0, W}, V(eighth cell) = W + 8g -- instead of a max with V per register (see MultiConsts::w0).
     int w0;
 };
+// (one definition for the kernel and k_lane_kat) l: the lane inside its slot's four
+__device__ __forceinline__ SmallConsts make_small_consts(int l, int gx) {
+    SmallConsts mc;
+    mc.laneKG = l * 8 * gx; mc.g8 = 8 * gx;
+#pragma unroll
+    for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
+    mc.w0 = pk(0, l == 0 ? 0 : ((l & 1) ? max(-32768, 8 * l * gx) : 4 * gx));   // (see SmallConsts)
+    return mc;
+}
+// R of the lane above's last cell: a scan over the quad's four lanes on values re-based by l * 8g; quad lane 0 has no lane above (a candidate that
+// never wins); floored at {0, W} (SmallConsts::w0)
+__device__ __forceinline__ int small_carry(int r3, const SmallConsts& mc, int l) {
+    const int pm = quad_prefix_max((int)as_s(r3).y - mc.laneKG);
+    int cin = __builtin_amdgcn_update_dpp(pm, pm, 0x90, 0xf, 0xf, false) + mc.laneKG - mc.g8;
+    cin = l == 0 ? -32768 : cin;
+    return vmax(scan8_splat_lo(cin), mc.w0);
+}
 
 // Sequence-to-profile steps (place_block_profile_*, scan_block.rs:612-783; ba_quad.hpp QuadProfile for two cells per lane). A slot's step runs along
 // the query ("right": one profile position per column, gap costs uniform in a column) or along the profile ("down": one query residue per column, gap
@@ -176,16 +193,11 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
             cend[k] = PROF ? adds(cn[k], Xj) : cn[k];                      // C11_end (scan_block.rs:694)
             d11[k] = vmax(d11[k], cend[k]);
             x[k] = adds(d11[k], goR);                                      // D11_open
-            r[k] = vmax(x[k], splat_lo(adds(x[k], fc.ge2)));               // inside the register
+            r[k] = scan8_inreg(x[k], fc.ge2);                              // inside the register
         }
         // R11: the chain over the lane's registers, then a scan over the quad's four lanes on values re-based by l * 8g
-#pragma unroll
-        for (int k = 1; k < 4; k++) r[k] = vmax(r[k], adds(splat_hi(r[k - 1]), mc.G[0]));
-        const int pm = quad_prefix_max((int)as_s(r[3]).y - mc.laneKG);
-        // R of the lane above's last cell; quad lane 0 has no lane above: a candidate that never wins
-        int cin = __builtin_amdgcn_update_dpp(pm, pm, 0x90, 0xf, 0xf, false) + mc.laneKG - mc.g8;
-        cin = l == 0 ? -32768 : cin;
-        const int cs = vmax(splat_lo(cin), mc.w0);   // (floored: see SmallConsts::w0)
+        scan8_chain(r, mc.G[0]);
+        const int cs = small_carry(r[3], mc, l);   // R of the lane above's last cell, floored: see SmallConsts::w0
         int dn[4];
 #pragma unroll
         for (int p2 = 0; p2 < 2; p2++) {   // two registers at a time: their trace flags are packed before the next two are touched (fewer values alive)
@@ -193,7 +205,7 @@ __device__ __forceinline__ void small_rect(const char* table, const FillConsts& 
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 const int k = 2 * p2 + kk;
-                r[k] = vmax(r[k], adds(k < 3 ? splat_lo(cs) : cs, mc.G[k]));
+                r[k] = scan8_apply(r[k], cs, mc.G[k], k == 3);
                 const int rend = PROF ? adds(r[k], Yk[k]) : r[k];          // R11_end (scan_block.rs:704)
                 dn[k] = vmax(d11[k], rend);
                 if (TRACE) {   // the cell's four flags as sign bits of saturating differences (see fast_rect)
@@ -325,22 +337,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
         // ================= solo mode: the pairs whose step was rolled back (or that a slot cannot take), one at a time on all 64 lanes
         while (pend_m) {
             int solo = __builtin_ctz(pend_m);
-            FillConsts fc;   // two cells per lane (as k_align)
-            {
-                fc.gap_extend = gx;
-                fc.go2 = splat(bp.gap_open); fc.ge2 = splat(gx); fc.ome2 = splat(clamp16(bp.gap_open - gx));
-                fc.g12 = pk(gx, 2 * gx);
-                fc.ones = 0x00010001;
-                fc.laneKG = lane * 2 * gx; fc.lanem1KG = lane ? (lane - 1) * 2 * gx : -32768;
-                int v[2];
-                for (int h = 0; h < 2; h++) {
-                    const int k = (2 * lane + h) & 15;
-                    const int mult = k == 15 ? 0 : (k == 7 ? 12 : (k & 7) + 1);
-                    v[h] = mult ? max(-32768, mult * gx) : -32768;
-                }
-                fc.vconst = pk(v[0], v[1]);
-                fc.vconst_top = pk(max(v[0], max(-32768, (2 * lane + 1) * gx)), max(v[1], max(-32768, (2 * lane + 2) * gx)));
-            }
+            const FillConsts fc = make_fill_consts(lane, bp.gap_open, gx);   // two cells per lane (as k_align)
             Aligner<PMAX, KIND, TRACE, XDROP, SPM != 0, true, SM_B> al(bp, L, fc);
             PairState st{};
             char* const smem_s = wave_mem + (uint32_t)solo * SM_SLOT_BYTES;
@@ -444,11 +441,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             const uint32_t total = bp.n;
             FillConsts fq;   // only the three gap constants (wave-uniform)
             fq.go2 = splat(bp.gap_open); fq.ge2 = splat(gx); fq.ome2 = splat(clamp16(bp.gap_open - gx));
-            SmallConsts mc;  // eight cells per lane
-            mc.laneKG = l * 8 * gx; mc.g8 = 8 * gx;
-#pragma unroll
-            for (int k = 0; k < 4; k++) mc.G[k] = pk(max(-32768, (2 * k + 1) * gx), max(-32768, (2 * k + 2) * gx));
-            mc.w0 = pk(0, l == 0 ? 0 : ((l & 1) ? max(-32768, 8 * l * gx) : 4 * gx));   // (see SmallConsts)
+            SmallConsts mc = make_small_consts(l, gx);  // eight cells per lane
             // ---- slot state (row-uniform, replicated over the slot's lanes)
             const bool live0 = (live_m >> g) & 1u;
             const char* rec = slot_mem + 2 * SM_BUF_BYTES;

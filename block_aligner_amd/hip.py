@@ -625,8 +625,13 @@ class SizedBatchAligner:
 
     def classes(self):
         """[(min, max, pairs, fill kernel, kernel ms of the last run)] per bin."""
-        r = np.zeros((64, 2), np.uint64); c = np.zeros(64, np.uint64); k = np.zeros(64, np.int32); t = np.zeros(64, np.float32)
-        nb = lib().ba_sized_batch_classes(self._h, r.ctypes.data, c.ctypes.data, k.ctypes.data, t.ctypes.data, 64)
+        cap = 64
+        while True:   # (the call returns the number of bins, however many fit: a second call with room for all of them if there are more)
+            r = np.zeros((cap, 2), np.uint64); c = np.zeros(cap, np.uint64); k = np.zeros(cap, np.int32); t = np.zeros(cap, np.float32)
+            nb = lib().ba_sized_batch_classes(self._h, r.ctypes.data, c.ctypes.data, k.ctypes.data, t.ctypes.data, cap)
+            if nb <= cap:
+                break
+            cap = nb
         return [(int(r[i, 0]), int(r[i, 1]), int(c[i]), int(k[i]), float(t[i])) for i in range(nb)]
 
     def close(self):

@@ -228,7 +228,9 @@ int ba_batch_run(BaBatch* batch, float* kernel_ms);
 int ba_batch_launch(BaBatch* batch);
 int ba_batch_wait(BaBatch* batch, float* kernel_ms);
 /* Upper bound on a ba_batch_wait / ba_batch_run (milliseconds; default 600000; 0 = none): the kernels of a launch wait for each other without a
- * give-up, so the host bounds the wait -- past it the call fails (ba_last_error) instead of never returning. Process-wide. */
+ * give-up, so the host bounds the wait -- past it the call fails (ba_last_error) instead of never returning. Process-wide. A timeout is not a failed
+ * launch: the batch stays in flight (results and a relaunch are refused; a later ba_batch_wait may still succeed -- raise the limit, or pass 0, for
+ * launches that legitimately take longer), and ba_batch_destroy blocks until the device has let go of the batch's memory. */
 void ba_set_wait_limit_ms(uint64_t ms);
 /* Copy results to host arrays of n_pairs elements; any pointer may be NULL. status: 0 = ok, else BA_ST_* bits. */
 int ba_batch_results(BaBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells,
@@ -271,7 +273,10 @@ BaSizedBatch* ba_sized_batch_create(int kind, const void* matrix, struct Gaps ga
 BaSizedBatch* ba_sized_batch_create_percent(int kind, const void* matrix, struct Gaps gaps, float min_percent, float max_percent, int32_t x_drop, uint32_t mode,
                                             const uint8_t* pool, const uint64_t* q_off, const uint32_t* q_len, const uint64_t* r_off, const uint32_t* r_len,
                                             uintptr_t n_pairs);
-int ba_sized_batch_run(BaSizedBatch* batch, float* kernel_ms);   /* kernel_ms: the bins' kernel times added up */
+/* The bins are launched together (each on its own stream, sharing the device) and waited for. kernel_ms (optional): host wall-clock milliseconds from the
+ * first launch to the last completion -- overflow re-runs and the host's work between the waits included; NOT a sum of HIP-event times: the bins overlap
+ * (per-bin event times of the same run: ba_sized_batch_classes). */
+int ba_sized_batch_run(BaSizedBatch* batch, float* kernel_ms);
 int ba_sized_batch_results(BaSizedBatch* batch, int32_t* score, uint32_t* query_idx, uint32_t* reference_idx, uint64_t* cells, uint32_t* cigar_len,
                            uint32_t* status);
 int ba_sized_batch_cigars(BaSizedBatch* batch, uint32_t* runs, uint64_t capacity);
