@@ -688,6 +688,10 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // (k_multi fills faster -- four pairs per wave, eight cells per lane -- and its walks are what it waits for: one traceback wave
         // per 2 workgroups. Config 3, same box: per 4: 217 ms, per 3: 200.4, per 2: 198.9)
         if (b->multi && b->grid >= 32) stride = 2;
+        // (round 6: the lanes' walk takes runs of diagonal moves at once -- ~45 % fewer instructions per rectangle crossed -- and one traceback wave per
+        // 3 workgroups keeps up: 85 more fill waves. Same box, per 2 / 3 / 4 / 6: 100 k pairs 159.2 / 158.3 / 159.8 / 188.8 ms, 50 k 90.2 / 89.1 / 88.6 / 97.1,
+        // 12.5 k 36.4 / 34.2 / 33.9 / 34.1. The special modes' walks are the round-5 ones: per 2 as before.)
+        if (b->multi && b->grid >= 32 && !special_of(mode)) stride = 3;
         if (const char* env = dev_env("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
         b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
@@ -713,7 +717,8 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // slots is taken -- four by its live pairs, the other spw - 4 >= 2 by pending walks --, so if EVERY fill wave waited there would be at
         // least 2 n_fill_waves hand-offs pending, more than the n_fill_waves reserved ones: some of them are the dedicated lanes', which are
         // resident and walking; and a wave that waits long walks a pending hand-off itself, traceback_help_one. Enforced below: spw >= 6.)
-        if (b->multi && n >= 5ull * b->n_fill_waves && spw >= 6) b->tb_reserve = b->n_fill_waves;
+        // (round 6, the cheaper lane walk: one per fill wave at every batch size -- 12.5 k pairs 34.2 -> 33.6 ms, 25 k 49.4 -> 49.2, 100 k 158.3 -> 157.9)
+        if (b->multi && (n >= 5ull * b->n_fill_waves || !special_of(mode)) && spw >= 6) b->tb_reserve = b->n_fill_waves;
         // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
         // less of the batch to walkers that only exist once the first wave has run out of pairs
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
