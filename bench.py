@@ -541,6 +541,11 @@ def main():
                         wp = W.config3(n_part, a.len, a.edits, a.tail, seed=1234, trace=True, workers=min(8, usable_cpus()), size=size)
                         wp.name += " (%d of the north-star's 100 000: the share of %d GPUs)" % (n_part, 100000 // n_part)
                         secondary.append(secondary_line(np, H, W, o, wp, cores))
+                    # reads above 12.8 kbp: percent_len (lib.rs:109-111) starts them at 256 cells -- 13 kbp pairs at 1 % .. 10 % = 256 .. 2048 as
+                    # examples/nanopore_bench_global.rs:144-171 sizes them; round 6: k_multi with two slots of 256 cells per wave
+                    wl = W.config3(30000, 13000, 1300, a.tail, seed=4321, trace=True, workers=min(8, usable_cpus()), size=(H.percent_len(13000, 0.01), H.percent_len(13000, 0.1)))
+                    wl.name += ", block %d..%d (percent_len 1 %% .. 10 %% of 13 kbp)" % wl.size
+                    secondary.append(secondary_line(np, H, W, o, wl, cores))
                 # ... and the same configurations at the batch sizes of the reference's own harnesses (BASELINE.json: 10 k pairs,
                 # examples/nanopore_bench.rs:73-95; 7 k protein pairs, examples/uc_bench.rs:79-104; 11 k PSSMs, examples/pssm_bench.rs:94-100):
                 # a few pairs per wave, bound by the longest pair's chain of steps rather than by the machine

@@ -1709,9 +1709,10 @@ struct Aligner {
             // (LOCAL_START / FREE_QUERY_START_GAPS steps are a slot's too -- k_small's special instantiations --, FREE_QUERY_END_GAPS ones are not; none takes the register path)
             // (round 5, later: the register path takes LOCAL_START steps -- fast_rect<.., SP> -- and FREE_QUERY_START_GAPS steps below row 0 of the matrix,
             // which are plain steps; FREE_QUERY_END_GAPS keeps the generic code)
-            const bool plain0 = !kBig && dir != DIR_GROW && rh <= 128 && !(h_flags & 0x100u) && !(special & F_FQE) && fast_eligible(ri, rh, lenV, rj, lenC);
+            // (round 6: a 256-cell slot of k_multi takes plain steps of 256 rows -- two chunks: never the register path)
+            const bool plain0 = !kBig && dir != DIR_GROW && (rh <= 128 || (MULTI && SLOT_B > 128 && rh == SLOT_B)) && !(h_flags & 0x100u) && !(special & F_FQE) && fast_eligible(ri, rh, lenV, rj, lenC);
             const bool plain = plain0 && (!special || MULTI);
-            const bool fast = plain0 && KIND != KIND_PROFILE && !((special & F_FQS) && si == 0);
+            const bool fast = plain0 && rh <= 128 && KIND != KIND_PROFILE && !((special & F_FQS) && si == 0);
             if (!fast) pf_ok = false;   // prefetched bytes only serve a shift step that directly follows the one that fetched them
             if constexpr (MULTI) if (mmode != MM_NONE && allow_quad && plain && !forced && block_size == SLOT_B && min_size == SLOT_B && !chain && !no_spec) {
                 // ---- the pair goes (back) to its slot of the multi-pair kernel: plain shift steps at MQ_B cells are taken there,
@@ -1725,15 +1726,19 @@ struct Aligner {
                 st.ck_tt = (uint32_t)unpark<3>(parked); st.ck_nb = (uint32_t)unpark<4>(parked);
                 st.trace_top = trace_top; st.nblocks = nblocks; st.status = status;
                 if (SLOT_B < max_size) {
-                    const uint32_t k = 2 * lane_id(), ms = h_max_size;
+                    const uint32_t ms = h_max_size;
                     lds_sync();
+#pragma unroll
+                    for (uint32_t k0 = 0; k0 < (SLOT_B > 128u ? SLOT_B : 128u); k0 += 128u) {   // (a checkpoint of more than 128 cells is never in registers)
+                    const uint32_t k = k0 + 2 * lane_id();
                     if (SLOT_B >= 128 || k < SLOT_B) {
-                    if (ck_in_regs) {
+                    if (SLOT_B <= 128 && ck_in_regs) {
                         *(int*)(L.D_col + SLOT_B + k) = ck_reg[0]; *(int*)(L.C_col + SLOT_B + k) = ck_reg[1];
                         *(int*)(L.D_row + SLOT_B + k) = ck_reg[2]; *(int*)(L.R_row + SLOT_B + k) = ck_reg[3];
                     } else {
                         *(int*)(L.D_col + SLOT_B + k) = ckpt_load(ckpt + k); *(int*)(L.C_col + SLOT_B + k) = ckpt_load(ckpt + ms + k);
                         *(int*)(L.D_row + SLOT_B + k) = ckpt_load(ckpt + 2 * ms + k); *(int*)(L.R_row + SLOT_B + k) = ckpt_load(ckpt + 3 * ms + k);
+                    }
                     }
                     }
                     lds_sync();
@@ -2070,24 +2075,29 @@ struct Aligner {
                 *(int4*)(L.D_row + l8) = int4{ckr[8], ckr[9], ckr[10], ckr[11]}; *(int4*)(L.R_row + l8) = int4{ckr[12], ckr[13], ckr[14], ckr[15]};
             }
             lds_sync();
-            int cDc = *(const int*)(L.D_col + 2 * lane), cCc = *(const int*)(L.C_col + 2 * lane);
-            int cDr = *(const int*)(L.D_row + 2 * lane), cRr = *(const int*)(L.R_row + 2 * lane);
-            lds_sync();
+            constexpr bool WIDE = SLOT_B > 128;   // (round 6) a 256-cell slot: two chunks -- the checkpoint lives in the arena, its step goes through the generic rectangle code
+            constexpr int NCH_S = WIDE ? (int)SLOT_B / 128 : 1;
+            int cDc = 0, cCc = 0, cDr = 0, cRr = 0;
+            if constexpr (!WIDE) {
+                cDc = *(const int*)(L.D_col + 2 * lane); cCc = *(const int*)(L.C_col + 2 * lane);
+                cDr = *(const int*)(L.D_row + 2 * lane); cRr = *(const int*)(L.R_row + 2 * lane);
+                lds_sync();
+            }
             if (ck_pre) {
                 constexpr int PR_DIST = (int)(lds_array_bytes_h(kBig ? 128u : (uint32_t)PMAX * 128u) / 2);
                 const bool cright = ck_dir == DIR_RIGHT;
                 const uint8_t* seqV = cright ? q : r; const uint8_t* seqC = cright ? r : q;
                 const uint32_t cri = cright ? ck_i : ck_j, crj = (cright ? ck_j : ck_i) + SLOT_B - STEP;
-                constexpr int FL = (int)SLOT_B / 2;   // lanes of the per-pair layout that hold cells
-                const int vc = 2 * lane < (int)SLOT_B ? (int)*(const unsigned short*)(seqV + cri + 2 * lane) : 0;
-                const unsigned long long cb = load_cols(seqC + crj);
                 FastOut fo{};
-                if constexpr (KIND != KIND_PROFILE && !SPECIAL) {
+                if constexpr (KIND != KIND_PROFILE && !SPECIAL && !WIDE) {
+                    constexpr int FL = (int)SLOT_B / 2;   // lanes of the per-pair layout that hold cells
+                    const int vc = 2 * lane < (int)SLOT_B ? (int)*(const unsigned short*)(seqV + cri + 2 * lane) : 0;
+                    const unsigned long long cb = load_cols(seqC + crj);
                     if (cright) fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDc, cCc, cDr, cRr, L.D_row, L.D_col, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
                     else fast_rect<KIND, false, XDROP, FL, PR_DIST>(L.table, fc, cDr, cRr, cDc, cCc, L.D_col, L.D_row, vc & 0xff, (vc >> 8) & 0xff, cb, FL, ck_corner, ck_offadd, -1, nullptr, fo);
                 } else {
-                    // sequence-to-profile / the special modes: the step through the generic rectangle code, on the LDS borders the checkpoint was just
-                    // written to (place_block[_profile_right / _down] + shift_and_offset, scan_block.rs:147-246); then the borders back into registers
+                    // sequence-to-profile / the special modes / slots of more than one chunk: the step through the generic rectangle code, on the LDS borders the
+                    // checkpoint was just written to (place_block[_profile_right / _down] + shift_and_offset, scan_block.rs:147-246); then the borders back into registers
                     const uint32_t pq_len = coldp()->q_len[pair_in], pr_len = coldp()->r_len[pair_in];
                     ProfileView pvv{};
                     if constexpr (KIND == KIND_PROFILE) {
@@ -2104,16 +2114,18 @@ struct Aligner {
                     unsigned long long none = 0;
                     Best cur;
                     if (cright) {
-                        cur = place_rect<1, KIND, false, XDROP, PD_R>(L, fc, q, r, pq_len, pr_len, cri, crj, STEP, SLOT_B, L.D_col, L.C_col, t1, t2, ck_corner, crz, ck_offadd, nullptr, none, nullptr, spb, nullptr, &pvv);
+                        cur = place_rect<NCH_S, KIND, false, XDROP, PD_R>(L, fc, q, r, pq_len, pr_len, cri, crj, STEP, SLOT_B, L.D_col, L.C_col, t1, t2, ck_corner, crz, ck_offadd, nullptr, none, nullptr, spb, nullptr, &pvv);
                         (void)lds_shift_and_offset(SLOT_B, L.D_row, L.R_row, t1, t2, ck_offadd);
                     } else {
-                        cur = place_rect<1, KIND, false, XDROP, PD_D>(L, fc, r, q, pr_len, pq_len, cri, crj, STEP, SLOT_B, L.D_row, L.R_row, t1, t2, ck_corner, crz, ck_offadd, nullptr, none, nullptr, spb, nullptr, &pvv);
+                        cur = place_rect<NCH_S, KIND, false, XDROP, PD_D>(L, fc, r, q, pr_len, pq_len, cri, crj, STEP, SLOT_B, L.D_row, L.R_row, t1, t2, ck_corner, crz, ck_offadd, nullptr, none, nullptr, spb, nullptr, &pvv);
                         (void)lds_shift_and_offset(SLOT_B, L.D_col, L.C_col, t1, t2, ck_offadd);
                     }
                     fo.row = cur.row; fo.col = cur.col;
                     lds_sync();
-                    cDc = *(const int*)(L.D_col + 2 * lane); cCc = *(const int*)(L.C_col + 2 * lane);
-                    cDr = *(const int*)(L.D_row + 2 * lane); cRr = *(const int*)(L.R_row + 2 * lane);
+                    if constexpr (!WIDE) {
+                        cDc = *(const int*)(L.D_col + 2 * lane); cCc = *(const int*)(L.C_col + 2 * lane);
+                        cDr = *(const int*)(L.D_row + 2 * lane); cRr = *(const int*)(L.R_row + 2 * lane);
+                    }
                 }
                 if (XDROP) {
                     if (cright) { best_i = ck_i + (uint32_t)fo.row; best_j = ck_j + (SLOT_B - STEP) + (uint32_t)fo.col; }
@@ -2121,7 +2133,8 @@ struct Aligner {
                 }
                 lds_sync();
             }
-            ck_reg[0] = cDc; ck_reg[1] = cCc; ck_reg[2] = cDr; ck_reg[3] = cRr; ck_in_regs = true;
+            if constexpr (WIDE) save_ckpt_borders(SLOT_B);   // (LDS -> this wave's checkpoint arena: restore_ckpt_borders / the slot's next entry read it there)
+            else { ck_reg[0] = cDc; ck_reg[1] = cCc; ck_reg[2] = cDr; ck_reg[3] = cRr; ck_in_regs = true; }
         }
         lds_sync();
         if (mine) {

@@ -71,6 +71,15 @@ BA_DECL_M_KIND(0) BA_DECL_M_KIND(1) BA_DECL_M_KIND(2)
 #define BA_MOROW(K) {ba_occupancy_m_k##K##_p1, ba_occupancy_m_k##K##_p2, ba_occupancy_m_k##K##_p4, ba_occupancy_m_k##K##_p8, ba_occupancy_m_k##K##_p16}
 static const LaunchFn g_launch_m[3][5] = {BA_MROW(0), BA_MROW(1), BA_MROW(2)};
 static const OccFn g_occ_m[3][5] = {BA_MOROW(0), BA_MOROW(1), BA_MOROW(2)};
+// ... with slots of 256 cells, two pairs per wave (round 6: DNA batches that start at 256 cells -- percent_len of reads above 12.8 kbp --, block classes 512 .. 2048)
+extern "C" hipError_t ba_launch_m256_k1_p4(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_m256_k1_p8(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_m256_k1_p16(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_occupancy_m256_k1_p4(int, int, unsigned, int*);
+extern "C" hipError_t ba_occupancy_m256_k1_p8(int, int, unsigned, int*);
+extern "C" hipError_t ba_occupancy_m256_k1_p16(int, int, unsigned, int*);
+static const LaunchFn g_launch_m256[5] = {nullptr, nullptr, ba_launch_m256_k1_p4, ba_launch_m256_k1_p8, ba_launch_m256_k1_p16};   // [block class]
+static const OccFn g_occ_m256[5] = {nullptr, nullptr, ba_occupancy_m256_k1_p4, ba_occupancy_m256_k1_p8, ba_occupancy_m256_k1_p16};
 // ... and its LOCAL_START / FREE_QUERY_START_GAPS instantiations (the batch's flags choose)
 #define BA_DECL_MS(K, P)                                                                                              \
     extern "C" hipError_t ba_launch_ms_k##K##_p##P(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);    \
@@ -285,6 +294,7 @@ struct BaBatch {
     uint32_t work_chunk = 1;    // pairs a wave takes per work-counter atomic (short pairs outrun one counter's ~90 atomics / us)
     uint32_t mq_drain = 0;      // k_multi: pairs at the end of the batch that are run one at a time (BatchParams::mq_drain)
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
+    uint32_t multi_b = 128;     // ... or at 256 cells (round 6): two pairs per wave, slots of 32 lanes
     uint32_t walk_wave_n = 0;   // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (plan_walks)
     uint32_t sm_excl_n = 0;     // k_small: the batch's longest pairs, run one to a wave (plan_exclusive)
     uint32_t sm_side_n = 0;     // ... of which the first sm_side_n run in a launch of their own beside the main one (TRACE batches: batch_launch)
@@ -597,7 +607,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (b->multi_b == 256 ? g_occ_m256[pc] : special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
@@ -700,10 +710,11 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         uint32_t spw = 4;   // one being filled + three pending walks per fill wave, HBM permitting (188 GB at config 3; 3 slots: -1 %, 2: -17 %, 5: no gain)
-        if (b->multi) spw = 9;   // four pairs being filled + pending walks (round 4: 8 instead of 10 -- 105 instead of 131 GB at config 3 for -0.7 %; round 5: 9, smaller -- see the margin above; 7: 190 ms, 6: 208)
+        const uint32_t mslots = b->multi ? 512u / b->multi_b : 0u;   // k_multi: pairs a wave fills at once (four slots of 128 cells, or two of 256)
+        if (b->multi) spw = mslots + 5;   // four pairs being filled + pending walks (round 4: 8 instead of 10 -- 105 instead of 131 GB at config 3 for -0.7 %; round 5: 9, smaller -- see the margin above; 7: 190 ms, 6: 208)
         if (const char* env = dev_env("BA_SLOTS_PER_WAVE")) { int v = atoi(env); if (v > 0) spw = (uint32_t)v; }
         while (spw > 1 && fixed + per_slot * spw * b->n_fill_waves > free_b * 9 / 10) spw--;
-        if (b->multi && spw < 6) return fail("device memory: the multi-pair kernel needs six trace slots per wave");   // (batch_build falls back to the per-pair kernel)
+        if (b->multi && spw < mslots + 2) return fail("device memory: the multi-pair kernel needs two trace slots per wave beside its pairs'");   // (batch_build falls back to the per-pair kernel)
         b->slots_per_wave = spw;
         // The last hand-offs of the batch go to fill waves that have run out of pairs (one walking lane per wave, on
         // SIMDs with nothing else left to do): a walk alone is much shorter than one among 40 in lockstep, and the
@@ -718,19 +729,19 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // least 2 n_fill_waves hand-offs pending, more than the n_fill_waves reserved ones: some of them are the dedicated lanes', which are
         // resident and walking; and a wave that waits long walks a pending hand-off itself, traceback_help_one. Enforced below: spw >= 6.)
         // (round 6, the cheaper lane walk: one per fill wave at every batch size -- 12.5 k pairs 34.2 -> 33.6 ms, 25 k 49.4 -> 49.2, 100 k 158.3 -> 157.9)
-        if (b->multi && (n >= 5ull * b->n_fill_waves || !special_of(mode)) && spw >= 6) b->tb_reserve = b->n_fill_waves;
+        if (b->multi && (n >= 5ull * b->n_fill_waves || !special_of(mode)) && spw >= mslots + 2) b->tb_reserve = b->n_fill_waves;
         // with fewer than three trace slots per wave a fill wave soon waits for the walk of its previous pair: leave
         // less of the batch to walkers that only exist once the first wave has run out of pairs
         if (spw < 3) b->tb_reserve = b->n_fill_waves / 4;
         if (const char* env = dev_env("BA_TB_RESERVE")) b->tb_reserve = (uint32_t)std::max(0, atoi(env));
         // (whatever the switches say: the reserved hand-offs stay below what the fill waves' spare slots can hold pending)
-        if (b->multi) b->tb_reserve = std::min<uint32_t>(b->tb_reserve, b->n_fill_waves * (spw > 4 ? spw - 4 : 1) - 1);
+        if (b->multi) b->tb_reserve = std::min<uint32_t>(b->tb_reserve, b->n_fill_waves * (spw > mslots ? spw - mslots : 1) - 1);
     }
     // (round 4: a quarter of the fill waves instead of all of them -- since waves that run out of pairs take over other waves' slots at the
     // end of the batch, fewer pairs need to be kept out of the slots: config 3 178.9 -> 176.7 ms, 25 k pairs 60.5 -> 58.0 ms; 0: the same)
     b->mq_drain = b->multi ? ((dev_env("BA_NO_DONATE") || !trace || special_of(mode)) ? b->n_fill_waves : b->n_fill_waves / 4) : 0;
     if (const char* env = dev_env("BA_MQ_DRAIN")) b->mq_drain = (uint32_t)std::max(0, atoi(env));
-    if (b->multi && b->slots_per_wave < 4) b->slots_per_wave = 4;   // (without the hand-off ring: one trace slot per slot of the wave)
+    if (b->multi && b->slots_per_wave < 512u / b->multi_b) b->slots_per_wave = 512u / b->multi_b;   // (without the hand-off ring: one trace slot per slot of the wave)
     b->slots = b->n_fill_waves * b->slots_per_wave;
     if (b->pipe) b->slots = (uint32_t)n;   // (slot = pair: slot_info holds one entry per pair for k_walk)
     {
@@ -880,8 +891,18 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     // pairs, 667 / 1112 at 200 k (before this rule those batches took k_multi); score-only 1361 / 1808 at 20 k, 2109 / 1925 at 60 k. Long pairs from
     // 12 288 pairs on (config 3's pairs: 10 k 1005 / 975, 12.5 k 1107 / 1054, 14 k 1198 / 1119).
     const uint64_t avg_len2 = n ? sum_len2 / n : 0;
-    const bool multi_fits = avg_len2 >= 3000 ? n >= 12288 : (!trace_mode && n >= 49152);
-    b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && min_size == ba::MQ_B_HOST && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || multi_fits);
+    // (round 6, the cheaper lane walk and one traceback wave per 3 workgroups: config 3's pairs 10 k 1068 / 1050, 12 k 1290 / 1071, 12.5 k 1342 / 1105 -> from 10 000 pairs)
+    bool multi_fits = avg_len2 >= 3000 ? n >= 10000 : (!trace_mode && n >= 49152);
+    // Round 6: batches that start at 256 cells -- what percent_len gives reads above 12.8 kbp (lib.rs:109-111, examples/nanopore_bench_global.rs:144-171) --
+    // take k_multi with two slots of 256 cells per wave: DNA, block classes 512 .. 2048, the plain modes. From the sizes at which every wave finds its two pairs.
+    b->multi_b = 128;
+    bool wide = false;
+    if (min_size == 256 && kind == BA_KIND_NUC && !special_of(mode) && max_size >= 512 && pc >= 2 && pc <= 4) {
+        wide = true; b->multi_b = 256;
+        multi_fits = avg_len2 >= 6000 && n >= 2048;   // (13 kbp reads, 256..2048, with traceback, GCUPS two-pair slots / per-pair kernel, same box: 1.5 k pairs 353 / 410, 2.5 k 576 / 401, 4 k 990 / 552, 8 k 1155 / 603, 20 k 1555 / 654, 70 k 1873 / 720)
+    }
+    b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && (min_size == ba::MQ_B_HOST || wide) && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || multi_fits);
+    if (!b->multi) b->multi_b = 128;
     if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
     if (b->small && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->small = false;   // (e.g. LDS: falls back to the per-pair kernel)
     if (!b->multi && !b->small)
@@ -1076,7 +1097,7 @@ static int batch_launch(BaBatch* b) {
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->ev_l0) HIP_TRY(hipEventRecord(b->ev_l0, b->stream));   // (a re-run sub-batch: batch_retry re-uses ev0 for the merge)
-    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (b->multi_b == 256 ? g_launch_m256[b->pclass] : special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
     if (b->quad && b->n <= b->cap_n) {
         // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
         // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a

@@ -86,6 +86,34 @@ extern "C" hipError_t BA_CAT(ba_occupancy_m_k, BA_KIND, _p, BA_PMAX)(int trace, 
     if (trace) return xdrop ? occ_multi<true, true>(blocks_per_cu, lds) : occ_multi<true, false>(blocks_per_cu, lds);
     return xdrop ? occ_multi<false, true>(blocks_per_cu, lds) : occ_multi<false, false>(blocks_per_cu, lds);
 }
+#if BA_KIND == 1 && BA_PMAX >= 4
+// ... with two slots of 256 cells per wave (round 6: DNA batches that start at 256 cells, block classes 512 .. 2048)
+template <bool TRACE, bool XDROP>
+static hipError_t launch_multi256(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 256><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP>
+static hipError_t occ_multi256(int* blocks_per_cu, unsigned lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 256>, ba::WAVES_PER_WG * 64, lds);
+}
+extern "C" hipError_t BA_CAT(ba_launch_m256_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch_multi256<true, true>(grid, lds, s, *bp) : launch_multi256<true, false>(grid, lds, s, *bp);
+    return xdrop ? launch_multi256<false, true>(grid, lds, s, *bp) : launch_multi256<false, false>(grid, lds, s, *bp);
+}
+extern "C" hipError_t BA_CAT(ba_occupancy_m256_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    if (trace) return xdrop ? occ_multi256<true, true>(blocks_per_cu, lds) : occ_multi256<true, false>(blocks_per_cu, lds);
+    return xdrop ? occ_multi256<false, true>(blocks_per_cu, lds) : occ_multi256<false, false>(blocks_per_cu, lds);
+}
+#endif
 #endif
 
 #if !BA_SPECIAL && !BA_BIG && BA_PMAX <= 8

@@ -45,6 +45,26 @@ __device__ __forceinline__ int sel_mask(unsigned long long m, int a, int b) {
     return r;
 }
 
+// ---- slots of SL = 16 lanes (128 cells, four pairs per wave) or SL = 32 lanes (256 cells, two pairs per wave: round 6). The 16-lane forms are DPP
+// row operations; a 32-lane slot spans two DPP rows, so its shifts are whole-wave shifts with the slot's own edge lane patched, and its broadcasts
+// go through the LDS crossbar (ds_bpermute: three per step). l = the lane inside its slot.
+template <int SL> __device__ __forceinline__ int slot_first(int v) {   // the slot's first lane's value, to all its lanes
+    if constexpr (SL == 16) return row_bcast<0>(v);
+    else return __builtin_amdgcn_ds_bpermute((lane_id() & 32) << 2, v);
+}
+template <int SL> __device__ __forceinline__ int slot_last(int v) {    // the slot's last lane's value, to all its lanes
+    if constexpr (SL == 16) return row_bcast<15>(v);
+    else return __builtin_amdgcn_ds_bpermute(((lane_id() & 32) + 31) << 2, v);
+}
+template <int SL> __device__ __forceinline__ int slot_shr1_z(int v, int l) {   // lane l <- l - 1 inside the slot; its first lane <- 0
+    if constexpr (SL == 16) return row_shr1_z(v);
+    else { const int t = wave_shr1_z(v); return l == 0 ? 0 : t; }
+}
+template <int SL> __device__ __forceinline__ int slot_shl1_keep(int last, int src, int l) {   // lane l <- src[l + 1] inside the slot; its last lane keeps `last`
+    if constexpr (SL == 16) return row_shl1_keep(last, src);
+    else { const int t = __builtin_amdgcn_update_dpp(last, src, 0x130, 0xf, 0xf, false); return l == SL - 1 ? last : t; }   // (wave_shl:1; lane 63 has no source: keeps `last`)
+}
+
 struct MultiConsts {
     int G[4];             // {(2k+1) g, (2k+2) g}: what a gap that enters the lane above its first cell has lost on reaching register k
     int laneKG, lanem1KG; // l * 8g; (l - 1) * 8g, except row lane 0 which holds -32768 (no lane above: a candidate that never wins)
@@ -67,9 +87,16 @@ __device__ __forceinline__ MultiConsts make_multi_consts(int l, int gx) {
 }
 // R of the lane above's last cell, from the lane's own last R (high half of its fourth register): one 16-lane scan on values re-based by l * 8g
 // serves the wave's four slots (no clamp: see fast_scan), floored at {0, W} (MultiConsts::w0)
-__device__ __forceinline__ int multi_carry(int r3, const MultiConsts& mc) {
-    const int pm = wave_prefix_max16((int)as_s(r3).y - mc.laneKG);
-    return vmax(scan8_splat_lo(add_row_shr1(pm, mc.lanem1KG)), mc.w0);
+template <int SL = 16>
+__device__ __forceinline__ int multi_carry(int r3, const MultiConsts& mc, int l = 0) {
+    if constexpr (SL == 16) {
+        const int pm = wave_prefix_max16((int)as_s(r3).y - mc.laneKG);
+        return vmax(scan8_splat_lo(add_row_shr1(pm, mc.lanem1KG)), mc.w0);
+    } else {   // 32 lanes: the scan restarts at lane 32 (wave_prefix_max32); the shift by one lane crosses the slots' edge, whose lane takes the filler instead
+        const int pm = wave_prefix_max32((int)as_s(r3).y - mc.laneKG);
+        const int cin = add_shr1(pm, mc.lanem1KG);
+        return vmax(scan8_splat_lo(l == 0 ? -32768 : cin), mc.w0);
+    }
 }
 
 struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
@@ -80,7 +107,7 @@ struct MultiOut { int mx, act_max8, pas_max8, corner_new; };
 // SPM (round 5): the special alignment modes a slot takes, as in small_rect (ba_small.hpp) -- 1 = LOCAL_START (every cell's D is at least the relative
 // zero rz2; TRACE: a zero mask of one bit per cell, two words per lane -- cells 0 .. 3 / 4 .. 7, byte = cell, bit = column --, stored by the caller behind
 // the rectangle's 128 trace words), 2 = FREE_QUERY_START_GAPS (fqs_row0: row 0 of a right step starts from the relative zero in every column).
-template <int KIND, bool TRACE, int SPM = 0>
+template <int KIND, bool TRACE, int SPM = 0, int SL = 16>
 __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& fc, const MultiConsts& mc, int l, int (&Ad)[4], int (&Ac)[4],
                                            int (&Pd)[4], int (&Pr)[4], uint2 vb, uint32_t cb_lo, uint32_t cb_hi, int corner, int off_add,
                                            uint32_t* __restrict__ tout, bool store, MultiOut& o, int rz2 = 0, bool fqs_row0 = false, int* zout = nullptr) {
@@ -91,7 +118,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
     for (int k = 0; k < 4; k++) {   // just_offset (scan_block.rs:1003-1012)
         d[k] = adds(Ad[k], offa); c[k] = adds(Ac[k], offa); pd[k] = adds(Pd[k], offa); pr[k] = adds(Pr[k], offa);
     }
-    o.corner_new = row_bcast<0>(pd[3]) >> 16;   // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based
+    o.corner_new = slot_first<SL>(pd[3]) >> 16;   // D_corner for a following orthogonal step: the orthogonal border's entry 7, re-based
     ScoreKey<KIND> key[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -117,7 +144,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
             else sc[k] = fetch_score<KIND>(table, key[k], cb);
         }
         // D00: the previous column shifted down one cell (scan_block.rs:1125); only column 0 has a cell above the block
-        int prev = row_shr1_z(d[3]);
+        int prev = slot_shr1_z<SL>(d[3], l);
         if (j == 0) prev = l == 0 ? (int)((uint32_t)corner << 16) : prev;
         int d00[4];
         d00[0] = __builtin_amdgcn_alignbit(d[0], prev, 16);
@@ -137,7 +164,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
         }
         // R11: the chain over the lane's registers, then one 16-lane scan on values re-based by l * 8g
         scan8_chain(r, mc.G[0]);
-        const int cs = multi_carry(r[3], mc);    // R of the lane above's last cell (no clamp: see fast_scan), floored: see MultiConsts::w0
+        const int cs = multi_carry<SL>(r[3], mc, l);    // R of the lane above's last cell (no clamp: see fast_scan), floored: see MultiConsts::w0
         int dn[4];
         uint32_t sC[4], sR[4], sCo[4], sRo[4];
 #pragma unroll
@@ -188,19 +215,19 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {   // shift_and_offset (scan_block.rs:1040-1061): 8 entries = one lane
-        Pd[k] = row_shl1_keep(nvD[k], pd[k]); Pr[k] = row_shl1_keep(nvR[k], pr[k]);
+        Pd[k] = slot_shl1_keep<SL>(nvD[k], pd[k], l); Pr[k] = slot_shl1_keep<SL>(nvR[k], pr[k], l);
         Ad[k] = d[k]; Ac[k] = c[k];
     }
     {   // max of the first 8 entries of both borders (row lane 0), to every lane of the slot (scan_block.rs:1020-1022)
         const int ma = vmax(vmax(d[0], d[1]), vmax(d[2], d[3])), mb = vmax(vmax(Pd[0], Pd[1]), vmax(Pd[2], Pd[3]));
         const s16x2 sa = as_s(ma), sb = as_s(mb);
         const int xa = vmax(ma, as_i(s16x2{sa.y, sa.x})), xb = vmax(mb, as_i(s16x2{sb.y, sb.x}));
-        const s16x2 rr = as_s(row_bcast<0>(__builtin_amdgcn_perm(xb, xa, 0x05040100)));
+        const s16x2 rr = as_s(slot_first<SL>(__builtin_amdgcn_perm(xb, xa, 0x05040100)));
         o.act_max8 = rr.x; o.pas_max8 = rr.y;
     }
     const int mm = vmax(vmax(dmax[0], dmax[1]), vmax(dmax[2], dmax[3]));
     const int m32 = max(mm & 0xffff, (int)((uint32_t)mm >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
-    o.mx = row_bcast<15>(wave_prefix_max16(m32));
+    o.mx = slot_last<SL>(SL == 16 ? wave_prefix_max16(m32) : wave_prefix_max32(m32));
     if constexpr (TRACE && SPM == 1) { zout[0] = (int)~zacc[0]; zout[1] = (int)~zacc[1]; }
 }
 
@@ -219,7 +246,7 @@ enum { MR_PAIR = 0, MR_BEST_I, MR_BEST_J, MR_CELLS_LO, MR_CELLS_HI, MR_BUDGET, M
        MR_BEST_MAX, MR_Y_DROP, MR_X_ITER, MR_D_CORNER, MR_NSTEPS, MR_TRACE_TOP, MR_NBLOCKS, MR_SEL, MR_WORDS };
 __device__ __forceinline__ int mq_load(const char* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }   // past the L1: the wave reads back its own stores
 
-template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0>
+template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0, int MBP = 128>
 #ifndef MQ_WAVES_EU
 #define MQ_WAVES_EU 4   // (waves per SIMD the kernel is compiled for. Tried, round 5: 2 = 256 registers, no spills -- config 3 163.6 -> 205.1 ms, 25 k pairs 55.6 -> 64.1: two waves do not fill the vector unit)
 #endif
@@ -227,11 +254,19 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
     // a slot rectangle's words on the trace stack (LOCAL_START: the zero mask takes 32 words behind the 128 trace words; the stack advances as the
     // per-pair kernel's does -- a mask word per trace word, Aligner::add_block); the walkers' records and mode bits (the special modes: room for the
     // zero-mask bits, the early stops of scan_block.rs:1597-1611)
-    constexpr uint32_t MQ_TW = (STEP * MQ_B / 8) * (SPM == 1 ? 2u : 1u);
+    // MBP (round 6): the slots' block size -- 128 cells (four slots of 16 lanes: MQ_B) or 256 (two slots of 32 lanes, the pairs percent_len starts at 256 cells:
+    // reads above 12.8 kbp, lib.rs:109-111). The same code: a slot's lanes, its buffers and its rectangles scale with it.
+    constexpr uint32_t MB = (uint32_t)MBP;
+    constexpr int SL = MBP / 8, NSLOT = 64 / SL;
+    constexpr uint32_t ALLM = (1u << NSLOT) - 1u;                                                     // every slot live
+    constexpr uint32_t ARR = 2u * MB, BUFL = 4u * ARR, BUFA = BUFL + 64u, SLOTA = 2u * BUFA + 128u;   // bytes: a border array of a slot, a state buffer in LDS / in the arena, a slot in the arena
+    static_assert((MBP == 128 || MBP == 256) && NSLOT * SLOTA <= MQ_WAVE_BYTES && NSLOT * 2u * BUFL <= MQ_LDS_SCALARS && (MBP == 128 || SPM == 0), "k_multi slot geometry");
+    static_assert(MBP != 128 || (BUFA == MQ_BUF_BYTES && SLOTA == MQ_SLOT_BYTES), "ba_params.h");
+    constexpr uint32_t MQ_TW = (STEP * MB / 8) * (SPM == 1 ? 2u : 1u);
     constexpr int TB_LB = SPM ? (int)TB_LANE_BYTES_LOC : (int)TB_LANE_BYTES_L2;
     constexpr uint32_t TB_MASK = SPM ? ~0u : (uint32_t)F_CIGAR_EQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = lane_id(), l = lane & 15, g = lane >> 4;
+    const int lane = lane_id(), l = lane & (SL - 1), g = lane / SL;
     const int wave = uni((int)threadIdx.x >> 6);
     {   // workgroup-shared scoring table, as in k_align
         char* tab = smem;
@@ -271,7 +306,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
     const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
     const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
     const uint32_t max_size = bp.max_size;
-    const bool keep_pre = XDROP || MQ_B < max_size;   // a slot keeps the state before its last improving step
+    const bool keep_pre = XDROP || MB < max_size;   // a slot keeps the state before its last improving step
     char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * MQ_WAVE_BYTES;
 
     // (values derived again after the per-pair driver instead of being kept across it: laundered so that they are not hoisted)
@@ -292,7 +327,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
     auto slot_mem_of = [&](uint32_t id, uint32_t s_i) {
         const uint32_t db = id / WAVES_PER_WG;
         const uint32_t dcb = batch_traceback ? (db + stride - 1) / stride + (db % stride == 0 ? 1u : 0u) : 0u;
-        return (char*)bp.big + (uint64_t)(id - dcb) * MQ_WAVE_BYTES + s_i * MQ_SLOT_BYTES;
+        return (char*)bp.big + (uint64_t)(id - dcb) * MQ_WAVE_BYTES + s_i * SLOTA;
     };
     // one pass over the waves' words (mq_donate[waves + 32]: offers outstanding, a hint that saves the pass): take one offered slot
     auto claim_offer = [&](uint32_t my_id, uint32_t& id_out, int& s_out) {
@@ -302,7 +337,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
         const uint32_t n_ids = gridDim.x * WAVES_PER_WG;
         for (uint32_t k0 = 0; k0 < n_ids; k0 += 64) {
             const uint32_t idx = ((my_id & ~63u) + k0 + (uint32_t)lane) % n_ids;   // (every word at least once, starting near this wave's own; the number of waves need not be a multiple of 64)
-            const uint32_t v = __hip_atomic_load(bp.mq_donate + idx, BA_RLX_AGENT) & 15u;
+            const uint32_t v = __hip_atomic_load(bp.mq_donate + idx, BA_RLX_AGENT) & ALLM;
             unsigned long long m = __ballot(v != 0u);
             while (m) {
                 const int src = __builtin_ctzll(m);
@@ -325,11 +360,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
         uint32_t id = 0; int s_o = 0;
         if ((bp.flags & 0x1000u) || !claim_offer(my_id, id, s_o)) return false;   // (0x1000 / 0x2000: development switches)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int e = __builtin_ctz(~live_m & 15u);
+        const int e = __builtin_ctz(~live_m & ALLM);
         const char* src = slot_mem_of(id, (uint32_t)s_o);
-        char* dst = wave_mem + (uint32_t)e * MQ_SLOT_BYTES;
+        char* dst = wave_mem + (uint32_t)e * SLOTA;
 #pragma unroll
-        for (int k = 0; k < (int)(MQ_SLOT_BYTES / 256u); k++) *(int*)(dst + 256 * k + 4 * lane) = mq_load(src + 256 * k + 4 * lane);
+        for (int k = 0; k < (int)(SLOTA / 256u); k++) *(int*)(dst + 256 * k + 4 * lane) = mq_load(src + 256 * k + 4 * lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the copy is in the L2 before this wave reads it back)
         live_m |= 1u << e;
         return true;
@@ -344,7 +379,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             int solo = -1; bool fresh = false, to_end = false;
             uint32_t new_pair = 0, donor_id = ~0u;
             if (pend_m) solo = __builtin_ctz(pend_m);
-            else if (more && (drain ? live_m == 0u : live_m != 15u)) {
+            else if (more && (drain ? live_m == 0u : live_m != ALLM)) {
                 if (w_next == w_end) {
                     uint32_t v = 0;
                     if (is_lane(0)) v = atomicAdd(bp.work_counter, bp.work_chunk);
@@ -352,10 +387,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                     if (w_next >= bp.n) { more = false; w_next = w_end = 0; continue; }
                     w_end = min(w_next + bp.work_chunk, bp.n);
                 }
-                new_pair = w_next++; solo = __builtin_ctz(~live_m & 15u); fresh = true;
+                new_pair = w_next++; solo = __builtin_ctz(~live_m & ALLM); fresh = true;
                 to_end = drain;                                      // (the batch is running out: this pair is not for a slot)
                 if (new_pair + bp.mq_drain >= bp.n) drain = true;    // from the next pair on
-            } else if (live_m && live_m != 15u) {
+            } else if (live_m && live_m != ALLM) {
                 // (tried in round 5: a wave with three live slots goes on stepping instead -- three slots take steps about as efficiently as a pair in
                 // solo mode --: no difference, 167.6 against 167.0 ms)
                 solo = __builtin_ctz(live_m); to_end = true;
@@ -413,12 +448,13 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
 
             BA_TSTAMP(ts_a);
             const FillConsts fc = make_fill_consts(lane, bp.gap_open, gx);   // two cells per lane (as k_align)
-            Aligner<PMAX, KIND, TRACE, XDROP, SPM != 0, true> al(bp, L, fc);
+            Aligner<PMAX, KIND, TRACE, XDROP, SPM != 0, true, MBP> al(bp, L, fc);
             PairState st{};
             uint32_t s_pair, s_slot;
-            char* smem_s = wave_mem + (uint32_t)solo * MQ_SLOT_BYTES;
+            char* smem_s = wave_mem + (uint32_t)solo * SLOTA;
             if (donor_id != ~0u) smem_s = slot_mem_of(donor_id, (uint32_t)solo);   // (a slot taken over: the other wave's region of the arena)
-            char* const rec = smem_s + 2 * MQ_BUF_BYTES;
+            char* const rec = smem_s + 2 * BUFA;
+            al.ckpt = bp.ckpt + (uint64_t)(fill_wave + bp.ckpt_wave0) * 8 * bp.max_size;   // (before import_slot: a 256-cell slot's checkpoint goes there)
             if (fresh) {
                 s_pair = new_pair;
                 // a free trace slot of this wave (a slot is busy from the pair's start until its traceback is done)
@@ -455,8 +491,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 const int rv = lane < MR_WORDS ? mq_load(rec + 4 * lane) : 0;   // the slot's record: lane k holds word k
 #define BA_W(v, k) __builtin_amdgcn_readlane(v, k)
                 const uint32_t s_sel = (uint32_t)BA_W(rv, MR_SEL);
-                const char* live_b = smem_s + (s_sel ^ 1u) * MQ_BUF_BYTES; const char* ck_b = smem_s + s_sel * MQ_BUF_BYTES;
-                const int cv = lane < 16 ? mq_load(ck_b + 1024 + 4 * lane) : 0;   // the checkpoint's scalars
+                const char* live_b = smem_s + (s_sel ^ 1u) * BUFA; const char* ck_b = smem_s + s_sel * BUFA;
+                const int cv = lane < 16 ? mq_load(ck_b + BUFL + 4 * lane) : 0;   // the checkpoint's scalars
                 s_pair = (uint32_t)BA_W(rv, MR_PAIR); s_slot = (uint32_t)BA_W(rv, MR_TSLOT);
                 st.si = (uint32_t)BA_W(rv, MR_SI); st.sj = (uint32_t)BA_W(rv, MR_SJ); st.dir = BA_W(rv, MR_DIR); st.prev_dir = BA_W(rv, MR_PREV_DIR);
                 st.off = BA_W(rv, MR_OFF); st.off_max = BA_W(rv, MR_OFF_MAX); st.best_max = BA_W(rv, MR_BEST_MAX);
@@ -464,7 +500,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 st.trace_top = (uint32_t)BA_W(rv, MR_TRACE_TOP); st.nblocks = (uint32_t)BA_W(rv, MR_NBLOCKS);
                 const uint32_t ns = (uint32_t)BA_W(rv, MR_NSTEPS);
                 st.best_i = (uint32_t)BA_W(rv, MR_BEST_I); st.best_j = (uint32_t)BA_W(rv, MR_BEST_J);
-                st.cells = ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_LO) | ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_HI) << 32)) + (unsigned long long)ns * (STEP * MQ_B);
+                st.cells = ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_LO) | ((unsigned long long)(uint32_t)BA_W(rv, MR_CELLS_HI) << 32)) + (unsigned long long)ns * (STEP * MB);
                 const uint32_t bud = (uint32_t)BA_W(rv, MR_BUDGET);
                 st.step_budget = bud > ns ? bud - ns : 1u;
                 st.status = (uint32_t)BA_W(rv, MR_STATUS);
@@ -477,19 +513,19 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 {   // the borders: lane l's 16 bytes of each array (lanes 0 .. 15), into the canonical order D_col, C_col, D_row, R_row
                     int reg[16], ckr[16];
                     const bool lr = st.dir == DIR_RIGHT, cr = ck_dir == DIR_RIGHT;
-                    const uint32_t oAd = (lr ? 0u : 512u) + l * 16, oAc = (lr ? 256u : 768u) + l * 16, oPd = (lr ? 512u : 0u) + l * 16, oPr = (lr ? 768u : 256u) + l * 16;
-                    const uint32_t cAd = (cr ? 0u : 512u) + l * 16, cAc = (cr ? 256u : 768u) + l * 16, cPd = (cr ? 512u : 0u) + l * 16, cPr = (cr ? 768u : 256u) + l * 16;
+                    // (lanes 0 .. SL - 1 hold the slot's cells: here l = lane for them)
+                    const uint32_t oAd = (lr ? 0u : 2 * ARR) + l * 16, oAc = (lr ? ARR : 3 * ARR) + l * 16, oPd = (lr ? 2 * ARR : 0u) + l * 16, oPr = (lr ? 3 * ARR : ARR) + l * 16;
+                    const uint32_t cAd = (cr ? 0u : 2 * ARR) + l * 16, cAc = (cr ? ARR : 3 * ARR) + l * 16, cPd = (cr ? 2 * ARR : 0u) + l * 16, cPr = (cr ? 3 * ARR : ARR) + l * 16;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         reg[k] = mq_load(live_b + oAd + 4 * k); reg[4 + k] = mq_load(live_b + oAc + 4 * k); reg[8 + k] = mq_load(live_b + oPd + 4 * k); reg[12 + k] = mq_load(live_b + oPr + 4 * k);
                         ckr[k] = mq_load(ck_b + cAd + 4 * k); ckr[4 + k] = mq_load(ck_b + cAc + 4 * k); ckr[8 + k] = mq_load(ck_b + cPd + 4 * k); ckr[12 + k] = mq_load(ck_b + cPr + 4 * k);
                     }
-                    al.import_slot(reg, ckr, s_pair, ck_pre || MQ_B < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j, st.ck_off);
+                    al.import_slot(reg, ckr, s_pair, ck_pre || MB < max_size, ck_pre, ck_dir, ck_offadd, ck_corner, st.ck_i, st.ck_j, st.best_i, st.best_j, st.ck_off);
                 }
             }
             al.trace = bp.trace_arena + (uint64_t)s_slot * bp.trace_stride;
             al.blocks = bp.blocks + (uint64_t)s_slot * bp.blocks_stride;
-            al.ckpt = bp.ckpt + (uint64_t)(fill_wave + bp.ckpt_wave0) * 8 * bp.max_size;
             // The per-pair driver needs every scalar register: what the wave keeps across it is parked in the lanes of one VGPR
             // (the compiler would otherwise spill and reload these values inside the driver's inner loops).
             int keepv = 0;
@@ -503,8 +539,8 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             live_m = (uint32_t)unpark<0>(keepv); pend_m = (uint32_t)unpark<1>(keepv); w_next = (uint32_t)unpark<2>(keepv); w_end = (uint32_t)unpark<3>(keepv);
             { const int fl = unpark<4>(keepv); more = fl & 1; fresh = fl & 2; to_end = fl & 4; drain = fl & 8; }
             solo = unpark<5>(keepv); s_pair = (uint32_t)unpark<6>(keepv); s_slot = (uint32_t)unpark<7>(keepv);
-            char* const smem_s2 = (char*)coldp_big() + (uint64_t)fill_wave_of() * MQ_WAVE_BYTES + (uint32_t)solo * MQ_SLOT_BYTES;
-            char* const rec2 = smem_s2 + 2 * MQ_BUF_BYTES;
+            char* const smem_s2 = (char*)coldp_big() + (uint64_t)fill_wave_of() * MQ_WAVE_BYTES + (uint32_t)solo * SLOTA;
+            char* const rec2 = smem_s2 + 2 * BUFA;
 #ifdef BA_TIMING
             {   // development: the per-pair driver's phase timers (as k_align), + 45 = run(), 56 / 57 / 58 = run() of a new pair / a pair back from its slot / a pair taken to its end
                 const unsigned long long tr_b = __builtin_amdgcn_s_memtime();
@@ -516,24 +552,24 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             }
 #endif
             pend_m &= ~(1u << solo);
-            if (st.exited) {   // the pair's next step is a plain shift step at MQ_B cells: into the slot (its memory)
+            if (st.exited) {   // the pair's next step is a plain shift step at MB cells: into the slot (its memory)
                 const bool rgt = st.dir == DIR_RIGHT;
-                if (lane < 16) {
+                if (lane < SL) {
                     const int l8 = 8 * l;
                     const int4 a_d = *(const int4*)((rgt ? L.D_col : L.D_row) + l8), a_c = *(const int4*)((rgt ? L.C_col : L.R_row) + l8);
                     const int4 p_d = *(const int4*)((rgt ? L.D_row : L.D_col) + l8), p_r = *(const int4*)((rgt ? L.R_row : L.C_col) + l8);
-                    char* b1 = smem_s2 + MQ_BUF_BYTES;   // the state at the top of the loop: buffer 1 (sel = 0)
-                    *(int4*)(b1 + l * 16) = a_d; *(int4*)(b1 + 256 + l * 16) = a_c; *(int4*)(b1 + 512 + l * 16) = p_d; *(int4*)(b1 + 768 + l * 16) = p_r;
-                    if (MQ_B < max_size) {   // the checkpoint as the reference keeps it (after its step): buffer 0
+                    char* b1 = smem_s2 + BUFA;   // the state at the top of the loop: buffer 1 (sel = 0)
+                    *(int4*)(b1 + l * 16) = a_d; *(int4*)(b1 + ARR + l * 16) = a_c; *(int4*)(b1 + 2 * ARR + l * 16) = p_d; *(int4*)(b1 + 3 * ARR + l * 16) = p_r;
+                    if (MB < max_size) {   // the checkpoint as the reference keeps it (after its step): buffer 0
                         char* b0 = smem_s2;
-                        *(int4*)(b0 + l * 16) = *(const int4*)(L.D_col + MQ_B + l8); *(int4*)(b0 + 256 + l * 16) = *(const int4*)(L.C_col + MQ_B + l8);
-                        *(int4*)(b0 + 512 + l * 16) = *(const int4*)(L.D_row + MQ_B + l8); *(int4*)(b0 + 768 + l * 16) = *(const int4*)(L.R_row + MQ_B + l8);
+                        *(int4*)(b0 + l * 16) = *(const int4*)(L.D_col + MB + l8); *(int4*)(b0 + ARR + l * 16) = *(const int4*)(L.C_col + MB + l8);
+                        *(int4*)(b0 + 2 * ARR + l * 16) = *(const int4*)(L.D_row + MB + l8); *(int4*)(b0 + 3 * ARR + l * 16) = *(const int4*)(L.R_row + MB + l8);
                     }
                 }
                 if (is_lane(0)) {
                     char* b0 = smem_s2;
-                    *(int4*)(b0 + 1024) = int4{0, (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + 1040) = int4{(int)st.ck_tt, (int)st.ck_nb, DIR_RIGHT, 0};
-                    *(int*)(b0 + 1056) = 0;
+                    *(int4*)(b0 + BUFL) = int4{0, (int)st.ck_i, (int)st.ck_j, st.ck_off}; *(int4*)(b0 + BUFL + 16) = int4{(int)st.ck_tt, (int)st.ck_nb, DIR_RIGHT, 0};
+                    *(int*)(b0 + BUFL + 32) = 0;
                     int* rc = (int*)rec2;
                     rc[MR_PAIR] = (int)s_pair; rc[MR_BEST_I] = (int)st.best_i; rc[MR_BEST_J] = (int)st.best_j; rc[MR_CELLS_LO] = (int)(uint32_t)st.cells; rc[MR_CELLS_HI] = (int)(uint32_t)(st.cells >> 32);
                     rc[MR_BUDGET] = (int)st.step_budget; rc[MR_STATUS] = (int)st.status; rc[MR_TSLOT] = (int)s_slot; rc[MR_SI] = (int)st.si; rc[MR_SJ] = (int)st.sj; rc[MR_DIR] = st.dir;
@@ -552,7 +588,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
         // ================= the slots: registers from memory, shift steps until a slot needs solo mode, registers to memory
         {
             BA_TSTAMP(tq_a);
-            char* const slot_mem = wave_mem + (uint32_t)g * MQ_SLOT_BYTES;   // this lane's slot
+            char* const slot_mem = wave_mem + (uint32_t)g * SLOTA;   // this lane's slot
             const int x_drop = bp.x_drop;
             FillConsts fq;   // only the three gap constants (wave-uniform)
             fq.go2 = splat(bp.gap_open); fq.ge2 = splat(gx); fq.ome2 = splat(clamp16(bp.gap_open - gx));
@@ -561,7 +597,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             const uint32_t tcap = (uint32_t)(tcap64 < 0x7fffffffull ? tcap64 : 0x7fffffffull), bcap = (uint32_t)(bcap64 < 0x7fffffffull ? bcap64 : 0x7fffffffull);
             // ---- slot state (row-uniform, replicated over the slot's lanes)
             const bool live = (live_m >> g) & 1u;   // (all four, except when the batch holds fewer pairs than the wave has slots)
-            const char* rec = slot_mem + 2 * MQ_BUF_BYTES;
+            const char* rec = slot_mem + 2 * BUFA;
 #define BA_R(k) (live ? mq_load(rec + 4 * (k)) : 0)
             const uint32_t pair = (uint32_t)BA_R(MR_PAIR), tslot = (uint32_t)BA_R(MR_TSLOT);
             uint32_t si = (uint32_t)BA_R(MR_SI), sj = (uint32_t)BA_R(MR_SJ), y_drop = (uint32_t)BA_R(MR_Y_DROP);
@@ -571,16 +607,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
 #undef BA_R
             int A_d[4], A_c[4], P_d[4], P_r[4];   // borders: (A) along the vector axis of the step at `dir`, (P) orthogonal
             {
-                const char* b = slot_mem + (sel ^ 1u) * MQ_BUF_BYTES + l * 16;
+                const char* b = slot_mem + (sel ^ 1u) * BUFA + l * 16;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    A_d[k] = live ? mq_load(b + 4 * k) : 0; A_c[k] = live ? mq_load(b + 256 + 4 * k) : 0;
-                    P_d[k] = live ? mq_load(b + 512 + 4 * k) : 0; P_r[k] = live ? mq_load(b + 768 + 4 * k) : 0;
+                    A_d[k] = live ? mq_load(b + 4 * k) : 0; A_c[k] = live ? mq_load(b + ARR + 4 * k) : 0;
+                    P_d[k] = live ? mq_load(b + 2 * ARR + 4 * k) : 0; P_r[k] = live ? mq_load(b + 3 * ARR + 4 * k) : 0;
                 }
             }
             // While the slots run, the two buffers of every slot live in this wave's LDS region (the solo borders' space): the checkpoint
             // (buffer `sel`) comes from the arena now and goes back after the loop; the other one is rewritten before every step.
-            char* const lbuf = base + (uint32_t)g * 2048u;                       // this slot's buffers: + which * 1024
+            char* const lbuf = base + (uint32_t)g * (2u * BUFL);                 // this slot's buffers: + which * BUFL
             int* const lsc = (int*)(base + MQ_LDS_SCALARS) + (uint32_t)g * MQ_LSC_INTS;   // their scalars: + which * 9; + 20: eight constants of the slot's pair
             lds_sync();
             // (score-only kernels have the registers: there the values stay where they were -- 119.8 against 125.5 ms at config 3 without traceback)
@@ -594,14 +630,14 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 *(int4*)(lsc + 24) = int4{live ? (int)bp.q_len[pair] : 0, live ? (int)bp.r_len[pair] : 0, (int)tslot, 0};
             }
             if (live) {
-                const char* cb = slot_mem + sel * MQ_BUF_BYTES;
-                char* d = lbuf + sel * 1024u + l * 16;
+                const char* cb = slot_mem + sel * BUFA;
+                char* d = lbuf + sel * BUFL + l * 16;
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
-                    const char* sp = cb + a * 256 + l * 16;
-                    *(int4*)(d + a * 256) = int4{mq_load(sp), mq_load(sp + 4), mq_load(sp + 8), mq_load(sp + 12)};
+                    const char* sp = cb + a * ARR + l * 16;
+                    *(int4*)(d + a * ARR) = int4{mq_load(sp), mq_load(sp + 4), mq_load(sp + 8), mq_load(sp + 12)};
                 }
-                if (l < 9) lsc[sel * 9u + l] = mq_load(cb + 1024 + 4 * l);
+                if (l < 9) lsc[sel * 9u + l] = mq_load(cb + BUFL + 4 * l);
             }
             lds_sync();
             // sequence bytes of the next step, fetched one step ahead for both possible directions
@@ -609,9 +645,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             bool leave = false;
             // the slot's registers and the scalars of the step at the top into the buffer `which` (see above)
             auto stage = [&](uint32_t which, uint32_t s_i, uint32_t s_j, int s_off, uint32_t s_tt, uint32_t s_nb, int s_dir, int s_offadd, int s_corner) {
-                char* b = lbuf + which * 1024u + l * 16;
-                *(int4*)(b) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + 256) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
-                *(int4*)(b + 512) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 768) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
+                char* b = lbuf + which * BUFL + l * 16;
+                *(int4*)(b) = int4{A_d[0], A_d[1], A_d[2], A_d[3]}; *(int4*)(b + ARR) = int4{A_c[0], A_c[1], A_c[2], A_c[3]};
+                *(int4*)(b + 2 * ARR) = int4{P_d[0], P_d[1], P_d[2], P_d[3]}; *(int4*)(b + 3 * ARR) = int4{P_r[0], P_r[1], P_r[2], P_r[3]};
                 if (l == 0) {
                     int* sc = lsc + which * 9u;
                     sc[0] = 1; sc[1] = (int)s_i; sc[2] = (int)s_j; sc[3] = s_off; sc[4] = (int)s_tt; sc[5] = (int)s_nb; sc[6] = s_dir; sc[7] = s_offadd; sc[8] = s_corner;
@@ -625,11 +661,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 const uint8_t* const qp = TRACE ? (const uint8_t*)((unsigned long long)(uint32_t)cA.x | ((unsigned long long)(uint32_t)cA.y << 32)) : (const uint8_t*)qa_r;
                 const uint8_t* const rp = TRACE ? (const uint8_t*)((unsigned long long)(uint32_t)cA.z | ((unsigned long long)(uint32_t)cA.w << 32)) : (const uint8_t*)ra_r;
                 const uint32_t qlen = TRACE ? (uint32_t)cB.x : qlen_r, rlen = TRACE ? (uint32_t)cB.y : rlen_r;
-                const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (MQ_B - STEP);
+                const uint32_t ri = right ? si : sj, rj = (right ? sj : si) + (MB - STEP);
                 const uint32_t lenV = right ? qlen : rlen, lenC = right ? rlen : qlen;
-                const bool q_out = si + MQ_B > qlen, r_out = sj + MQ_B > rlen;
+                const bool q_out = si + MB > qlen, r_out = sj + MB > rlen;
                 // a step that could break early at the matrix edge (never with X-drop) or that the trace slot has no room for is not a slot's
-                bool elig = XDROP || ri + MQ_B <= lenV || rj + STEP <= lenC;
+                bool elig = XDROP || ri + MB <= lenV || rj + STEP <= lenC;
                 if (TRACE) elig = elig && nblocks < bcap && trace_top + MQ_TW + 64 <= tcap;
                 leave = live && !elig;
                 const bool run = live && !leave;
@@ -648,7 +684,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 asm volatile("" : "+v"(mc.laneKG), "+v"(mc.lanem1KG), "+v"(mc.w0));
                 uint32_t l8;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l8));
-                l8 = (l8 & 15u) * 8u;
+                l8 = (l8 & (uint32_t)(SL - 1)) * 8u;
                 uint2 vb, cbv;
                 {
                     const uint8_t* Vp = right ? qp : rp; const uint8_t* Cp = right ? rp : qp;
@@ -664,7 +700,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                     asm volatile("" : "+v"(vb.x), "+v"(vb.y));   // (consume the old prefetch before the next one is issued: the memory counter is in-order)
                     if (run) {                                    // for the step after this one, whichever way it goes
                         const uint32_t* a = (const uint32_t*)(qp + (si + l8)); const uint32_t* b = (const uint32_t*)(rp + (sj + l8));
-                        const uint32_t* cq = (const uint32_t*)(qp + si + MQ_B); const uint32_t* cr = (const uint32_t*)(rp + sj + MQ_B);
+                        const uint32_t* cq = (const uint32_t*)(qp + si + MB); const uint32_t* cr = (const uint32_t*)(rp + sj + MB);
                         pf_qv.x = a[0]; pf_qv.y = a[1]; pf_rv.x = b[0]; pf_rv.y = b[1];
                         pf_qc.x = cq[0]; pf_qc.y = cq[1]; pf_rc.x = cr[0]; pf_rc.y = cr[1];
                         pf_ok = true;
@@ -679,14 +715,14 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                     if (run && l == 0) {   // add_block(i, j, width, height, right) in matrix orientation (scan_block.rs:154,204)
                         BlockRec br;
                         br.i = (right ? ri : rj) | 0x80000000u;   // (bit 31: words of 4 cells x 2 columns, see multi_rect)
-                        br.j = right ? rj : ri; br.h = (uint16_t)(right ? MQ_B : STEP); br.w = (uint16_t)(right ? STEP : MQ_B);
+                        br.j = right ? rj : ri; br.h = (uint16_t)(right ? MB : STEP); br.w = (uint16_t)(right ? STEP : MB);
                         br.trace_base = trace_top | (right ? 0x80000000u : 0u);
                         bp.blocks[(uint64_t)(uint32_t)cB.z * bp.blocks_stride + nblocks] = br;
                     }
                 }
                 MultiOut o;
                 int zw[2] = {0, 0};
-                multi_rect<KIND, TRACE, SPM>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, tw, run, o, SPM ? splat(sat16(ZERO - off_n)) : 0,
+                multi_rect<KIND, TRACE, SPM, SL>(smem, fq, mc, l, A_d, A_c, P_d, P_r, vb, cbv.x, cbv.y, corner, off_add, tw, run, o, SPM ? splat(sat16(ZERO - off_n)) : 0,
                                              SPM == 2 && right && ri == 0u && l == 0, zw);
                 if (TRACE && SPM == 1 && run) *(int2*)(tw - 8 * l + 128 + 2 * l) = int2{zw[0], zw[1]};   // the rectangle's zero mask behind its 128 trace words
 
@@ -697,7 +733,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 const uint32_t new_y = improve ? 0u : y_drop + 1;
                 bool stop = q_out && r_out;                                                                   // end of the matrix
                 if (XDROP) stop = stop || (!improve && new_off_max < best_max - x_drop && x_iter >= 1);      // X-drop termination
-                stop = stop || (!q_out && !r_out && 2 * MQ_B <= max_size && new_y > MQ_B / STEP - 1);        // grow
+                stop = stop || (!q_out && !r_out && 2 * MB <= max_size && new_y > MB / STEP - 1);        // grow
                 const bool commit = run && !stop;
                 leave = leave || (run && stop);   // rolled back: the pair's state is what was staged before this step
                 {
@@ -735,16 +771,16 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
             if (live) {   // both buffers back to the arena (solo mode needs the LDS region, and reads a pair's state from the arena)
 #pragma unroll
                 for (int w = 0; w < 2; w++) {
-                    const char* sp = lbuf + w * 1024 + l * 16;
-                    char* d = slot_mem + w * MQ_BUF_BYTES + l * 16;
+                    const char* sp = lbuf + w * BUFL + l * 16;
+                    char* d = slot_mem + w * BUFA + l * 16;
 #pragma unroll
-                    for (int a = 0; a < 4; a++) *(int4*)(d + a * 256) = *(const int4*)(sp + a * 256);
-                    if (l < 9) *(int*)(slot_mem + w * MQ_BUF_BYTES + 1024 + 4 * l) = lsc[w * 9 + l];
+                    for (int a = 0; a < 4; a++) *(int4*)(d + a * ARR) = *(const int4*)(sp + a * ARR);
+                    if (l < 9) *(int*)(slot_mem + w * BUFA + BUFL + 4 * l) = lsc[w * 9 + l];
                 }
             }
             lds_sync();
             if (live && l == 0) {
-                int* rc = (int*)(slot_mem + 2 * MQ_BUF_BYTES);
+                int* rc = (int*)(slot_mem + 2 * BUFA);
                 // (the steps taken here are not counted in a register: every one moved the block by STEP in one direction)
                 const uint32_t nsteps = (uint32_t)mq_load((const char*)(rc + MR_NSTEPS)) + ((si + sj) - (uint32_t)mq_load((const char*)(rc + MR_SI)) - (uint32_t)mq_load((const char*)(rc + MR_SJ))) / (uint32_t)STEP;
                 rc[MR_SI] = (int)si; rc[MR_SJ] = (int)sj; rc[MR_DIR] = dir; rc[MR_PREV_DIR] = prev_dir; rc[MR_OFF] = off; rc[MR_OFF_MAX] = off_max; rc[MR_BEST_MAX] = best_max;
@@ -752,7 +788,9 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 rc[MR_NBLOCKS] = (int)nblocks; rc[MR_SEL] = (int)sel;
             }
             const unsigned long long lm = __ballot(leave && l == 0);
-            pend_m = (uint32_t)((lm & 1ull) | ((lm >> 15) & 2ull) | ((lm >> 30) & 4ull) | ((lm >> 45) & 8ull));
+            pend_m = 0;
+#pragma unroll
+            for (int sl_i = 0; sl_i < NSLOT; sl_i++) pend_m |= (uint32_t)((lm >> (sl_i * SL)) & 1ull) << sl_i;
 #ifdef BA_TIMING
             t_quad += __builtin_amdgcn_s_memtime() - tq_a;
 #endif

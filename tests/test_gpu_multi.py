@@ -133,3 +133,51 @@ def test_multi_at_production_threshold(hip, oracle, mode):
     """No forcing: a batch above the size from which the library itself picks the multi-pair kernel."""
     pairs = synth.make_pairs(20000, (300, 900), (20, 90), 60, synth.DNA, seed=2024)
     compare(hip, oracle, pairs, NUC, (-5, -1), (128, 256), 80, mode, threads=16)
+
+
+# ---- round 6: slots of 256 cells (two pairs per wave, 32 lanes each): DNA batches that start at 256 cells -- percent_len of reads above
+# 12.8 kbp (lib.rs:109-111, examples/nanopore_bench_global.rs:144-171)
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("size", [(256, 512), (256, 1024), (256, 2048)])
+def test_multi256_dna(hip, oracle, force_multi, mode, size):
+    """Indels of 20 .. 400 bases force grows, checkpoint restores and shrinks: pairs move between their 256-cell slot and solo mode many times."""
+    pairs = synth.make_pairs(150, (1500, 6000), (100, 600), 200, synth.DNA, seed=1900 + size[1], indels=3, indel_len=(20, 400))
+    b = hip.BatchAligner(NUC, (-5, -1), size, 100, sum({"trace": hip.TRACE, "x_drop": hip.X_DROP}[k] for k in mode), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi"
+    b.close()
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, mode)
+    assert res["cells"].max() > 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_multi256_ragged_and_short(hip, oracle, force_multi, mode):
+    """Pairs shorter than a block, empty sequences and one-sided pairs share waves with ordinary ones."""
+    rng = np.random.default_rng(12)
+    lists = [(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A", b"A"), (b"A" * 255, b"A" * 257), (b"ACGT" * 70, b"ACGT" * 500)]
+    for _ in range(60):
+        n = int(rng.integers(0, 2400))
+        a = synth.rand_str(rng, n, synth.DNA)
+        b = synth.mutate(rng, a, int(rng.integers(0, 1 + n // 8)), synth.DNA) if n else a
+        lists.append((a.tobytes(), b.tobytes()))
+    pairs = synth.PairSet.from_lists(lists)
+    compare(hip, oracle, pairs, NUC, (-5, -1), (256, 1024), 60, mode)
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",), ("x_drop",)])
+def test_multi256_long_reads_with_traceback_waves(hip, oracle, force_multi, monkeypatch, mode):
+    """13 kbp-shaped pairs (what percent_len starts at 256 cells) with the in-launch hand-off to traceback waves, recycled trace slots and the
+    slots changing waves at the end of the batch."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", "1")
+    pairs = synth.make_pairs(700, (6000, 14000), (500, 1400), 500, synth.DNA, seed=4322)
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), (256, 2048), 100, mode)
+    assert (res["query_idx"] > 4000).all()
+
+
+def test_multi256_release_library_takes_it_from_the_threshold(hip, oracle):
+    """The release library itself picks the 256-cell slots for a batch of long reads (no development switch)."""
+    pairs = synth.make_pairs(2100, (3200, 3600), (300, 350), 100, synth.DNA, seed=77, workers=8)
+    b = hip.BatchAligner(NUC, (-5, -1), (256, 512), 100, hip.TRACE | hip.X_DROP | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi", b.info()
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), (256, 512), 100, ("trace", "x_drop"))

@@ -8,7 +8,7 @@ if os.environ.get("BA_LIB"):   # another build of the library (same-box A/B)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 trace = os.environ.get("C3_TRACE", "1") == "1"
 w = W.config3(n, length=int(os.environ.get("C3_LEN", "10000")), edits=int(os.environ.get("C3_EDITS", "1000")), tail=int(os.environ.get("C3_TAIL", "500")),
-              workers=int(os.environ.get("BA_GEN_WORKERS", "8")), size=(128, 1024), trace=trace)
+              workers=int(os.environ.get("BA_GEN_WORKERS", "8")), size=tuple(int(x) for x in os.environ.get("C3_SIZE", "128,1024").split(",")), trace=trace)
 if os.environ.get("C3_MODE"):   # e.g. local_start / free_query_start_gaps on top of the configuration's own modes
     w.mode = tuple(w.mode) + tuple(os.environ["C3_MODE"].split(","))
 b = W.make_batch(H, w)
