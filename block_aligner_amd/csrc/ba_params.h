@@ -130,7 +130,10 @@ constexpr uint32_t MQ_LDS_SCALARS = 8192, MQ_LSC_INTS = 28, MQ_LDS_BYTES = 8192 
 constexpr uint32_t SM_B_HOST = 32, SM_SLOTS = 16;
 constexpr uint32_t SM_BUF_BYTES = 4 * 64 + 32, SM_SLOT_BYTES = 2 * SM_BUF_BYTES + 128, SM_WAVE_BYTES = SM_SLOTS * SM_SLOT_BYTES;
 constexpr uint32_t SM_LDS_SCALARS = 8192, SM_LDS_BYTES = 8192 + SM_SLOTS * 2 * 32;
-constexpr int WAVES_PER_WG = 8;   // independent waves per workgroup; they share the read-only score table in LDS
+#ifndef BA_WAVES_PER_WG
+#define BA_WAVES_PER_WG 8   // (development: a kernel object built with 6 runs three waves per SIMD under a host built with 8 -- the arenas are only larger than needed)
+#endif
+constexpr int WAVES_PER_WG = BA_WAVES_PER_WG;   // independent waves per workgroup; they share the read-only score table in LDS
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
 BA_HD constexpr uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }

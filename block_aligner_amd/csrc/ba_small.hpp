@@ -392,7 +392,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64) __attribute__((amdgpu_waves
             park<0>(keepv, (int)live_m); park<1>(keepv, (int)pend_m); park<2>(keepv, (int)w_next); park<3>(keepv, (int)w_end);
             park<4>(keepv, (more ? 1 : 0) | (excl_more ? 2 : 0)); park<5>(keepv, solo); park<6>(keepv, (int)s_pair);
             // (a pair in solo mode keeps the wave's other fifteen slots waiting: its dependent chain goes first among the SIMD's waves)
-            __builtin_amdgcn_s_setprio(MQ_SOLO_PRIO);
+#ifndef SM_EXCL_PRIO
+#define SM_EXCL_PRIO MQ_SOLO_PRIO   // (priority of the pairs run from start to end -- the batch's longest, whose chain ends the launch; 3: see DESIGN.md)
+#endif
+            if (to_end) __builtin_amdgcn_s_setprio(SM_EXCL_PRIO); else __builtin_amdgcn_s_setprio(MQ_SOLO_PRIO);
             // (a pair run from start to end here -- one of the batch's longest -- walks its path at once, with the whole wave: the batch's longest
             // walks overlap with the fill. Tried instead: the first waves to run out of work take these walks from a counter -- they all run out
             // at about the same time, so the walks only lengthen the launch: protein set with traceback 11.1 -> 13.3 ms)
