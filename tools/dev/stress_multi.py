@@ -39,9 +39,15 @@ for seed in range(seed0, seed0 + count):
                 r = np.concatenate([synth.rand_str(rng, int(rng.integers(0, 400)), alpha), r])
             lists.append((q.astype(np.uint8).tobytes(), r.astype(np.uint8).tobytes()))
         pairs = synth.PairSet.from_lists(lists)
-    what = (seed, kind, (128, hi), (opn, ext), x_drop, mode)
+    lo = 128
+    if os.environ.get("STRESS_WIDE"):   # round 6: k_multi's 256-cell slots (DNA, the plain modes, 256..512 / 1024 / 2048), longer pairs
+        lo, hi = 256, 512 << int(rng.integers(0, 3))
+        alpha, matrix, kind = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))), 0
+        mode = tuple(m for m in mode if m in ("trace", "x_drop"))
+        pairs = synth.make_pairs(5000, (2 * lo_len + 3000, 2 * hi_len + 4000), (2 * edits[0], 3 * edits[1]), tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 300), workers=8)
+    what = (seed, kind, (lo, hi), (opn, ext), x_drop, mode)
     try:
-        run_and_compare(H, o, pairs, matrix, (opn, ext), (128, hi), x_drop if "x_drop" in mode else 0, mode, kind == 0, what)
+        run_and_compare(H, o, pairs, matrix, (opn, ext), (lo, hi), x_drop if "x_drop" in mode else 0, mode, kind == 0, what)
         print("ok", what, flush=True)
     except Exception as e:   # noqa: BLE001
         bad += 1
