@@ -930,7 +930,10 @@ __device__ __forceinline__ void traceback_consumer(const BatchParams& bp, uint32
 #ifndef BA_TB_PRIO
 #define BA_TB_PRIO 3
 #endif
-    if (prio == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(BA_TB_PRIO);   // (k_multi: below its solo mode's priority, ten trace slots per wave give the walks slack: +0.8 %)
+#ifndef MQ_TB_PRIO
+#define MQ_TB_PRIO 1   // (k_multi's traceback waves)
+#endif
+    if (prio == 1) __builtin_amdgcn_s_setprio(MQ_TB_PRIO); else __builtin_amdgcn_s_setprio(BA_TB_PRIO);   // (k_multi: below its solo mode's priority, ten trace slots per wave give the walks slack: +0.8 %)
 #ifdef BA_TIMING
     unsigned long long c_sec[3] = {};
     unsigned long long c_iters = 0, c_walk_lanes = 0, c_walk_iters = 0, c_poll_iters = 0, c_walk_ticks = 0, c_t0 = __builtin_amdgcn_s_memtime();
