@@ -78,6 +78,17 @@ extern "C" hipError_t ba_launch_m256_k1_p16(int, int, unsigned, unsigned, hipStr
 extern "C" hipError_t ba_occupancy_m256_k1_p4(int, int, unsigned, int*);
 extern "C" hipError_t ba_occupancy_m256_k1_p8(int, int, unsigned, int*);
 extern "C" hipError_t ba_occupancy_m256_k1_p16(int, int, unsigned, int*);
+extern "C" hipError_t ba_launch_mg3_k1_p4(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_mg3_k1_p8(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_mg2_k1_p4(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_mg2_k1_p8(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_occupancy_mg3_k1_p4(int, int, unsigned, int*);
+extern "C" hipError_t ba_occupancy_mg3_k1_p8(int, int, unsigned, int*);
+extern "C" hipError_t ba_occupancy_mg2_k1_p4(int, int, unsigned, int*);
+extern "C" hipError_t ba_occupancy_mg2_k1_p8(int, int, unsigned, int*);
+// k_multi in four-wave workgroups at three / two waves per SIMD (DNA, block classes 512 and 1024): [waves per SIMD - 2][block class]
+static const LaunchFn g_launch_mg[2][5] = {{nullptr, nullptr, ba_launch_mg2_k1_p4, ba_launch_mg2_k1_p8, nullptr}, {nullptr, nullptr, ba_launch_mg3_k1_p4, ba_launch_mg3_k1_p8, nullptr}};
+static const OccFn g_occ_mg[2][5] = {{nullptr, nullptr, ba_occupancy_mg2_k1_p4, ba_occupancy_mg2_k1_p8, nullptr}, {nullptr, nullptr, ba_occupancy_mg3_k1_p4, ba_occupancy_mg3_k1_p8, nullptr}};
 static const LaunchFn g_launch_m256[5] = {nullptr, nullptr, ba_launch_m256_k1_p4, ba_launch_m256_k1_p8, ba_launch_m256_k1_p16};   // [block class]
 static const OccFn g_occ_m256[5] = {nullptr, nullptr, ba_occupancy_m256_k1_p4, ba_occupancy_m256_k1_p8, ba_occupancy_m256_k1_p16};
 // ... and its LOCAL_START / FREE_QUERY_START_GAPS instantiations (the batch's flags choose)
@@ -295,6 +306,8 @@ struct BaBatch {
     uint32_t mq_drain = 0;      // k_multi: pairs at the end of the batch that are run one at a time (BatchParams::mq_drain)
     bool multi = false;         // the batch starts at 128 cells: four pairs per wave while a pair's block is 128 cells (ba_multi.hpp)
     uint32_t multi_b = 128;     // ... or at 256 cells (round 6): two pairs per wave, slots of 32 lanes
+    uint32_t geom = 0;          // k_multi, round 6: 0 = workgroups of WAVES_PER_WG waves at four waves per SIMD; 3 / 2 = four-wave workgroups at that many waves per SIMD (batch_build)
+    uint32_t wpw = ba::WAVES_PER_WG;   // waves per workgroup of the batch's launch (MQ_GEOM_WPW with geom)
     uint32_t walk_wave_n = 0;   // k_walk: the first walk_wave_n pairs of the batch order are walked one to a wave (plan_walks)
     uint32_t sm_excl_n = 0;     // k_small: the batch's longest pairs, run one to a wave (plan_exclusive)
     uint32_t sm_side_n = 0;     // ... of which the first sm_side_n run in a launch of their own beside the main one (TRACE batches: batch_launch)
@@ -339,7 +352,7 @@ struct BaBatch {
         bp.work_counter = counter.as<uint32_t>();
         bp.work_chunk = work_chunk;
         bp.mq_drain = mq_drain;
-        bp.mq_waves = grid * ba::WAVES_PER_WG;
+        bp.mq_waves = grid * wpw;
         bp.mq_donate = (multi && (mode & BA_TRACE) && !special_of(mode) && donate.p && !dev_env("BA_NO_DONATE")) ? donate.as<uint32_t>() : nullptr;   // (the special modes: no slot donation)   // (the score-only kernels are compiled without the end-of-batch code)
         bp.sm_excl_n = small ? sm_excl_n : 0; bp.sm_excl_first = 0;
         bp.prof = prof.as<unsigned long long>();
@@ -601,20 +614,24 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     if (hipGetDeviceProperties(&prop, b->device) != hipSuccess) { fail("hipGetDeviceProperties failed"); return 1; }
     // (sized by the block class 128 << pc, as the kernels lay it out, + the traceback wave's windows)
     // (k_multi's traceback waves keep their records in their own wave's region: no extra space)
-    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc)) : (b->small ? ba::sm_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? (special_of(mode) ? ba::TB_LDS_BYTES_LOC : ba::TB_LDS_BYTES) : 0u));   // (the special modes' walk records also hold zero-mask bits)
+    b->lds = b->multi ? ba::mq_wg_bytes_h(kind, lds_class_cells(pc), b->wpw) : (b->small ? ba::sm_wg_bytes_h(kind, lds_class_cells(pc)) : ba::lds_wg_bytes_h(kind, lds_class_cells(pc)) + (trace ? (special_of(mode) ? ba::TB_LDS_BYTES_LOC : ba::TB_LDS_BYTES) : 0u));   // (the special modes' walk records also hold zero-mask bits)
     if (b->lds > 160 * 1024) { fail("block size %zu needs %u bytes of LDS per workgroup", max_size, b->lds); return 1; }
     if (b->lds > 64 * 1024) {
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (b->multi_b == 256 ? g_occ_m256[pc] : special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (b->geom ? g_occ_mg[b->geom - 2][pc] : b->multi_b == 256 ? g_occ_m256[pc] : special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
-    if (per_cu * ba::WAVES_PER_WG > 32) per_cu = 32 / ba::WAVES_PER_WG;
+    if (per_cu * b->wpw > 32) per_cu = 32 / b->wpw;
+    if (b->geom && per_cu > (int)b->geom) per_cu = (int)b->geom;   // (a score-only instantiation needs fewer registers than its geometry allows: still that many waves per SIMD)
     if (const char* env = dev_env("BA_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = v; }
     uint64_t grid = (uint64_t)prop.multiProcessorCount * per_cu;
-    const uint64_t per_wg = (uint64_t)ba::WAVES_PER_WG * (b->small ? ba::SM_SLOTS : 1u);
+    // (k_multi, score-only batches, round 6: no more waves than the batch fills with four pairs each -- a wave that finds fewer goes through them one
+    // at a time, solo. 10 kbp pairs, two waves per SIMD: 8 k pairs 16.4 -> 12.1 ms, 7 k 18.3 -> 16.1; three: 11 k 20.0 -> 18.2. With traceback the spare
+    // waves are the ones that walk: 8 k 23.9 -> 25.2 ms, 11 k 27.9 -> 28.1 -- not cut.)
+    const uint64_t per_wg = (uint64_t)b->wpw * (b->small ? ba::SM_SLOTS : ((b->multi && b->geom && !trace) ? 512u / b->multi_b : 1u));   // (the eight-wave workgroups: 16 k pairs 22.9 -> 24.2 ms, not cut)
     const uint64_t need = (n + per_wg - 1) / per_wg;
     if (grid > need) grid = need;
     if (const char* env = dev_env("BA_GRID")) { int v = atoi(env); if (v > 0 && (uint64_t)v < grid) grid = (uint64_t)v; }   // (development: fewer workgroups)
@@ -653,10 +670,10 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         const uint64_t fixed = fixed_bytes + (1ull << 30);
         const uint64_t budget = free_b * 9 / 10 > fixed ? free_b * 9 / 10 - fixed : 0;
         const uint64_t max_waves = per_slot ? budget / per_slot : ~0ull;
-        if (max_waves < ba::WAVES_PER_WG) { fail("device memory: one workgroup's trace slots need %llu MB, %llu MB are free", (unsigned long long)(per_slot * ba::WAVES_PER_WG >> 20), (unsigned long long)(budget >> 20)); return 1; }
-        if (grid * ba::WAVES_PER_WG > max_waves) grid = max_waves / ba::WAVES_PER_WG;
+        if (max_waves < b->wpw) { fail("device memory: one workgroup's trace slots need %llu MB, %llu MB are free", (unsigned long long)(per_slot * b->wpw >> 20), (unsigned long long)(budget >> 20)); return 1; }
+        if (grid * b->wpw > max_waves) grid = max_waves / b->wpw;
     }
-    if (b->small) grid = std::min<uint64_t>(grid, 512ull * 32 / ba::WAVES_PER_WG);   // (the trace arena's sink area holds 512 x 32 waves: pipe_regions)
+    if (b->small) grid = std::min<uint64_t>(grid, 512ull * 32 / b->wpw);   // (the trace arena's sink area holds 512 x 32 waves: pipe_regions)
     b->grid = (uint32_t)grid;
     b->cq_grid = 0;
     if (b->quad) {   // the per-pair kernel beside k_quad: one workgroup per CU, so that k_quad always finds room next to it
@@ -666,12 +683,12 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // TRACE batches big enough to keep them busy get dedicated traceback waves (ba_driver.hpp traceback_consumer)
     // and several trace slots per fill wave, so a wave can start its next pair while earlier ones are being walked.
     b->tb_stride = 0; b->slots_per_wave = 1;
-    b->n_fill_waves = b->grid * ba::WAVES_PER_WG;
+    b->n_fill_waves = b->grid * b->wpw;
     // Short pairs: a walk is a few hundred dependent steps, cheaper done at once by the fill wave's lane 0 than handed to a
     // traceback lane (protein pairs of ~300 residues, block 32..256: 202 vs 99 GCUPS; 1 kbp DNA pairs already prefer the hand-off).
     const bool short_pairs = kind != BA_KIND_PROFILE_ && avg_len2 <= 1024 && !dev_env("BA_FORCE_TB");
     {   // several short pairs per work-counter atomic; long pairs one by one (a chunk of long pairs would lengthen the launch's ragged end)
-        const uint64_t waves = grid * ba::WAVES_PER_WG;
+        const uint64_t waves = grid * b->wpw;
         const uint64_t by_len = avg_len2 != ~0ull ? 16384 / (avg_len2 + 1) : 1, by_n = waves ? n / (waves * 8) : 1;
         b->work_chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, std::min(by_len, by_n)));
         if (b->small) b->work_chunk = 4;   // (sixteen slots refill one by one; pairs come longest first: a long chunk would queue the longest pairs on one wave)
@@ -686,7 +703,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     // (one pair per wave at most: in every block class; two: measured for the classes with large LDS regions only)
     uint64_t few_x = lds_class_cells(pc) >= 512 ? 2u : 1u;
     if (const char* env = dev_env("BA_FEW_PAIRS_X")) { int v = atoi(env); if (v >= 0) few_x = (uint64_t)v; }   // (development)
-    const bool few_pairs = !special_of(mode) && n <= few_x * (uint64_t)grid * ba::WAVES_PER_WG && !dev_env("BA_FORCE_TB");
+    const bool few_pairs = !special_of(mode) && n <= few_x * (uint64_t)grid * b->wpw && !dev_env("BA_FORCE_TB");
     if (trace && (b->grid >= 32 || (dev_env("BA_FORCE_TB") && b->grid >= 2)) && !short_pairs && !few_pairs && !b->pipe && !dev_env("BA_INLINE_TRACEBACK")) {
         // one traceback wave per 4 workgroups = per 31 fill waves: at config 3 one per 5 ties and one per 6 is
         // 3.5 % slower, so 4 leaves a margin for workloads with more traceback per filled cell. (Workgroup b runs on XCD
@@ -702,9 +719,12 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // 3 workgroups keeps up: 85 more fill waves. Same box, per 2 / 3 / 4 / 6: 100 k pairs 159.2 / 158.3 / 159.8 / 188.8 ms, 50 k 90.2 / 89.1 / 88.6 / 97.1,
         // 12.5 k 36.4 / 34.2 / 33.9 / 34.1. The special modes' walks are the round-5 ones: per 2 as before.)
         if (b->multi && b->grid >= 32 && !special_of(mode)) stride = 3;
+        // (the four-wave workgroups of round 6's geometries: the same share of the waves. 12 k pairs at three waves per SIMD, one per 4 / 6 / 8 workgroups:
+        // 33.3 / 29.0 / 30.3 ms; 8 k pairs at two: 3 / 4 / 6: 28.3 / 27.4 / 23.3)
+        if (b->multi && b->geom && b->grid >= 32) stride = 6;
         if (const char* env = dev_env("BA_TB_STRIDE")) { int v = atoi(env); if (v > 0) stride = (uint32_t)v; }
         b->tb_stride = stride;
-        b->n_fill_waves = b->grid * ba::WAVES_PER_WG - (b->grid + stride - 1) / stride;
+        b->n_fill_waves = b->grid * b->wpw - (b->grid + stride - 1) / stride;
         size_t free_b = 0, total_b = 0;
         mem_info(&free_b, &total_b);
         const uint64_t per_slot = b->trace_stride * 4 + b->blocks_stride * sizeof(BlockRec);
@@ -758,12 +778,12 @@ static int batch_alloc_scratch(BaBatch* b) {
 #define BA_ALLOC(buf, bytes) if (b->buf.alloc(bytes)) return 1
     BA_ALLOC(trace, b->pipe ? b->pipe_words * 4 : b->trace_stride * 4 * b->slots);
     BA_ALLOC(blocks, b->pipe ? b->pipe_recs * sizeof(BlockRec) : b->blocks_stride * sizeof(BlockRec) * b->slots);
-    BA_ALLOC(ckpt, (size_t)(b->grid + b->cq_grid) * ba::WAVES_PER_WG * 8 * b->max_size * sizeof(short));
-    BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * ba::WAVES_PER_WG * ba::big_wave_shorts(b->max_size) * sizeof(short)
-                                              : (b->multi ? (size_t)b->grid * ba::WAVES_PER_WG * ba::MQ_WAVE_BYTES : (b->small ? (size_t)b->grid * ba::WAVES_PER_WG * ba::SM_WAVE_BYTES : 0)));
+    BA_ALLOC(ckpt, (size_t)(b->grid + b->cq_grid) * b->wpw * 8 * b->max_size * sizeof(short));
+    BA_ALLOC(big, b->pclass == BA_PCLASS_BIG ? (size_t)b->grid * b->wpw * ba::big_wave_shorts(b->max_size) * sizeof(short)
+                                              : (b->multi ? (size_t)b->grid * b->wpw * ba::MQ_WAVE_BYTES : (b->small ? (size_t)b->grid * b->wpw * ba::SM_WAVE_BYTES : 0)));
     BA_ALLOC(tb_queue, (size_t)b->tb_qsize * 4); BA_ALLOC(tb_ctrl, 256); BA_ALLOC(prof, 2048); BA_ALLOC(params_dev, sizeof(BatchParams));
     BA_ALLOC(slot_free, (size_t)b->slots * 4); BA_ALLOC(slot_info, (size_t)b->slots * sizeof(ba::SlotInfo)); BA_ALLOC(counter, 128);
-    if (b->multi) BA_ALLOC(donate, ((size_t)b->grid * ba::WAVES_PER_WG + 64) * 4);   // (+ two counters in their own cache lines)
+    if (b->multi) BA_ALLOC(donate, ((size_t)b->grid * b->wpw + 64) * 4);   // (+ two counters in their own cache lines)
 #undef BA_ALLOC
     return 0;
 }
@@ -901,9 +921,38 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         wide = true; b->multi_b = 256;
         multi_fits = avg_len2 >= 6000 && n >= 2048;   // (13 kbp reads, 256..2048, with traceback, GCUPS two-pair slots / per-pair kernel, same box: 1.5 k pairs 353 / 410, 2.5 k 576 / 401, 4 k 990 / 552, 8 k 1155 / 603, 20 k 1555 / 654, 70 k 1873 / 720)
     }
+    // Round 6: the launch geometry of k_multi by the batch size. The kernel is bound by vector issue, so a round of the batch -- every slot of every resident
+    // wave filled once -- takes as long as a SIMD has waves; a batch of about one round is fastest on the geometry whose slots it just fills (four-wave
+    // workgroups, two / three of them per CU = 32 / 48 slots per CU; at three waves per SIMD the traced driver also spills 171 registers instead of 344), while
+    // batches of many rounds want four waves per SIMD (config 3's 100 k pairs: 157.5 ms against 168.7 at three). DNA, block classes 512 and 1024, plain modes.
+    // 10 kbp pairs at 128..1024, ms at four / three / two waves per SIMD / per-pair kernel, same box (tools/dev/geom_sweep.sh, geom_sweep2.sh) --
+    // with traceback: 6 k pairs 38.4 / 38.6 / 22.2 / 22.5, 8 k 40.9 / 27.0 / 23.3 / 28.6, 10 k 32.6 / 27.3 / 27.4 / 34.1, 12.5 k 33.3 / 30.4 / 32.0 / -, 14 k 34.7 / 32.2 / 34.4,
+    // 16 k 35.4 / 34.2 / 36.7, 20 k 41.6 / 42.2, 25 k 48.7 / 53.1; score only: 8 k 18.2 / 22.5 / 16.4 / 15.0, 10 k 22.6 / 22.7 / 18.3 / 19.5, 12 k 27.5 / 18.1 / 23.7 / 22.1,
+    // 14 k 24.1 / 19.1, 16 k 22.9 / 26.0, 20 k 26.6 / 30.0.
+    b->geom = 0; b->wpw = ba::WAVES_PER_WG;
+    const bool geom_ok = !wide && kind == BA_KIND_NUC && !special_of(mode) && (pc == 2 || pc == 3) && min_size == ba::MQ_B_HOST;   // (the instantiations that exist: ba_kernels.hip)
+    if (geom_ok && avg_len2 >= 3000) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
+        const uint64_t s2 = 32ull * (uint64_t)cus, s3 = 48ull * (uint64_t)cus;   // slots of the two geometries
+        // (where the geometries change over, tools/dev/geom_edges.sh -- with traceback, two / three waves per SIMD: 8.4 k pairs 25.6 / 27.5 ms, 9 k 26.4 / 27.0, 9.5 k 27.1 / 27.1;
+        // three / four: 16 k 34.0 / 35.4, 17.5 k 40.1 / 39.7, 19 k 40.9 / 40.2; two / per-pair kernel: 5.5 k 20.4 / 22.3, 5 k - / 19.2. Score only (with the
+        // workgroups cut to the batch, batch_plan; geom_edges3.sh): two / per-pair 7 k 16.1 / 14.1, 7.6 k 12.0 / 15.0, 9 k 13.5 / 17.2; two / three 9.2 k 13.4 / 17.8,
+        // 9.5 k 18.3 / 17.7, 10.5 k 19.1 / 17.9; three / four 15 k 20.5 / 22.8, 15.5 k 26.0 / 23.0 -- steps, not slopes: a wave whose slots cannot all be refilled
+        // finishes its pairs one at a time)
+        if (trace_mode) {
+            b->geom = n <= s2 * 115 / 100 ? 2u : (n <= s3 * 136 / 100 ? 3u : 0u);
+            multi_fits = n >= s2 * 65 / 100;
+        } else {
+            b->geom = n <= s2 * 113 / 100 ? 2u : (n <= s3 * 124 / 100 ? 3u : 0u);
+            multi_fits = n >= s2 * 92 / 100;
+        }
+    }
+    if (const char* env = dev_env("BA_MQ_GEOM")) { const int v = atoi(env); b->geom = (geom_ok && (v == 2 || v == 3)) ? (uint32_t)v : 0u; }   // (development / tests: 0 = the eight-wave workgroups)
     b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && (min_size == ba::MQ_B_HOST || wide) && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || multi_fits);
-    if (!b->multi) b->multi_b = 128;
-    if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->multi = false;
+    if (!b->multi) { b->multi_b = 128; b->geom = 0; }
+    if (b->geom) b->wpw = (uint32_t)ba::MQ_GEOM_WPW;
+    if (b->multi && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) { b->multi = false; b->geom = 0; b->wpw = ba::WAVES_PER_WG; }
     if (b->small && batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) b->small = false;   // (e.g. LDS: falls back to the per-pair kernel)
     if (!b->multi && !b->small)
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
@@ -1092,12 +1141,12 @@ static int batch_launch(BaBatch* b) {
         HIP_TRY(hipMemsetAsync(b->prof.p, 0, 2048, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_queue.p, 0, (size_t)b->tb_qsize * 4, b->stream));
         HIP_TRY(hipMemsetAsync(b->slot_free.p, 1, (size_t)b->slots * 4, b->stream));   // any non-zero value = free
-        if (b->multi && b->donate.p) HIP_TRY(hipMemsetAsync(b->donate.p, 0, ((size_t)b->grid * ba::WAVES_PER_WG + 64) * 4, b->stream));
+        if (b->multi && b->donate.p) HIP_TRY(hipMemsetAsync(b->donate.p, 0, ((size_t)b->grid * b->wpw + 64) * 4, b->stream));
     }
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->ev_l0) HIP_TRY(hipEventRecord(b->ev_l0, b->stream));   // (a re-run sub-batch: batch_retry re-uses ev0 for the merge)
-    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (b->multi_b == 256 ? g_launch_m256[b->pclass] : special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (b->geom ? g_launch_mg[b->geom - 2][b->pclass] : b->multi_b == 256 ? g_launch_m256[b->pclass] : special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
     if (b->quad && b->n <= b->cap_n) {
         // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
         // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a
@@ -1515,7 +1564,7 @@ int ba_batch_prof(BaBatch* b, uint64_t out[128]) {   // development: phase timer
 }
 int ba_batch_info(BaBatch* b, uint64_t out[4]) {
     if (!b) return fail("null batch");
-    out[0] = (uint64_t)b->grid * ba::WAVES_PER_WG; out[1] = b->lds / ba::WAVES_PER_WG; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
+    out[0] = (uint64_t)b->grid * b->wpw; out[1] = b->lds / b->wpw; out[2] = b->trace.bytes; out[3] = b->pool_bytes;
     return 0;
 }
 // Cells of the speculative, untraced rectangles of the last run (X-drop + TRACE batches: the chain of grows that closes an alignment,
@@ -1529,6 +1578,7 @@ int ba_batch_spec_cells(BaBatch* b, uint64_t* cells) {
     return 0;
 }
 int ba_batch_kernel(BaBatch* b) { return !b ? -1 : (b->small ? 3 : (b->quad ? 2 : (b->multi ? 1 : 0))); }
+int ba_batch_geometry(BaBatch* b) { return !b ? -1 : (int)b->geom; }
 int ba_batch_retried(BaBatch* b) { return b ? (int)b->retried : -1; }
 void ba_batch_destroy(BaBatch* b) { delete b; }
 

@@ -114,6 +114,38 @@ extern "C" hipError_t BA_CAT(ba_occupancy_m256_k, BA_KIND, _p, BA_PMAX)(int trac
     return xdrop ? occ_multi256<false, true>(blocks_per_cu, lds) : occ_multi256<false, false>(blocks_per_cu, lds);
 }
 #endif
+#if BA_KIND == 1 && (BA_PMAX == 4 || BA_PMAX == 8)
+// ... in workgroups of four waves at three / two waves per SIMD (round 6: DNA batches whose pairs fill that many waves' slots about once -- ba_host.cpp batch_build)
+template <bool TRACE, bool XDROP, int EU>
+static hipError_t launch_multi_g(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 128, ba::MQ_GEOM_WPW, EU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 128, ba::MQ_GEOM_WPW, EU><<<dim3(grid), dim3(ba::MQ_GEOM_WPW * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP, int EU>
+static hipError_t occ_multi_g(int* blocks_per_cu, unsigned lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 128, ba::MQ_GEOM_WPW, EU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 128, ba::MQ_GEOM_WPW, EU>, ba::MQ_GEOM_WPW * 64, lds);
+}
+#define BA_MULTI_GEOM(EU)                                                                                                                                              \
+    extern "C" hipError_t BA_CAT(ba_launch_mg##EU##_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) { \
+        if (trace) return xdrop ? launch_multi_g<true, true, EU>(grid, lds, s, *bp) : launch_multi_g<true, false, EU>(grid, lds, s, *bp);                              \
+        return xdrop ? launch_multi_g<false, true, EU>(grid, lds, s, *bp) : launch_multi_g<false, false, EU>(grid, lds, s, *bp);                                       \
+    }                                                                                                                                                                  \
+    extern "C" hipError_t BA_CAT(ba_occupancy_mg##EU##_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {                               \
+        if (trace) return xdrop ? occ_multi_g<true, true, EU>(blocks_per_cu, lds) : occ_multi_g<true, false, EU>(blocks_per_cu, lds);                                  \
+        return xdrop ? occ_multi_g<false, true, EU>(blocks_per_cu, lds) : occ_multi_g<false, false, EU>(blocks_per_cu, lds);                                           \
+    }
+BA_MULTI_GEOM(3)
+BA_MULTI_GEOM(2)
+#undef BA_MULTI_GEOM
+#endif
 #endif
 
 #if !BA_SPECIAL && !BA_BIG && BA_PMAX <= 8

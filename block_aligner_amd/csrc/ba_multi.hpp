@@ -246,11 +246,14 @@ enum { MR_PAIR = 0, MR_BEST_I, MR_BEST_J, MR_CELLS_LO, MR_CELLS_HI, MR_BUDGET, M
        MR_BEST_MAX, MR_Y_DROP, MR_X_ITER, MR_D_CORNER, MR_NSTEPS, MR_TRACE_TOP, MR_NBLOCKS, MR_SEL, MR_WORDS };
 __device__ __forceinline__ int mq_load(const char* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }   // past the L1: the wave reads back its own stores
 
-template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0, int MBP = 128>
 #ifndef MQ_WAVES_EU
 #define MQ_WAVES_EU 4   // (waves per SIMD the kernel is compiled for. Tried, round 5: 2 = 256 registers, no spills -- config 3 163.6 -> 205.1 ms, 25 k pairs 55.6 -> 64.1: two waves do not fill the vector unit)
 #endif
-__global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_EU)) k_multi(const BatchParams bp) {
+// WPW / EU (round 6): waves per workgroup and waves per SIMD the instantiation is compiled and launched for. The batch geometry is the host's choice
+// (ba_host.cpp batch_build): eight-wave workgroups at four waves per SIMD for batches of many rounds; four-wave workgroups -- one wave per SIMD,
+// EU of them per CU -- at three or two waves per SIMD (168 / 256 registers) for batches whose pairs fill the slots of that many waves about once.
+template <int PMAX, int KIND, bool TRACE, bool XDROP, int SPM = 0, int MBP = 128, int WPW = WAVES_PER_WG, int EU = MQ_WAVES_EU>
+__global__ void __launch_bounds__(WPW * 64, (PMAX >= 16 ? 2 : EU)) k_multi(const BatchParams bp) {
     // a slot rectangle's words on the trace stack (LOCAL_START: the zero mask takes 32 words behind the 128 trace words; the stack advances as the
     // per-pair kernel's does -- a mask word per trace word, Aligner::add_block); the walkers' records and mode bits (the special modes: room for the
     // zero-mask bits, the early stops of scan_block.rs:1597-1611)
@@ -271,10 +274,10 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
     {   // workgroup-shared scoring table, as in k_align
         char* tab = smem;
         if (KIND == KIND_NUC) {
-            nuc_table_fill(tab, bp.matrix, (int)threadIdx.x, WAVES_PER_WG * 64);   // (layout: ba_device.hpp nuc_key_off)
+            nuc_table_fill(tab, bp.matrix, (int)threadIdx.x, WPW * 64);   // (layout: ba_device.hpp nuc_key_off)
         } else {
             const int nbytes = KIND == KIND_AA ? 27 * 32 : 2;
-            for (int k = (int)threadIdx.x; k < nbytes; k += WAVES_PER_WG * 64) tab[k] = (char)bp.matrix[k];
+            for (int k = (int)threadIdx.x; k < nbytes; k += WPW * 64) tab[k] = (char)bp.matrix[k];
         }
     }
     __syncthreads();
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
         return;
     }
     const uint32_t cons_before = batch_traceback ? (blockIdx.x + stride - 1) / stride + (blockIdx.x % stride == 0 ? 1u : 0u) : 0u;
-    const uint32_t fill_wave = blockIdx.x * WAVES_PER_WG + (uint32_t)wave - cons_before;
+    const uint32_t fill_wave = blockIdx.x * WPW + (uint32_t)wave - cons_before;
     const uint32_t max_size = bp.max_size;
     const bool keep_pre = XDROP || MB < max_size;   // a slot keeps the state before its last improving step
     char* const wave_mem = (char*)bp.big + (uint64_t)fill_wave * MQ_WAVE_BYTES;
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
     // (values derived again after the per-pair driver instead of being kept across it: laundered so that they are not hoisted)
     auto coldp_big = [&]() { const __attribute__((address_space(4))) BatchParams* p = (const __attribute__((address_space(4))) BatchParams*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return p->big; };
     auto fill_wave_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); const uint32_t st = ((const __attribute__((address_space(4))) BatchParams*)__builtin_amdgcn_kernarg_segment_ptr())->tb_stride;
-                                const uint32_t cb = (TRACE && st > 0) ? (b + st - 1) / st + (b % st == 0 ? 1u : 0u) : 0u; return b * WAVES_PER_WG + w - cb; };
+                                const uint32_t cb = (TRACE && st > 0) ? (b + st - 1) / st + (b % st == 0 ? 1u : 0u) : 0u; return b * WPW + w - cb; };
     uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
     uint32_t w_next = 0, w_end = 0;
     bool more = true, drain = false;
@@ -321,11 +324,11 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
     // state in the arena is a complete resumable record). `don` (bits 8 / 9 of the wave's own word): bit 0 this wave has been counted in mq_donate[waves] (it will offer nothing
     // more), bit 1 its word holds offers; donor_id: the wave whose slot `solo` is (a slot taken over), else this wave.
     // (neither is kept in a register across the loop of steps: the id is derived again, the bits live in the wave's own word, bits 8 / 9)
-#define don_final (bp.mq_donate + gridDim.x * WAVES_PER_WG)   /* fill waves that will offer nothing more */
+#define don_final (bp.mq_donate + gridDim.x * WPW)   /* fill waves that will offer nothing more */
 #define don_offers (don_final + 32)                            /* (its own cache line) offers outstanding */
-    // a slot's memory in the arena: `id` = blockIdx * 8 + wave of the wave that owns it
+    // a slot's memory in the arena: `id` = blockIdx * WPW + wave of the wave that owns it
     auto slot_mem_of = [&](uint32_t id, uint32_t s_i) {
-        const uint32_t db = id / WAVES_PER_WG;
+        const uint32_t db = id / WPW;
         const uint32_t dcb = batch_traceback ? (db + stride - 1) / stride + (db % stride == 0 ? 1u : 0u) : 0u;
         return (char*)bp.big + (uint64_t)(id - dcb) * MQ_WAVE_BYTES + s_i * SLOTA;
     };
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
         uint32_t avail = 0;
         if (is_lane(0)) avail = __hip_atomic_load(don_offers, BA_RLX_AGENT);
         if ((int)uni((int)avail) <= 0) return false;
-        const uint32_t n_ids = gridDim.x * WAVES_PER_WG;
+        const uint32_t n_ids = gridDim.x * WPW;
         for (uint32_t k0 = 0; k0 < n_ids; k0 += 64) {
             const uint32_t idx = ((my_id & ~63u) + k0 + (uint32_t)lane) % n_ids;   // (every word at least once, starting near this wave's own; the number of waves need not be a multiple of 64)
             const uint32_t v = __hip_atomic_load(bp.mq_donate + idx, BA_RLX_AGENT) & ALLM;
@@ -369,7 +372,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
         live_m |= 1u << e;
         return true;
     };
-    auto my_id_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); return b * WAVES_PER_WG + w; };
+    auto my_id_of = [&]() { uint32_t b = blockIdx.x, w = (uint32_t)wave; asm volatile("" : "+s"(b), "+s"(w)); return b * WPW + w; };
 
     for (;;) {
         // ================= solo mode: one pair at a time on all 64 lanes, the slots' state in memory. Whose turn? a slot whose step
@@ -428,7 +431,7 @@ __global__ void __launch_bounds__(WAVES_PER_WG * 64, (PMAX >= 16 ? 2 : MQ_WAVES_
                 // nothing left here: take over a slot that another wave offers and run it solo to its end; leave when no wave can offer any more
                 const uint32_t my_id = my_id_of();
                 if (is_lane(0) && !(__hip_atomic_fetch_or(bp.mq_donate + my_id, 0x100u, BA_RLX_AGENT) & 0x100u)) __hip_atomic_fetch_add(don_final, 1u, BA_RLX_AGENT);
-                const uint32_t n_fill = gridDim.x * WAVES_PER_WG - (batch_traceback ? (gridDim.x + stride - 1) / stride : 0u);
+                const uint32_t n_fill = gridDim.x * WPW - (batch_traceback ? (gridDim.x + stride - 1) / stride : 0u);
                 bool got = false;
                 uint32_t nap = 1;
                 for (;;) {

@@ -134,6 +134,7 @@ constexpr uint32_t SM_LDS_SCALARS = 8192, SM_LDS_BYTES = 8192 + SM_SLOTS * 2 * 3
 #define BA_WAVES_PER_WG 8   // (development: a kernel object built with 6 runs three waves per SIMD under a host built with 8 -- the arenas are only larger than needed)
 #endif
 constexpr int WAVES_PER_WG = BA_WAVES_PER_WG;   // independent waves per workgroup; they share the read-only score table in LDS
+constexpr int MQ_GEOM_WPW = 4;   // k_multi's geometries of three / two waves per SIMD (round 6): workgroups of one wave per SIMD, three / two of them per CU
 
 // LDS layout: [score table (per workgroup)] [wave 0: 4 borders + misc] [wave 1: ...] ...
 BA_HD constexpr uint32_t lds_array_bytes_h(uint32_t max_size) { return max_size * 2 + 32; }
@@ -141,7 +142,7 @@ BA_HD constexpr uint32_t lds_wave_bytes_h(uint32_t max_size) { return 4 * lds_ar
 BA_HD constexpr uint32_t lds_table_bytes_h(int kind) { return kind == KIND_NUC ? 8192 : 896; }
 BA_HD constexpr uint32_t lds_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * lds_wave_bytes_h(max_size); }
 BA_HD constexpr uint32_t mq_wave_bytes_h(uint32_t max_size) { return lds_wave_bytes_h(max_size) > MQ_LDS_BYTES ? lds_wave_bytes_h(max_size) : MQ_LDS_BYTES; }   // k_multi
-BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size) { return lds_table_bytes_h(kind) + WAVES_PER_WG * mq_wave_bytes_h(max_size); }
+BA_HD constexpr uint32_t mq_wg_bytes_h(int kind, uint32_t max_size, uint32_t wpw = WAVES_PER_WG) { return lds_table_bytes_h(kind) + wpw * mq_wave_bytes_h(max_size); }
 constexpr uint32_t SM_PROF_STAGE = 16 * 256;   // k_small, profile batches: per wave, 8 rows x 32 bytes of pos_aa per slot (the columns of a right step; behind the wave's region)
 BA_HD constexpr uint32_t sm_wave_bytes_h(uint32_t max_size, int kind = 0) {   // k_small
     return (lds_wave_bytes_h(max_size) > SM_LDS_BYTES ? lds_wave_bytes_h(max_size) : SM_LDS_BYTES) + (kind == KIND_PROFILE ? SM_PROF_STAGE : 0u);

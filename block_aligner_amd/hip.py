@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
         L.ba_device_memory.argtypes = [vp, vp]
         L.ba_batch_info.argtypes = [vp, vp]
         L.ba_batch_kernel.argtypes = [vp]
+        L.ba_batch_geometry.argtypes = [vp]
         L.ba_batch_spec_cells.argtypes = [vp, vp]
         L.ba_build_id.restype = C.c_char_p
         L.ba_batch_destroy.argtypes = [vp]
@@ -494,7 +495,7 @@ class BatchAligner:
         o = np.zeros(4, np.uint64)
         lib().ba_batch_info(self._h, o.ctypes.data)
         return dict(grid=int(o[0]), lds_bytes_per_wave=int(o[1]), trace_arena_bytes=int(o[2]), pool_bytes=int(o[3]),
-                    kernel=self.KERNELS[lib().ba_batch_kernel(self._h)])
+                    kernel=self.KERNELS[lib().ba_batch_kernel(self._h)], geometry=lib().ba_batch_geometry(self._h))
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:

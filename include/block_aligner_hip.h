@@ -251,6 +251,9 @@ int ba_batch_info(BaBatch* batch, uint64_t out[4]);
 /* Which fill kernel the batch's launches use: 0 the per-pair kernel (k_align), 1 four pairs per wave at 128 cells (k_multi), 2 the round-2/3
  * small-block pipeline (k_quad + queue; profile batches), 3 sixteen pairs per wave at 32 cells (k_small). -1 for a null batch. */
 int ba_batch_kernel(BaBatch* batch);
+/* k_multi batches: the launch geometry chosen for the batch size -- 0: eight-wave workgroups at four waves per SIMD (batches of many rounds); 3 / 2: four-wave
+ * workgroups at three / two waves per SIMD (DNA, block classes 512 and 1024: batches whose pairs fill that many waves' slots about once). -1 for a null batch. */
+int ba_batch_geometry(BaBatch* batch);
 /* X-drop + BA_TRACE batches: cells of the last run's speculative, untraced rectangles (the chain of grows that closes an X-drop alignment
  * can lie on no path: filled without trace flags and location bookkeeping) -- a part of the computed cells that needed 14 instead of 20
  * int16 operations per cell (bench.py: roofline.ops_required). */

@@ -181,3 +181,41 @@ def test_multi256_release_library_takes_it_from_the_threshold(hip, oracle):
     assert b.info()["kernel"] == "k_multi", b.info()
     b.close()
     compare(hip, oracle, pairs, NUC, (-5, -1), (256, 512), 100, ("trace", "x_drop"))
+
+
+# ---- round 6: k_multi's launch geometries (four-wave workgroups at three / two waves per SIMD: batches of about one round -- ba_host.cpp batch_build)
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("geom", [2, 3])
+@pytest.mark.parametrize("size", [(128, 512), (128, 1024)])
+def test_multi_geometries(hip, oracle, force_multi, monkeypatch, mode, geom, size):
+    """The same kernel compiled for 256 / 168 registers in workgroups of four waves: indels force grows, restores and shrinks, so pairs change
+    between slot and solo mode many times (the solo driver is what the register budget changes)."""
+    monkeypatch.setenv("BA_MQ_GEOM", str(geom))
+    pairs = synth.make_pairs(150, (800, 3000), (50, 300), 100, synth.DNA, seed=1900 + size[1] + geom, indels=3, indel_len=(20, 200))
+    b = hip.BatchAligner(NUC, (-5, -1), size, 100, 0, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi" and b.info()["geometry"] == geom, b.info()
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, mode)
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",)])
+@pytest.mark.parametrize("geom,n,wgs", [(2, 700, "1"), (3, 2500, "1"), (3, 6000, "3"), (2, 6000, "2")])
+def test_multi_geometries_with_traceback_waves(hip, oracle, force_multi, monkeypatch, geom, n, wgs, mode):
+    """... with the in-launch hand-off to traceback waves (one per six workgroups), recycled trace slots, and slots changing waves at the end of the batch."""
+    monkeypatch.setenv("BA_MQ_GEOM", str(geom))
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", wgs)
+    pairs = synth.make_pairs(n, (1500, 6000), (100, 600), 300, synth.DNA, seed=177 + n + geom, indels=1, indel_len=(20, 200))
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, mode, threads=16)
+
+
+@pytest.mark.parametrize("n,geom", [(6400, 2), (9000, 3)])
+def test_multi_geometry_release_library_by_batch_size(hip, oracle, n, geom):
+    """No development switch: the release library picks the geometry whose slots the batch fills about once (MI355X: 8192 slots at two waves per SIMD,
+    12288 at three), and every pair still matches the oracle."""
+    pairs = synth.make_pairs(n, (1500, 1700), (100, 170), 60, synth.DNA, seed=4000 + n, workers=8)
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 100, hip.TRACE | hip.X_DROP | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    info = b.info()
+    b.close()
+    assert info["kernel"] == "k_multi" and info["geometry"] == geom and info["grid"] == 1024 * geom, info
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, ("trace", "x_drop"), threads=16)
