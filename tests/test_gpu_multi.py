@@ -209,7 +209,7 @@ def test_multi_geometries_with_traceback_waves(hip, oracle, force_multi, monkeyp
     compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, mode, threads=16)
 
 
-@pytest.mark.parametrize("n,geom", [(6400, 2), (9000, 3)])
+@pytest.mark.parametrize("n,geom", [(6400, 2), (9800, 3)])
 def test_multi_geometry_release_library_by_batch_size(hip, oracle, n, geom):
     """No development switch: the release library picks the geometry whose slots the batch fills about once (MI355X: 8192 slots at two waves per SIMD,
     12288 at three), and every pair still matches the oracle."""

@@ -6,6 +6,8 @@ from block_aligner_amd import hip as H, scores as S, synth
 from oracle.oracle_py import Oracle
 from tests.test_gpu_pipelines import run_and_compare
 o = Oracle("avx2")
+if os.environ.get("STRESS_GEOM"):   # the development library reads BA_MQ_GEOM / BA_FORCE_MULTI
+    H.use_library(H.DEV_LIB_PATH); os.environ["BA_FORCE_MULTI"] = "1"
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = 0
@@ -45,7 +47,13 @@ for seed in range(seed0, seed0 + count):
         alpha, matrix, kind = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))), 0
         mode = tuple(m for m in mode if m in ("trace", "x_drop"))
         pairs = synth.make_pairs(5000, (2 * lo_len + 3000, 2 * hi_len + 4000), (2 * edits[0], 3 * edits[1]), tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 300), workers=8)
-    what = (seed, kind, (lo, hi), (opn, ext), x_drop, mode)
+    if os.environ.get("STRESS_GEOM"):   # round 6: k_multi in four-wave workgroups at two / three waves per SIMD (DNA, the plain modes, 128..512 / 1024), ~8 k pairs
+        hi = 512 << int(rng.integers(0, 2))
+        alpha, matrix, kind = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))), 0
+        mode = tuple(m for m in mode if m in ("trace", "x_drop"))
+        os.environ["BA_MQ_GEOM"] = str(2 + seed % 2)
+        pairs = synth.make_pairs(int(rng.integers(3000, 9000)), (lo_len + 1000, hi_len + 2000), (edits[0], 2 * edits[1]), tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 200), workers=8)
+    what = (seed, kind, (lo, hi), (opn, ext), x_drop, mode) + ((("geom", os.environ["BA_MQ_GEOM"]),) if os.environ.get("STRESS_GEOM") else ())
     try:
         run_and_compare(H, o, pairs, matrix, (opn, ext), (lo, hi), x_drop if "x_drop" in mode else 0, mode, kind == 0, what)
         print("ok", what, flush=True)
