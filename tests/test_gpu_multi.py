@@ -209,13 +209,15 @@ def test_multi_geometries_with_traceback_waves(hip, oracle, force_multi, monkeyp
     compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, mode, threads=16)
 
 
-@pytest.mark.parametrize("n,geom", [(6400, 2), (9800, 3)])
-def test_multi_geometry_release_library_by_batch_size(hip, oracle, n, geom):
+@pytest.mark.parametrize("n,geom,mode", [(6400, 2, ("trace", "x_drop")), (9800, 3, ("trace", "x_drop")), (8000, 2, ("x_drop",)), (11000, 3, ("x_drop",)), (11000, 3, ())])
+def test_multi_geometry_release_library_by_batch_size(hip, oracle, n, geom, mode):
     """No development switch: the release library picks the geometry whose slots the batch fills about once (MI355X: 8192 slots at two waves per SIMD,
-    12288 at three), and every pair still matches the oracle."""
+    12288 at three; score-only batches: no more workgroups than the batch fills with four pairs per wave), and every pair still matches the oracle."""
     pairs = synth.make_pairs(n, (1500, 1700), (100, 170), 60, synth.DNA, seed=4000 + n, workers=8)
-    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 100, hip.TRACE | hip.X_DROP | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    bits = (hip.TRACE | hip.CIGAR_EQ if "trace" in mode else 0) | (hip.X_DROP if "x_drop" in mode else 0)
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 512), 100, bits, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
     info = b.info()
     b.close()
-    assert info["kernel"] == "k_multi" and info["geometry"] == geom and info["grid"] == 1024 * geom, info
-    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, ("trace", "x_drop"), threads=16)
+    waves = 1024 * geom if "trace" in mode else min(1024 * geom, 4 * ((n + 15) // 16))
+    assert info["kernel"] == "k_multi" and info["geometry"] == geom and info["grid"] == waves, info
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, mode, threads=16)
