@@ -1594,7 +1594,11 @@ struct Aligner {
         FqeOut fq{0, 0};
         // scratch reset (scan_block.rs:1322-1339): borders to MIN = 0. The checkpoint copies need no reset: they are
         // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
-        if (!MULTI || mmode != MM_RESUME) { lds_fill0(L.D_col, max_size); lds_fill0(L.C_col, max_size); lds_fill0(L.D_row, max_size); lds_fill0(L.R_row, max_size); }
+        // (round 6: a launch of the 2048-cell class may carry pairs whose block range ends above it -- the host's bet that few of them grow that far,
+        // ba_host.cpp batch_build; CLASS_CAP: what this kernel's border arrays hold)
+        constexpr uint32_t CLASS_CAP = kBig ? 32768u : (uint32_t)PMAX * 128u;
+        const uint32_t fill_n = max_size < CLASS_CAP ? max_size : CLASS_CAP;
+        if (!MULTI || mmode != MM_RESUME) { lds_fill0(L.D_col, fill_n); lds_fill0(L.C_col, fill_n); lds_fill0(L.D_row, fill_n); lds_fill0(L.R_row, fill_n); }
         short* temp1 = L.misc + 16; short* temp2 = L.misc + 32;
         lds_fill0(temp1, 32);
 
@@ -1941,6 +1945,7 @@ struct Aligner {
 
             const uint32_t next_size = block_size * 2;
             if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
+                if (!kBig && next_size > CLASS_CAP) { status |= ST_CLASS_OVERFLOW; break; }   // (the pair is run again in the row-tiled class: nothing of this run is kept)
                 // (X-drop only: a global alignment's path starts at its end cell, so every chain of untraced grows would be rolled back at the
                 // end of the matrix at the latest -- the protein set's growers did all their large-block work twice)
                 if (TRACE && XDROP && KIND != KIND_PROFILE && !SPECIAL && !kBig && !chain && !no_spec && !(h_flags & 0x400u)) {

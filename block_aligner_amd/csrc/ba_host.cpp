@@ -294,6 +294,9 @@ struct BaBatch {
     uint64_t trace_stride = 0, blocks_stride = 0, cig_total = 0, pool_bytes = 0;
     uint64_t trace_full = 0;    // trace words per slot by the reference's worst-case bound (Trace::new)
     bool adaptive = false;      // trace_stride < trace_full: pairs that overflow their slot are re-run by batch_wait
+    bool opt_class = false;     // round 6: max_size belongs to the row-tiled class, the launch is the 2048-cell class's; pairs whose block wants past 2048 cells are re-run by batch_wait
+    bool bet_lost = false;      // ... and the last run re-ran more than an eighth of its pairs: the next launch is the row-tiled class's (batch_drop_class_bet)
+    uint64_t plan_fixed = 0, plan_maxlen2 = 0, plan_avg = 0;   // batch_plan's arguments, for that second plan
     uint32_t retried = 0;       // pairs the last run had to re-run with full-size slots
     uint64_t cap_n = 0, cap_pool = 0, cap_cig = 0, cap_maxlen2 = 0;   // what the device buffers were sized for (ba_batch_reload)
     DevBuf pool, q_off, q_len, r_off, r_len, matrix, score, qidx, ridx, cig_ops, cig_off, cig_len, cells, status, nblocks, pair_slot, trace_words, trace, blocks, ckpt, big, counter,
@@ -833,13 +836,23 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (min_size > max_size) { fail("min block size exceeds max block size"); return nullptr; }
     if (profile && (mode & BA_CIGAR_EQ)) { fail("=/X CIGARs need two sequences; a profile alignment has none to compare"); return nullptr; }
     if (kind == BA_KIND_BYTES && (mode & BA_X_DROP)) { /* allowed by the reference, documented as inaccurate (scores.rs:235-239) */ }
-    const int pc = pclass_of(max_size);
+    int pc = pclass_of(max_size);
     if (pc < 0) { fail("max block size %zu not supported by the HIP backend (16..%zu)", max_size, (size_t)BA_MAX_BLOCK); return nullptr; }
     if (n == 0 || n > 0x7fffffffu) { fail("batch must hold between 1 and 2^31-1 pairs"); return nullptr; }
+    // Round 6: block ranges that end above 2048 cells but start well below (percent_len 1 % .. 10 % of a 20 .. 40 kbp read: 256 / 512 .. 4096). The
+    // row-tiled class keeps a pair's borders in global memory and has neither the eight-cells-per-lane rectangles nor the untraced end-game grows --
+    // and such a pair's block rarely passes 2048 cells. The batch is launched in the 2048-cell class (LDS borders, every fast path) with its own maximum;
+    // a pair whose block wants to grow past 2048 cells stops with ST_CLASS_OVERFLOW and batch_wait runs it again in the row-tiled class (batch_retry).
+    // 2500 pairs of 32 kbp at 512..4096, none of which passes 2048 cells, same box: 192.9 -> 140.1 ms with traceback, 132.5 -> 81.8 score only
+    // (tools/dev/big_probe.sh).
+    bool opt_class = false;
+    // (from 128 cells: the small-block pipelines are not in the bet. A batch that loses the bet -- more than an eighth of its pairs re-run -- is launched
+    // in the row-tiled class from its next run on: batch_drop_class_bet.)
+    if (pc == BA_PCLASS_BIG && min_size >= 128 && min_size <= 1024 && !dev_env("BA_NO_OPT_CLASS")) { pc = 4; opt_class = true; }
 
     std::unique_ptr<BaBatch> b(new BaBatch);
     b->device = g_device; b->kind = kind; b->mode = mode; b->n = (uint32_t)n;
-    b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc;
+    b->min_size = (uint32_t)min_size; b->max_size = (uint32_t)max_size; b->pclass = (uint32_t)pc; b->opt_class = opt_class;
     b->gap_open = gaps.open; b->gap_extend = gaps.extend; b->x_drop = x_drop;
 
     Packed P;
@@ -957,6 +970,7 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     if (!b->multi && !b->small)
     if (batch_plan(b.get(), n, total + cig_total * 4 + (uint64_t)n * 64, maxlen2, false, sum_len2 / n)) return nullptr;
     if (b->pipe) b->adaptive = true;
+    b->plan_fixed = total + cig_total * 4 + (uint64_t)n * 64; b->plan_maxlen2 = maxlen2; b->plan_avg = sum_len2 / n;
     plan_exclusive(b.get(), ql, rl);
     b->cig_total = trace ? cig_total : 0;
 
@@ -1130,11 +1144,20 @@ static uint32_t walk_grid(const BaBatch* b) {   // workgroups of k_walk (4 waves
     if (const char* env = dev_env("BA_WALK_WGS_PER_CU")) { int v = atoi(env); if (v > 0) per_cu = (uint32_t)v; }
     return std::min((b->n + 255u) / 256u + (b->walk_wave_n + 3u) / 4u, (uint32_t)prop.multiProcessorCount * per_cu);
 }
+// A batch launched in the 2048-cell class on the bet that few of its pairs grow past it (opt_class) whose last run lost the bet: plan and allocate it
+// again as what its block range says -- the row-tiled class, per-pair kernel.
+static int batch_drop_class_bet(BaBatch* b) {
+    b->opt_class = false; b->bet_lost = false;
+    b->pclass = (uint32_t)BA_PCLASS_BIG; b->multi = false; b->multi_b = 128; b->geom = 0; b->wpw = ba::WAVES_PER_WG;
+    if (batch_plan(b, b->n, b->plan_fixed, b->plan_maxlen2, false, b->plan_avg)) return 1;
+    return batch_alloc_scratch(b);
+}
 static int batch_launch(BaBatch* b) {
     if (b->in_flight) return fail("the batch already has a launch in flight (ba_batch_wait first)");
     b->compacted = false;
     if (b->n == 0) return fail("the batch holds no pairs (its last reload failed)");
     HIP_TRY(hipSetDevice(b->device));
+    if (b->bet_lost && batch_drop_class_bet(b)) return 1;
     if (!b->handle_mode) {   // (a handle's work counter arrives zeroed with its upload; it has no hand-off structures)
         HIP_TRY(hipMemsetAsync(b->counter.p, 0, 128, b->stream));
         HIP_TRY(hipMemsetAsync(b->tb_ctrl.p, 0, 256, b->stream));
@@ -1251,7 +1274,7 @@ static int batch_retry(BaBatch* b, const std::vector<uint32_t>& idx, float* retr
     if (d2h(b->q_len, ql.data(), n) || d2h(b->r_len, rl.data(), n)) return 1;
     BaBatch sub;
     sub.device = b->device; sub.kind = b->kind; sub.mode = b->mode; sub.n = (uint32_t)k; sub.min_size = b->min_size; sub.max_size = b->max_size;
-    sub.pclass = b->pclass; sub.gap_open = b->gap_open; sub.gap_extend = b->gap_extend; sub.x_drop = b->x_drop;
+    sub.pclass = b->opt_class ? (uint32_t)BA_PCLASS_BIG : b->pclass; sub.gap_open = b->gap_open; sub.gap_extend = b->gap_extend; sub.x_drop = b->x_drop;
     std::vector<uint64_t> qo(k), ro(k), co(k + 1);
     std::vector<uint32_t> sql(k), srl(k);
     uint64_t maxlen2 = 0, cig_total = 0;
@@ -1336,10 +1359,16 @@ static int batch_wait(BaBatch* b, float* kernel_ms) {
         // every queued pair was taken by a per-pair wave: positions handed out (head) cover the entries appended (tail)
         if (ctl[16] < ctl[0]) return fail("small-block pipeline: %u queued pairs were never taken by the per-pair kernel", ctl[0] - ctl[16]);
     }
-    if (b->adaptive) {   // pairs whose trace stack outgrew the expected size: once more, with the reference's full bound
+    if (b->adaptive || b->opt_class) {   // pairs whose trace stack outgrew the expected size: once more, with the reference's full bound
+        // (... and, round 6, pairs whose block outgrew the launch's class: once more in the row-tiled class, opt_class)
         std::vector<uint32_t> st(b->n), again;
         if (d2h(b->status, st.data(), b->n)) return 1;
-        for (uint32_t p = 0; p < b->n; p++) if (st[p] & BA_ST_TRACE_OVERFLOW) again.push_back(p);
+        for (uint32_t p = 0; p < b->n; p++) if (st[p] & (BA_ST_TRACE_OVERFLOW | ba::ST_CLASS_OVERFLOW)) again.push_back(p);
+        if (b->opt_class) {
+            size_t grew = 0;
+            for (uint32_t p : again) if (st[p] & ba::ST_CLASS_OVERFLOW) grew++;
+            if (grew * 8 > b->n && !dev_env("BA_KEEP_CLASS_BET")) b->bet_lost = true;
+        }
         if (!again.empty()) {
             float retry_ms = 0;
             if (batch_retry(b, again, &retry_ms)) return 1;

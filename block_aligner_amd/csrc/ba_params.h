@@ -12,7 +12,8 @@ constexpr int DIR_RIGHT = 0, DIR_DOWN = 1, DIR_GROW = 2;
 enum : uint32_t {
     F_TRACE = 1u << 0, F_XDROP = 1u << 1, F_LOCAL = 1u << 2, F_FQS = 1u << 3, F_FQE = 1u << 4, F_CIGAR_EQ = 1u << 5
 };
-enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8, ST_WATCHDOG = 16, ST_SLOT_TIMEOUT = 32, ST_MODE = 64 };
+enum : uint32_t { ST_OK = 0, ST_TRACE_OVERFLOW = 1, ST_BLOCKS_OVERFLOW = 2, ST_CIGAR_OVERFLOW = 4, ST_TRACEBACK_LOST = 8, ST_WATCHDOG = 16, ST_SLOT_TIMEOUT = 32, ST_MODE = 64,
+                  ST_CLASS_OVERFLOW = 128 /* internal (round 6): the pair's block wants to grow past the launch's block class -- the host runs it again in the row-tiled class, batch_wait */ };
 
 struct BlockRec {   // one computed rectangle (scan_block.rs:1428-1443), 16 bytes
     uint32_t i, j;

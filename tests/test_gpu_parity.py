@@ -612,6 +612,56 @@ def test_big_blocks(hip, oracle, mode, size):
     assert res["cells"].max() > 60000 * size[0]
 
 
+def test_block_ranges_into_the_tiled_class_start_in_the_2048_cell_class(hip, oracle):
+    """Round 6 (ba_host.cpp batch_build, opt_class): a block range that starts at 1024 cells or below and ends above 2048 is launched in the 2048-cell
+    class; pairs whose block never passes 2048 cells end there, a pair that wants to grow further is run again in the row-tiled class by
+    ba_batch_wait -- the caller sees one run, and every pair equals the oracle's run with the full range."""
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    quiet = synth.make_pairs(24, (20000, 30000), (2000, 3000), 300, synth.DNA, seed=31, workers=4)
+    b = hip.BatchAligner(NUC, (-5, -1), (256, 4096), 100, mode, quiet.pool, quiet.q_off, quiet.q_len, quiet.r_off, quiet.r_len)
+    b.run()
+    assert b.retried() == 0
+    b.close()
+    compare(hip, oracle, quiet, NUC, (-5, -1), (256, 4096), 100, ("trace", "x_drop"))
+    growers = synth.make_pairs(6, (40000, 60000), (2000, 5000), 300, synth.DNA, seed=32, indels=4, indel_len=(2500, 6000), workers=4)
+    both = synth.PairSet.from_lists([(quiet.query(p), quiet.reference(p)) for p in range(6)] + [(growers.query(p), growers.reference(p)) for p in range(len(growers))])
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 4096), 400, mode, both.pool, both.q_off, both.q_len, both.r_off, both.r_len)
+    b.run()
+    assert 0 < b.retried() <= len(growers), b.retried()
+    b.close()
+    for m in (("trace", "x_drop"), ("x_drop",), ("trace",)):
+        compare(hip, oracle, both, NUC, (-5, -1), (128, 4096), 400, m)
+
+
+def test_a_batch_that_loses_the_class_bet_runs_in_the_tiled_class_from_then_on(hip, oracle):
+    """More than an eighth of the pairs grew past 2048 cells: the batch's next run is the row-tiled class's own (no first pass, nothing re-run),
+    with the same results."""
+    pairs = synth.make_pairs(6, (40000, 60000), (2000, 5000), 300, synth.DNA, seed=33, indels=4, indel_len=(2500, 6000), workers=4)
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 4096), 400, hip.TRACE | hip.X_DROP | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    lds0 = b.info()["lds_bytes_per_wave"]
+    b.run()
+    first, n_again = b.results(), b.retried()
+    runs1, off1 = b.cigars(first["cigar_len"])
+    assert n_again >= 1
+    b.run()
+    second = b.results()
+    runs2, off2 = b.cigars(second["cigar_len"])
+    assert b.retried() == 0 and b.info()["lds_bytes_per_wave"] < lds0, (b.retried(), b.info(), lds0)
+    for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"):
+        assert np.array_equal(first[k], second[k]), k
+    assert np.array_equal(runs1, runs2) and np.array_equal(off1, off2)
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 4096), 400, ("trace", "x_drop"))
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ()])
+def test_big_blocks_without_the_2048_cell_first_pass(hip, oracle, devlib, monkeypatch, mode):
+    """The row-tiled class on a range it no longer gets first (development switch BA_NO_OPT_CLASS): the same pairs as test_big_blocks."""
+    monkeypatch.setenv("BA_NO_OPT_CLASS", "1")
+    pairs = synth.make_pairs(5, (40000, 60000), (2000, 5000), 300, synth.DNA, seed=4096 + len(mode), indels=4, indel_len=(800, 6000), workers=4)
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 4096), 400, mode)
+
+
 def test_percent_len_sizes_are_accepted(hip, oracle):
     """Every size block_percent_len can return is a size the batch constructor takes (lib.rs:109-111: up to 16384)."""
     assert hip.percent_len(10 ** 7, 0.1) == 16384 and hip.percent_len(60000, 0.1) == 8192
