@@ -1596,8 +1596,12 @@ struct Aligner {
         // always written (first iteration is a grow, scan_block.rs:313-322) before they can be read.
         // (round 6: a launch of the 2048-cell class may carry pairs whose block range ends above it -- the host's bet that few of them grow that far,
         // ba_host.cpp batch_build; CLASS_CAP: what this kernel's border arrays hold)
-        constexpr uint32_t CLASS_CAP = kBig ? 32768u : (uint32_t)PMAX * 128u;
-        const uint32_t fill_n = max_size < CLASS_CAP ? max_size : CLASS_CAP;
+        // (only the 2048-cell class is compiled with it: every register of the smaller classes' drivers is spoken for -- the two lines in all classes moved
+        // k_multi<8>'s solo driver from 315 to 336 SGPR spills and config 3 from 158.2 to 161.1 ms)
+        constexpr bool CLASS_BET = !kBig && PMAX >= 16;
+        constexpr uint32_t CLASS_CAP = (uint32_t)PMAX * 128u;
+        uint32_t fill_n = max_size;
+        if constexpr (CLASS_BET) fill_n = max_size < CLASS_CAP ? max_size : CLASS_CAP;
         if (!MULTI || mmode != MM_RESUME) { lds_fill0(L.D_col, fill_n); lds_fill0(L.C_col, fill_n); lds_fill0(L.D_row, fill_n); lds_fill0(L.R_row, fill_n); }
         short* temp1 = L.misc + 16; short* temp2 = L.misc + 32;
         lds_fill0(temp1, 32);
@@ -1945,7 +1949,7 @@ struct Aligner {
 
             const uint32_t next_size = block_size * 2;
             if (next_size <= max_size && (y_drop_iter > block_size / STEP - 1 || grow_no_max)) {
-                if (!kBig && next_size > CLASS_CAP) { status |= ST_CLASS_OVERFLOW; break; }   // (the pair is run again in the row-tiled class: nothing of this run is kept)
+                if constexpr (CLASS_BET) { if (next_size > CLASS_CAP) { status |= ST_CLASS_OVERFLOW; break; } }   // (the pair is run again in the row-tiled class: nothing of this run is kept)
                 // (X-drop only: a global alignment's path starts at its end cell, so every chain of untraced grows would be rolled back at the
                 // end of the matrix at the latest -- the protein set's growers did all their large-block work twice)
                 if (TRACE && XDROP && KIND != KIND_PROFILE && !SPECIAL && !kBig && !chain && !no_spec && !(h_flags & 0x400u)) {
