@@ -311,6 +311,8 @@ int ba_shard_slices(const uint32_t* q_len, const uint32_t* r_len, uintptr_t n_pa
 enum { BA_ST_TRACE_OVERFLOW = 1, BA_ST_BLOCKS_OVERFLOW = 2, BA_ST_CIGAR_OVERFLOW = 4, BA_ST_TRACEBACK_LOST = 8, BA_ST_WATCHDOG = 16,
        BA_ST_SLOT_TIMEOUT = 32 /* never reported since round 4 (a fill wave that waits for a trace slot walks pending tracebacks itself); kept for ABI stability */,
        BA_ST_MODE = 64 /* FREE_QUERY_END_GAPS reached a down step: the reference panics there */ };
+/* (bit 128 is the library's own: a pair of a block range that ends above 2048 cells wanted to grow past the 2048-cell class its batch was launched in -- ba_batch_wait
+ * runs such pairs again in the row-tiled class before it returns, so the bit is never reported) */
 
 /* One-shot convenience over create/run/results/cigars/destroy. */
 int block_batch_align(int kind, const void* matrix, struct Gaps gaps, struct SizeRange size, int32_t x_drop, uint32_t mode,
