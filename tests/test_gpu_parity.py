@@ -654,6 +654,26 @@ def test_a_batch_that_loses_the_class_bet_runs_in_the_tiled_class_from_then_on(h
     compare(hip, oracle, pairs, NUC, (-5, -1), (128, 4096), 400, ("trace", "x_drop"))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_class_bet_random_configurations(hip, oracle, seed):
+    """Random block ranges that start at 128 .. 1024 cells and end at 4096 / 8192, random modes (the special ones too), DNA and protein, pairs with and
+    without indels long enough to push the block past 2048 cells: the first pass in the 2048-cell class + the re-run of the pairs that grow equal
+    the oracle's run with the full range, pair by pair."""
+    rng = np.random.default_rng(9000 + seed)
+    lo = 128 << int(rng.integers(0, 4)); hi = 4096 << int(rng.integers(0, 2))
+    protein = seed % 3 == 2
+    alpha, matrix, gaps = (synth.AMINO, S.BLOSUM62, (-11, -1)) if protein else (synth.DNA, NUC, (-int(rng.integers(4, 9)), -1))
+    mode = [("trace", "x_drop"), ("trace",), ("x_drop",), (), ("trace", "local_start"), ("trace", "x_drop", "free_query_start_gaps")][int(rng.integers(0, 4 if protein else 6))]
+    lists = []
+    for k in range(10):
+        n = int(rng.integers(6000, 20000))
+        pr = synth.make_pairs(1, n, (n // 20, n // 8), int(rng.integers(0, 600)), alpha, seed=int(rng.integers(1 << 30)),
+                              indels=int(rng.integers(0, 3)) if k % 2 else 0, indel_len=(1500, 5000))
+        lists.append((pr.query(0), pr.reference(0)))
+    pairs = synth.PairSet.from_lists(lists)
+    compare(hip, oracle, pairs, matrix, gaps, (lo, hi), int(rng.integers(50, 400)), mode, cigar_eq=not protein)
+
+
 @pytest.mark.parametrize("mode", [("trace", "x_drop"), ()])
 def test_big_blocks_without_the_2048_cell_first_pass(hip, oracle, devlib, monkeypatch, mode):
     """The row-tiled class on a range it no longer gets first (development switch BA_NO_OPT_CLASS): the same pairs as test_big_blocks."""
