@@ -89,6 +89,12 @@ extern "C" hipError_t ba_occupancy_mg2_k1_p8(int, int, unsigned, int*);
 // k_multi in four-wave workgroups at three / two waves per SIMD (DNA, block classes 512 and 1024): [waves per SIMD - 2][block class]
 static const LaunchFn g_launch_mg[2][5] = {{nullptr, nullptr, ba_launch_mg2_k1_p4, ba_launch_mg2_k1_p8, nullptr}, {nullptr, nullptr, ba_launch_mg3_k1_p4, ba_launch_mg3_k1_p8, nullptr}};
 static const OccFn g_occ_mg[2][5] = {{nullptr, nullptr, ba_occupancy_mg2_k1_p4, ba_occupancy_mg2_k1_p8, nullptr}, {nullptr, nullptr, ba_occupancy_mg3_k1_p4, ba_occupancy_mg3_k1_p8, nullptr}};
+extern "C" hipError_t ba_launch_m512_k1_p8(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_launch_m512_k1_p16(int, int, unsigned, unsigned, hipStream_t, const BatchParams*);
+extern "C" hipError_t ba_occupancy_m512_k1_p8(int, int, unsigned, int*);
+extern "C" hipError_t ba_occupancy_m512_k1_p16(int, int, unsigned, int*);
+static const LaunchFn g_launch_m512[5] = {nullptr, nullptr, nullptr, ba_launch_m512_k1_p8, ba_launch_m512_k1_p16};   // k_multi with one slot of 512 cells per wave: [block class]
+static const OccFn g_occ_m512[5] = {nullptr, nullptr, nullptr, ba_occupancy_m512_k1_p8, ba_occupancy_m512_k1_p16};
 static const LaunchFn g_launch_m256[5] = {nullptr, nullptr, ba_launch_m256_k1_p4, ba_launch_m256_k1_p8, ba_launch_m256_k1_p16};   // [block class]
 static const OccFn g_occ_m256[5] = {nullptr, nullptr, ba_occupancy_m256_k1_p4, ba_occupancy_m256_k1_p8, ba_occupancy_m256_k1_p16};
 // ... and its LOCAL_START / FREE_QUERY_START_GAPS instantiations (the batch's flags choose)
@@ -623,7 +629,7 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
         // handled per kernel in the launcher TU (hipFuncSetAttribute) -- see ba_kernels.hip
     }
     int per_cu = 0;
-    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (b->geom ? g_occ_mg[b->geom - 2][pc] : b->multi_b == 256 ? g_occ_m256[pc] : special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
+    const OccFn occ = pc == BA_PCLASS_BIG ? g_occ_big[special_of(mode)][kind] : (b->multi ? (b->geom ? g_occ_mg[b->geom - 2][pc] : b->multi_b == 512 ? g_occ_m512[pc] : b->multi_b == 256 ? g_occ_m256[pc] : special_of(mode) ? g_occ_ms[kind][pc] : g_occ_m[kind][pc]) : (b->small ? (special_of(mode) ? g_occ_sms[kind][pc] : g_occ_sm[kind][pc]) : g_occ[special_of(mode)][kind][pc]));
     if (occ(trace, (mode & BA_X_DROP) != 0, b->lds, &per_cu) != hipSuccess || per_cu <= 0) {
         fail("occupancy query failed for kind %d class %d (lds %u)", kind, pc, b->lds); return 1;
     }
@@ -650,7 +656,8 @@ static int batch_plan(BaBatch* b, size_t n, uint64_t fixed_bytes, uint64_t maxle
     b->adaptive = false;
     // (... and the batches of a sized batch's block ranges, which share the device memory: full-size slots of long pairs at large blocks -- 140 MB
     // each -- left a range's batch a few dozen resident waves)
-    if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || g_mem_cap != ~0ull || dev_env("BA_ADAPTIVE_TRACE"))) {
+    // (round 6: ... and batches of long pairs -- a full-size slot of a 32 kbp pair at 4096 cells is 140 MB, 2500 of them left room for 1816 resident waves)
+    if (trace && !full_trace && !dev_env("BA_FULL_TRACE_SLOTS") && (n >= 4096 || (maxlen2 >= 20000 && n >= 256) || g_mem_cap != ~0ull || dev_env("BA_ADAPTIVE_TRACE"))) {
         const uint64_t est = (maxlen2 * b->min_size / 8 + (uint64_t)max_size * max_size / 8 + 16ull * max_size) * zm;
         // margin over the expected stack, in percent (development / test switch: BA_TRACE_MARGIN_PCT). LOCAL_START, short pairs: see pipe_cut (long
         // pairs: the flanks are a small part of the stack, and a slot of 3 x 2 x the plain size halves the number of resident waves)
@@ -962,6 +969,14 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
         }
     }
     if (const char* env = dev_env("BA_MQ_GEOM")) { const int v = atoi(env); b->geom = (geom_ok && (v == 2 || v == 3)) ? (uint32_t)v : 0u; }   // (development / tests: 0 = the eight-wave workgroups)
+    // ... and batches that start at 512 cells (percent_len 1 % of reads above 25.6 kbp): one slot of 512 cells per wave -- the same pair per wave as the per-pair
+    // kernel, but its plain steps in the slots' loop (the state in registers, the driver's decisions in vector code) instead of the per-pair driver's shell.
+    if (min_size == 512 && kind == BA_KIND_NUC && !special_of(mode) && max_size >= 1024 && pc >= 3 && pc <= 4) {
+        wide = true; b->multi_b = 512;
+        // (32 kbp pairs at 512..4096, one slot per wave / per-pair kernel, same box, ms with traceback (tools/dev/m512_ab.sh): 300 pairs 54.3 / 84.6, 1200 54.6 / 85.0,
+        // 2500 84.2 / 136.9, 5000 117.1 / 212.0; score only 600 pairs 26.2 / 48.8, 2500 64.9 / 81.6 -- a pair's own chain of steps is a third shorter)
+        multi_fits = avg_len2 >= 8000 && n >= 256;
+    }
     b->multi = !profile && small_mode && pc != BA_PCLASS_BIG && (min_size == ba::MQ_B_HOST || wide) && !dev_env("BA_NO_MULTI") && (dev_env("BA_FORCE_MULTI") || multi_fits);
     if (!b->multi) { b->multi_b = 128; b->geom = 0; }
     if (b->geom) b->wpw = (uint32_t)ba::MQ_GEOM_WPW;
@@ -1169,7 +1184,7 @@ static int batch_launch(BaBatch* b) {
     const BatchParams bp = b->params();
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     if (b->ev_l0) HIP_TRY(hipEventRecord(b->ev_l0, b->stream));   // (a re-run sub-batch: batch_retry re-uses ev0 for the merge)
-    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (b->geom ? g_launch_mg[b->geom - 2][b->pclass] : b->multi_b == 256 ? g_launch_m256[b->pclass] : special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
+    const LaunchFn launch = b->pclass == BA_PCLASS_BIG ? g_launch_big[special_of(b->mode)][b->kind] : (b->multi ? (b->geom ? g_launch_mg[b->geom - 2][b->pclass] : b->multi_b == 512 ? g_launch_m512[b->pclass] : b->multi_b == 256 ? g_launch_m256[b->pclass] : special_of(b->mode) ? g_launch_ms[b->kind][b->pclass] : g_launch_m[b->kind][b->pclass]) : g_launch[special_of(b->mode)][b->kind][b->pclass]);
     if (b->quad && b->n <= b->cap_n) {
         // k_quad starts every pair -- its first block and plain shift steps, four pairs per wave -- and finishes the global
         // alignments that never need more. A pair that does (a grow, X-drop termination, fewer than 32 residues) goes through a

@@ -114,6 +114,34 @@ extern "C" hipError_t BA_CAT(ba_occupancy_m256_k, BA_KIND, _p, BA_PMAX)(int trac
     return xdrop ? occ_multi256<false, true>(blocks_per_cu, lds) : occ_multi256<false, false>(blocks_per_cu, lds);
 }
 #endif
+#if BA_KIND == 1 && BA_PMAX >= 8
+// ... with one slot of 512 cells per wave (round 6: DNA batches that start at 512 cells -- percent_len 1 % of reads above 25.6 kbp --, block classes 1024 and 2048)
+template <bool TRACE, bool XDROP>
+static hipError_t launch_multi512(unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams& bp) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 512><<<dim3(grid), dim3(ba::WAVES_PER_WG * 64), lds, s>>>(bp);
+    return hipGetLastError();
+}
+template <bool TRACE, bool XDROP>
+static hipError_t occ_multi512(int* blocks_per_cu, unsigned lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ba::k_multi<BA_PMAX, BA_KIND, TRACE, XDROP, 0, 512>, ba::WAVES_PER_WG * 64, lds);
+}
+extern "C" hipError_t BA_CAT(ba_launch_m512_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned grid, unsigned lds, hipStream_t s, const ba::BatchParams* bp) {
+    if (trace) return xdrop ? launch_multi512<true, true>(grid, lds, s, *bp) : launch_multi512<true, false>(grid, lds, s, *bp);
+    return xdrop ? launch_multi512<false, true>(grid, lds, s, *bp) : launch_multi512<false, false>(grid, lds, s, *bp);
+}
+extern "C" hipError_t BA_CAT(ba_occupancy_m512_k, BA_KIND, _p, BA_PMAX)(int trace, int xdrop, unsigned lds, int* blocks_per_cu) {
+    if (trace) return xdrop ? occ_multi512<true, true>(blocks_per_cu, lds) : occ_multi512<true, false>(blocks_per_cu, lds);
+    return xdrop ? occ_multi512<false, true>(blocks_per_cu, lds) : occ_multi512<false, false>(blocks_per_cu, lds);
+}
+#endif
 #if BA_KIND == 1 && (BA_PMAX == 4 || BA_PMAX == 8)
 // ... in workgroups of four waves at three / two waves per SIMD (round 6: DNA batches whose pairs fill that many waves' slots about once -- ba_host.cpp batch_build)
 template <bool TRACE, bool XDROP, int EU>

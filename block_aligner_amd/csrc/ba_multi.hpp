@@ -48,16 +48,20 @@ __device__ __forceinline__ int sel_mask(unsigned long long m, int a, int b) {
 // ---- slots of SL = 16 lanes (128 cells, four pairs per wave) or SL = 32 lanes (256 cells, two pairs per wave: round 6). The 16-lane forms are DPP
 // row operations; a 32-lane slot spans two DPP rows, so its shifts are whole-wave shifts with the slot's own edge lane patched, and its broadcasts
 // go through the LDS crossbar (ds_bpermute: three per step). l = the lane inside its slot.
+// (SL = 64, round 6: one slot of 512 cells -- the whole wave: the edges are the wave's, the broadcasts scalar reads of lane 0 / 63)
 template <int SL> __device__ __forceinline__ int slot_first(int v) {   // the slot's first lane's value, to all its lanes
     if constexpr (SL == 16) return row_bcast<0>(v);
+    else if constexpr (SL == 64) return __builtin_amdgcn_readfirstlane(v);
     else return __builtin_amdgcn_ds_bpermute((lane_id() & 32) << 2, v);
 }
 template <int SL> __device__ __forceinline__ int slot_last(int v) {    // the slot's last lane's value, to all its lanes
     if constexpr (SL == 16) return row_bcast<15>(v);
+    else if constexpr (SL == 64) return __builtin_amdgcn_readlane(v, 63);
     else return __builtin_amdgcn_ds_bpermute(((lane_id() & 32) + 31) << 2, v);
 }
 template <int SL> __device__ __forceinline__ int slot_shr1_z(int v, int l) {   // lane l <- l - 1 inside the slot; its first lane <- 0
     if constexpr (SL == 16) return row_shr1_z(v);
+    else if constexpr (SL == 64) return wave_shr1_z(v);
     else { const int t = wave_shr1_z(v); return l == 0 ? 0 : t; }
 }
 template <int SL> __device__ __forceinline__ int slot_shl1_keep(int last, int src, int l) {   // lane l <- src[l + 1] inside the slot; its last lane keeps `last`
@@ -93,7 +97,7 @@ __device__ __forceinline__ int multi_carry(int r3, const MultiConsts& mc, int l 
         const int pm = wave_prefix_max16((int)as_s(r3).y - mc.laneKG);
         return vmax(scan8_splat_lo(add_row_shr1(pm, mc.lanem1KG)), mc.w0);
     } else {   // 32 lanes: the scan restarts at lane 32 (wave_prefix_max32); the shift by one lane crosses the slots' edge, whose lane takes the filler instead
-        const int pm = wave_prefix_max32((int)as_s(r3).y - mc.laneKG);
+        const int pm = SL == 64 ? wave_prefix_max((int)as_s(r3).y - mc.laneKG) : wave_prefix_max32((int)as_s(r3).y - mc.laneKG);
         const int cin = add_shr1(pm, mc.lanem1KG);
         return vmax(scan8_splat_lo(l == 0 ? -32768 : cin), mc.w0);
     }
@@ -227,7 +231,7 @@ __device__ __forceinline__ void multi_rect(const char* table, const FillConsts& 
     }
     const int mm = vmax(vmax(dmax[0], dmax[1]), vmax(dmax[2], dmax[3]));
     const int m32 = max(mm & 0xffff, (int)((uint32_t)mm >> 16));   // halves are >= 0 (D_max starts at MIN = 0)
-    o.mx = slot_last<SL>(SL == 16 ? wave_prefix_max16(m32) : wave_prefix_max32(m32));
+    o.mx = slot_last<SL>(SL == 16 ? wave_prefix_max16(m32) : (SL == 64 ? wave_prefix_max(m32) : wave_prefix_max32(m32)));
     if constexpr (TRACE && SPM == 1) { zout[0] = (int)~zacc[0]; zout[1] = (int)~zacc[1]; }
 }
 
@@ -263,7 +267,7 @@ __global__ void __launch_bounds__(WPW * 64, (PMAX >= 16 ? 2 : EU)) k_multi(const
     constexpr int SL = MBP / 8, NSLOT = 64 / SL;
     constexpr uint32_t ALLM = (1u << NSLOT) - 1u;                                                     // every slot live
     constexpr uint32_t ARR = 2u * MB, BUFL = 4u * ARR, BUFA = BUFL + 64u, SLOTA = 2u * BUFA + 128u;   // bytes: a border array of a slot, a state buffer in LDS / in the arena, a slot in the arena
-    static_assert((MBP == 128 || MBP == 256) && NSLOT * SLOTA <= MQ_WAVE_BYTES && NSLOT * 2u * BUFL <= MQ_LDS_SCALARS && (MBP == 128 || SPM == 0), "k_multi slot geometry");
+    static_assert((MBP == 128 || MBP == 256 || MBP == 512) && NSLOT * SLOTA <= MQ_WAVE_BYTES && NSLOT * 2u * BUFL <= MQ_LDS_SCALARS && (MBP == 128 || SPM == 0), "k_multi slot geometry");
     static_assert(MBP != 128 || (BUFA == MQ_BUF_BYTES && SLOTA == MQ_SLOT_BYTES), "ba_params.h");
     constexpr uint32_t MQ_TW = (STEP * MB / 8) * (SPM == 1 ? 2u : 1u);
     constexpr int TB_LB = SPM ? (int)TB_LANE_BYTES_LOC : (int)TB_LANE_BYTES_L2;

@@ -221,3 +221,50 @@ def test_multi_geometry_release_library_by_batch_size(hip, oracle, n, geom, mode
     waves = 1024 * geom if "trace" in mode else min(1024 * geom, 4 * ((n + 15) // 16))
     assert info["kernel"] == "k_multi" and info["geometry"] == geom and info["grid"] == waves, info
     compare(hip, oracle, pairs, NUC, (-5, -1), (128, 512), 100, mode, threads=16)
+
+
+# ---- round 6: one slot of 512 cells per wave (DNA batches that start at 512 cells: percent_len 1 % of reads above 25.6 kbp, lib.rs:109-111)
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("size", [(512, 1024), (512, 2048), (512, 4096)])
+def test_multi512_dna(hip, oracle, force_multi, mode, size):
+    """Indels of 50 .. 900 bases force grows, checkpoint restores and shrinks: pairs move between their 512-cell slot and solo mode many times
+    (512..4096: launched in the 2048-cell class, pairs that grow past it re-run in the row-tiled one)."""
+    pairs = synth.make_pairs(100, (3000, 12000), (200, 1200), 300, synth.DNA, seed=2900 + size[1], indels=3, indel_len=(50, 900))
+    b = hip.BatchAligner(NUC, (-5, -1), size, 100, sum({"trace": hip.TRACE, "x_drop": hip.X_DROP}[k] for k in mode), pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi"
+    b.close()
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), size, 100, mode)
+    assert res["cells"].max() > 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_multi512_ragged_and_short(hip, oracle, force_multi, mode):
+    """Pairs shorter than a block, empty sequences and one-sided pairs beside ordinary ones."""
+    rng = np.random.default_rng(13)
+    lists = [(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A", b"A"), (b"A" * 511, b"A" * 513), (b"ACGT" * 140, b"ACGT" * 1000)]
+    for _ in range(50):
+        n = int(rng.integers(0, 5000))
+        a = synth.rand_str(rng, n, synth.DNA)
+        b = synth.mutate(rng, a, int(rng.integers(0, 1 + n // 8)), synth.DNA) if n else a
+        lists.append((a.tobytes(), b.tobytes()))
+    pairs = synth.PairSet.from_lists(lists)
+    compare(hip, oracle, pairs, NUC, (-5, -1), (512, 2048), 60, mode)
+
+
+@pytest.mark.parametrize("mode", [("trace", "x_drop"), ("trace",), ("x_drop",)])
+def test_multi512_long_reads_with_traceback_waves(hip, oracle, force_multi, monkeypatch, mode):
+    """32 kbp-shaped pairs with the in-launch hand-off to traceback waves, recycled trace slots and the slot changing waves at the end of the batch."""
+    monkeypatch.setenv("BA_FORCE_TB", "1")
+    monkeypatch.setenv("BA_WGS_PER_CU", "1")
+    pairs = synth.make_pairs(500, (12000, 30000), (1000, 3000), 500, synth.DNA, seed=4323, workers=8)
+    res = compare(hip, oracle, pairs, NUC, (-5, -1), (512, 4096), 100, mode, threads=16)
+    assert (res["query_idx"] > 8000).all()
+
+
+def test_multi512_release_library_takes_it_from_the_threshold(hip, oracle):
+    """The release library itself picks the 512-cell slot for a few hundred long reads (no development switch), here through the class bet of 512..4096."""
+    pairs = synth.make_pairs(300, (5000, 9000), (400, 900), 200, synth.DNA, seed=78, indels=1, indel_len=(50, 3000), workers=8)
+    b = hip.BatchAligner(NUC, (-5, -1), (512, 4096), 100, hip.TRACE | hip.X_DROP | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["kernel"] == "k_multi", b.info()
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), (512, 4096), 100, ("trace", "x_drop"), threads=16)

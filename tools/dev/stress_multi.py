@@ -47,6 +47,11 @@ for seed in range(seed0, seed0 + count):
         alpha, matrix, kind = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))), 0
         mode = tuple(m for m in mode if m in ("trace", "x_drop"))
         pairs = synth.make_pairs(5000, (2 * lo_len + 3000, 2 * hi_len + 4000), (2 * edits[0], 3 * edits[1]), tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(5, 300), workers=8)
+    if os.environ.get("STRESS_M512"):   # round 6: k_multi's 512-cell slot (DNA, the plain modes, 512..1024 / 2048 / 4096 -- the last one through the class bet), long pairs
+        lo, hi = 512, 1024 << int(rng.integers(0, 3))
+        alpha, matrix, kind = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))), 0
+        mode = tuple(m for m in mode if m in ("trace", "x_drop"))
+        pairs = synth.make_pairs(int(rng.integers(300, 1500)), (4 * lo_len + 5000, 4 * hi_len + 8000), (4 * edits[0], 6 * edits[1]), tails, alpha, seed=seed, indels=int(rng.integers(0, 3)), indel_len=(20, 1500), workers=8)
     if os.environ.get("STRESS_GEOM"):   # round 6: k_multi in four-wave workgroups at two / three waves per SIMD (DNA, the plain modes, 128..512 / 1024), ~8 k pairs
         hi = 512 << int(rng.integers(0, 2))
         alpha, matrix, kind = synth.DNA, S.NucMatrix.new_simple(int(rng.integers(1, 4)), -int(rng.integers(1, 5))), 0
