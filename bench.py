@@ -546,6 +546,11 @@ def main():
                     wl = W.config3(30000, 13000, 1300, a.tail, seed=4321, trace=True, workers=min(8, usable_cpus()), size=(H.percent_len(13000, 0.01), H.percent_len(13000, 0.1)))
                     wl.name += ", block %d..%d (percent_len 1 %% .. 10 %% of 13 kbp)" % wl.size
                     secondary.append(secondary_line(np, H, W, o, wl, cores))
+                    # ... and reads above 25.6 kbp at 512 cells: 32 kbp pairs at 1 % .. 10 % = 512 .. 4096 -- a range that ends in the row-tiled class and is
+                    # launched in the 2048-cell one (round 6: the class bet), k_multi with one slot of 512 cells per wave
+                    wl = W.config3(5000, 32000, 3200, a.tail, seed=4322, trace=True, workers=min(8, usable_cpus()), size=(H.percent_len(32000, 0.01), H.percent_len(32000, 0.1)))
+                    wl.name += ", block %d..%d (percent_len 1 %% .. 10 %% of 32 kbp)" % wl.size
+                    secondary.append(secondary_line(np, H, W, o, wl, cores))
                 # ... and the same configurations at the batch sizes of the reference's own harnesses (BASELINE.json: 10 k pairs,
                 # examples/nanopore_bench.rs:73-95; 7 k protein pairs, examples/uc_bench.rs:79-104; 11 k PSSMs, examples/pssm_bench.rs:94-100):
                 # a few pairs per wave, bound by the longest pair's chain of steps rather than by the machine
