@@ -322,9 +322,11 @@ def test_batch_reload(hip, oracle):
     b.close()
 
 
-def test_trace_slots_larger_than_memory_share(hip, oracle):
-    """330 pairs of 2 x 400 kbp at max block 2048: one trace slot is 0.8 GB, so the full launch (4096 waves) would need
-    3 TB; the launch shrinks to the waves whose slots fit in device memory instead of failing to allocate."""
+def test_trace_slots_larger_than_memory_share(hip, oracle, devlib, monkeypatch):
+    """330 pairs of 2 x 400 kbp at max block 2048: one full-size trace slot is 0.8 GB, so the full launch (4096 waves) would need
+    3 TB; the launch shrinks to the waves whose slots fit in device memory instead of failing to allocate. (Full-size slots by the development
+    switch: since round 6 batches of long pairs get slots sized by the expected stack from 256 pairs on -- the next test.)"""
+    monkeypatch.setenv("BA_FULL_TRACE_SLOTS", "1")
     pairs = synth.make_pairs(330, 400000, 12000, 100, synth.DNA, seed=777, workers=8)
     mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
     b = hip.BatchAligner(NUC, (-5, -1), (128, 2048), 200, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
@@ -337,6 +339,16 @@ def test_trace_slots_larger_than_memory_share(hip, oracle):
     assert np.array_equal(res["score"], ref["scores"]) and np.array_equal(res["query_idx"], ref["query_idx"]) and np.array_equal(res["cigar_len"], ref["cig_len"])
     assert int(res["cells"].sum()) == ref["cells"]
     b.close()
+
+
+def test_long_pairs_get_trace_slots_by_the_expected_stack(hip, oracle):
+    """Round 6: 300 pairs of 2 x 60 kbp at 128..2048 -- full-size slots would be 37 GB, slots sized by the expected stack (with the re-run of pairs that
+    outgrow theirs) a fraction of it; results as the oracle's."""
+    pairs = synth.make_pairs(300, 60000, 3000, 100, synth.DNA, seed=778, indels=2, indel_len=(100, 2500), workers=8)
+    b = hip.BatchAligner(NUC, (-5, -1), (128, 2048), 200, hip.TRACE | hip.X_DROP | hip.CIGAR_EQ, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len)
+    assert b.info()["trace_arena_bytes"] < 12e9, b.info()
+    b.close()
+    compare(hip, oracle, pairs, NUC, (-5, -1), (128, 2048), 200, ("trace", "x_drop"), threads=16)
 
 
 @pytest.mark.parametrize("mode", [("trace", "local_start"), ("local_start", "x_drop"), ("trace", "free_query_start_gaps"),
