@@ -268,3 +268,24 @@ def test_multi512_release_library_takes_it_from_the_threshold(hip, oracle):
     assert b.info()["kernel"] == "k_multi", b.info()
     b.close()
     compare(hip, oracle, pairs, NUC, (-5, -1), (512, 4096), 100, ("trace", "x_drop"), threads=16)
+
+
+def test_multi512_batch_that_loses_the_class_bet(hip, oracle):
+    """A 512..4096 batch in the 512-cell slots (launched in the 2048-cell class) of which more than an eighth grows past 2048 cells: those pairs are re-run in
+    the row-tiled class, and the batch's next run is the row-tiled class's own -- per-pair kernel, nothing re-run, identical results."""
+    quiet = synth.make_pairs(216, (5000, 7000), (300, 600), 100, synth.DNA, seed=81, workers=8)
+    growers = synth.make_pairs(44, (11000, 13000), (300, 600), 100, synth.DNA, seed=82, indels=1, indel_len=(3000, 5000), workers=8)
+    both = synth.PairSet.from_lists([(quiet.query(p), quiet.reference(p)) for p in range(len(quiet))] + [(growers.query(p), growers.reference(p)) for p in range(len(growers))])
+    b = hip.BatchAligner(NUC, (-5, -1), (512, 4096), 0, hip.TRACE | hip.CIGAR_EQ, both.pool, both.q_off, both.q_len, both.r_off, both.r_len)
+    assert b.info()["kernel"] == "k_multi", b.info()
+    b.run()
+    first, n_again = b.results(), b.retried()
+    assert n_again * 8 > len(both), n_again
+    b.run()
+    second = b.results()
+    # (what it still re-runs are growers whose trace stack outgrew a slot sized by the expected stack: fewer than grew past the class)
+    assert b.retried() < n_again and b.info()["kernel"] == "k_align" and b.info()["lds_bytes_per_wave"] < 4096, (b.retried(), n_again, b.info())
+    for k in ("score", "query_idx", "reference_idx", "cells", "cigar_len", "status"):
+        assert np.array_equal(first[k], second[k]), k
+    b.close()
+    compare(hip, oracle, both, NUC, (-5, -1), (512, 4096), 0, ("trace",), threads=16)
