@@ -259,7 +259,10 @@ int ba_batch_geometry(BaBatch* batch);
  * int16 operations per cell (bench.py: roofline.ops_required). */
 int ba_batch_spec_cells(BaBatch* batch, uint64_t* cells);
 /* Large TRACE batches size their trace slots for the expected stack, not for the reference's worst case (Trace::new,
- * scan_block.rs:1363-1366); pairs that outgrow a slot are re-run with full-size slots inside ba_batch_run / ba_batch_wait.
+ * scan_block.rs:1363-1366); pairs that outgrow a slot are re-run with full-size slots inside ba_batch_run / ba_batch_wait. (Large: from 4096 pairs, or
+ * from 256 pairs of 10 kbp and more.) Likewise a batch whose block range starts at 128 .. 1024 cells and ends above 2048 is launched in the 2048-cell class;
+ * pairs whose block wants to grow past 2048 cells are re-run in the row-tiled class, and a batch of which more than an eighth did is launched in the
+ * row-tiled class from its next run on.
  * Number of pairs the last run re-ran (results are identical either way; -1 for a null batch). */
 int ba_batch_retried(BaBatch* batch);
 void ba_batch_destroy(BaBatch* batch);
