@@ -939,7 +939,9 @@ static BaBatch* batch_build(int kind, const void* matrix, Gaps gaps, SizeRange s
     bool wide = false;
     if (min_size == 256 && kind == BA_KIND_NUC && !special_of(mode) && max_size >= 512 && pc >= 2 && pc <= 4) {
         wide = true; b->multi_b = 256;
-        multi_fits = avg_len2 >= 6000 && n >= 2048;   // (13 kbp reads, 256..2048, with traceback, GCUPS two-pair slots / per-pair kernel, same box: 1.5 k pairs 353 / 410, 2.5 k 576 / 401, 4 k 990 / 552, 8 k 1155 / 603, 20 k 1555 / 654, 70 k 1873 / 720)
+        // (round 6, later: a wave whose second slot stays empty goes on stepping with the first -- from 256 pairs: 600 pairs of 22 kbp at 256..4096 34.9 ms against the
+        // per-pair kernel's 45.4, 1500 of 13 kbp at 256..2048 21.5 / 27.2. The figures of the earlier rule, from 2048 pairs:)
+        multi_fits = avg_len2 >= 6000 && n >= 256;   // (13 kbp reads, 256..2048, with traceback, GCUPS two-pair slots / per-pair kernel, same box: 1.5 k pairs 353 / 410, 2.5 k 576 / 401, 4 k 990 / 552, 8 k 1155 / 603, 20 k 1555 / 654, 70 k 1873 / 720)
     }
     // Round 6: the launch geometry of k_multi by the batch size. The kernel is bound by vector issue, so a round of the batch -- every slot of every resident
     // wave filled once -- takes as long as a SIMD has waves; a batch of about one round is fastest on the geometry whose slots it just fills (four-wave
@@ -2038,14 +2040,26 @@ int ba_sized_batch_run(BaSizedBatch* m, float* kernel_ms) {
     const auto t0 = std::chrono::steady_clock::now();
     int rc = 0;
     std::string first_err;
-    size_t launched = 0;
-    for (size_t k : order) { if (ba_batch_launch(m->part[k].get())) { rc = 1; first_err = g_err; break; } launched++; }
-    for (size_t i = 0; i < launched; i++) {   // (also after a failed launch: nothing is left in flight behind the caller's back)
-        const size_t k = order[i];
-        float ms = 0;
-        if (ba_batch_wait(m->part[k].get(), &ms) && !rc) { rc = 1; first_err = g_err; }
-        m->last_ms[k] = ms;
+    // Round 6: a launch whose waves wait for each other -- the hand-off ring of a traced batch (its traceback waves and helpers wait for the fill waves'
+    // hand-offs), k_multi's end-of-batch slot donation (its idle waves wait until every fill wave has been counted) -- needs all of its workgroups resident
+    // to be sure to end. Alone it is (the grid is what the device holds); beside launches that simply run out it still is, later; but two or more such
+    // launches that each hold a part of the device wait for workgroups the other's waiting waves keep out (three ranges of k_multi in one per-pair-ranges
+    // batch: 9 .. 25 s instead of 0.2, every wait ended by a time-out). So: the ranges without such waits all at once, the ones with them one after the
+    // other beside those.
+    auto waits_inside = [&](const BaBatch* b) { return b->tb_stride != 0 || (b->multi && (b->mode & BA_TRACE) && b->donate.p != nullptr); };
+    std::vector<size_t> free_run, chained;
+    for (size_t k : order) (waits_inside(m->part[k].get()) ? chained : free_run).push_back(k);
+    std::vector<char> launched(m->part.size(), 0);
+    auto wait_one = [&](size_t k) { float ms = 0; if (ba_batch_wait(m->part[k].get(), &ms) && !rc) { rc = 1; first_err = g_err; } m->last_ms[k] = ms; launched[k] = 0; };
+    auto launch_one = [&](size_t k) { if (rc) return; if (ba_batch_launch(m->part[k].get())) { rc = 1; first_err = g_err; } else launched[k] = 1; };
+    if (!chained.empty()) launch_one(chained[0]);   // (the longest chain first: the other ranges fill the device around it)
+    for (size_t k : free_run) launch_one(k);
+    for (size_t i = 0; i < chained.size(); i++) {
+        if (launched[chained[i]]) wait_one(chained[i]);
+        if (i + 1 < chained.size()) launch_one(chained[i + 1]);
     }
+    for (size_t k : free_run) if (launched[k]) wait_one(k);   // (also after a failed launch: nothing is left in flight behind the caller's back)
+    for (size_t k = 0; k < launched.size(); k++) if (launched[k]) wait_one(k);
     if (rc) return fail("%s", first_err.c_str());
     if (kernel_ms) *kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;

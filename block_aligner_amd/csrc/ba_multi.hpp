@@ -250,6 +250,14 @@ enum { MR_PAIR = 0, MR_BEST_I, MR_BEST_J, MR_CELLS_LO, MR_CELLS_HI, MR_BUDGET, M
        MR_BEST_MAX, MR_Y_DROP, MR_X_ITER, MR_D_CORNER, MR_NSTEPS, MR_TRACE_TOP, MR_NBLOCKS, MR_SEL, MR_WORDS };
 __device__ __forceinline__ int mq_load(const char* p) { return __hip_atomic_load((const int*)p, BA_RLX_AGENT); }   // past the L1: the wave reads back its own stores
 
+#ifndef MQ_PARTIAL_MB
+// Slots of this many cells and more go on stepping when the wave cannot refill its empty ones, instead of finishing the live pairs one at a time in solo mode
+// (round 6). A 256-cell slot's plain steps in the per-pair driver are its generic rectangles and its shell -- the loop of steps with one of two slots live is
+// faster (22 kbp pairs at 256..4096, same box: 600 pairs 54.6 -> 34.9 ms, per-pair kernel 45.4; 2500 pairs 55.7 -> 37.2, per-pair 77.4; 13 kbp at 256..2048: 30 k
+// pairs 133.3 -> 125.7); a 128-cell slot's are the register path, which beats a quarter-full loop of steps (config 3, 100 k pairs 157.7 -> 161.9 ms, 12.5 k 30.1 ->
+// 31.9: tools/dev/partial_ab.sh, partial_ab2.sh).
+#define MQ_PARTIAL_MB 256
+#endif
 #ifndef MQ_WAVES_EU
 #define MQ_WAVES_EU 4   // (waves per SIMD the kernel is compiled for. Tried, round 5: 2 = 256 registers, no spills -- config 3 163.6 -> 205.1 ms, 25 k pairs 55.6 -> 64.1: two waves do not fill the vector unit)
 #endif
@@ -322,7 +330,7 @@ __global__ void __launch_bounds__(WPW * 64, (PMAX >= 16 ? 2 : EU)) k_multi(const
                                 const uint32_t cb = (TRACE && st > 0) ? (b + st - 1) / st + (b % st == 0 ? 1u : 0u) : 0u; return b * WPW + w - cb; };
     uint32_t live_m = 0, pend_m = 0;   // wave-uniform: bit s = slot s holds a pair / its pair has to go through solo mode
     uint32_t w_next = 0, w_end = 0;
-    bool more = true, drain = false;
+    bool more = true, drain = false, fin_counted = false;
     // The end of the batch (round 4): a wave whose slots are filled for the last time (the pool is closed for them) takes its live slots solo,
     // one after the other -- and offers the ones it is not working on to waves that have nothing left (mq_donate[its id], bit s; a slot's
     // state in the arena is a complete resumable record). `don` (bits 8 / 9 of the wave's own word): bit 0 this wave has been counted in mq_donate[waves] (it will offer nothing
@@ -397,7 +405,7 @@ __global__ void __launch_bounds__(WPW * 64, (PMAX >= 16 ? 2 : EU)) k_multi(const
                 new_pair = w_next++; solo = __builtin_ctz(~live_m & ALLM); fresh = true;
                 to_end = drain;                                      // (the batch is running out: this pair is not for a slot)
                 if (new_pair + bp.mq_drain >= bp.n) drain = true;    // from the next pair on
-            } else if (live_m && live_m != ALLM) {
+            } else if (live_m && live_m != ALLM && MB < (uint32_t)(MQ_PARTIAL_MB)) {
                 // (tried in round 5: a wave with three live slots goes on stepping instead -- three slots take steps about as efficiently as a pair in
                 // solo mode --: no difference, 167.6 against 167.0 ms)
                 solo = __builtin_ctz(live_m); to_end = true;
@@ -451,7 +459,19 @@ __global__ void __launch_bounds__(WPW * 64, (PMAX >= 16 ? 2 : EU)) k_multi(const
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 to_end = true;
             }
-            else break;
+            else {
+                // (a wave of wide slots that goes on stepping with an empty slot the batch cannot fill any more: it will offer nothing -- counted as the waves
+                // that finish their pairs solo are, or the idle waves would not turn into the helpers whose walks this wave's trace slots wait for. Without
+                // it a per-pair-ranges batch took 25 s: every wait ended by its time-out.)
+                if constexpr (TRACE && MB >= (uint32_t)(MQ_PARTIAL_MB)) {
+                    if (bp.mq_donate && live_m && live_m != ALLM && !more && !fin_counted) {
+                        fin_counted = true;
+                        const uint32_t my_id = my_id_of();
+                        if (is_lane(0) && !(__hip_atomic_fetch_or(bp.mq_donate + my_id, 0x100u, BA_RLX_AGENT) & 0x100u)) __hip_atomic_fetch_add(don_final, 1u, BA_RLX_AGENT);
+                    }
+                }
+                break;
+            }
 
             BA_TSTAMP(ts_a);
             const FillConsts fc = make_fill_consts(lane, bp.gap_open, gx);   // two cells per lane (as k_align)

@@ -224,7 +224,11 @@ int ba_batch_reload_profile(BaBatch* batch, const struct AAProfile* const* profi
 /* Launch on the batch's stream and wait. kernel_ms (optional) = HIP-event time of the alignment kernel alone. */
 int ba_batch_run(BaBatch* batch, float* kernel_ms);
 /* The two halves of ba_batch_run: enqueue on the batch's own stream and return / wait for it. Launches of different
- * batches overlap on the device; results, cigars and reload are valid after the wait. */
+ * batches overlap on the device; results, cigars and reload are valid after the wait.
+ * At most TWO launches in flight per device if they are BA_TRACE batches of more than a few pairs per resident wave: such a launch's waves wait for each other
+ * (the traceback waves for the fill waves' hand-offs, k_multi's idle waves for its last fill wave), so it must become fully resident to end. The first launch
+ * on an idle device is; a second one follows it; three or more may each hold a part of the device and keep each other's remaining workgroups out
+ * (ba_sized_batch_run orders its ranges' launches accordingly). Score-only batches have no such waits. */
 int ba_batch_launch(BaBatch* batch);
 int ba_batch_wait(BaBatch* batch, float* kernel_ms);
 /* Upper bound on a ba_batch_wait / ba_batch_run (milliseconds; default 600000; 0 = none): the kernels of a launch wait for each other without a

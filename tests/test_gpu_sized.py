@@ -76,3 +76,37 @@ def test_explicit_ranges_and_caller_order(hip, oracle):
         assert (int(res["score"][p]), int(res["cells"][p])) == (ref["score"], ref["cells"]), (p, sizes[p])
         assert cigar_runs_to_string(runs[int(off[p]): int(off[p + 1])]) == ref["cigar"], p
     b.close()
+
+
+def test_ranges_whose_launches_wait_inside_run_one_after_the_other(hip, oracle):
+    """Three ranges that take k_multi with traceback (slot donation: a launch's idle waves wait until all of its fill waves have been counted), together larger
+    than the device: launched all at once they each held a part of the device and waited for workgroups the others' waiting waves kept out (round 6: seconds
+    instead of milliseconds, every wait ended by a time-out); ba_sized_batch_run launches such ranges one after the other beside the rest."""
+    ranges = [(256, 2048), (256, 4096), (512, 4096), (32, 256)]
+    sets = [synth.make_pairs(1100 if k < 3 else 3000, (4000, 5200) if k < 3 else (300, 900), (300, 500) if k < 3 else (20, 80), 100, synth.DNA, seed=500 + k, workers=8) for k in range(4)]
+    lists, sizes = [], []
+    for k, ps in enumerate(sets):
+        for p in range(len(ps)):
+            lists.append((ps.query(p), ps.reference(p))); sizes.append(ranges[k])
+    order = np.random.default_rng(3).permutation(len(lists))
+    lists = [lists[i] for i in order]; sizes = [sizes[i] for i in order]
+    pairs = synth.PairSet.from_lists(lists)
+    mode = hip.TRACE | hip.X_DROP | hip.CIGAR_EQ
+    b = hip.SizedBatchAligner(NUC, (-5, -1), 100, mode, pairs.pool, pairs.q_off, pairs.q_len, pairs.r_off, pairs.r_len, sizes=np.array(sizes))
+    cls = b.classes()
+    assert sum(1 for c in cls if c[3] == 1) >= 3, cls          # three ranges in k_multi
+    b.run()
+    ms = b.run()
+    assert ms < 1500, ms
+    res = b.results()
+    assert not res["status"].any()
+    runs, off = b.cigars(res["cigar_len"])
+    for rg in ranges:
+        idx = np.array([p for p in range(len(pairs)) if tuple(sizes[p]) == rg])
+        sub = synth.PairSet.from_lists([lists[p] for p in idx])
+        ref = oracle.batch_align(NUC, sub.pool, sub.q_off, sub.q_len, sub.r_off, sub.r_len, (-5, -1), rg, 100, ("trace", "x_drop"), cigar_eq=True, threads=16)
+        assert np.array_equal(res["score"][idx], ref["scores"]) and np.array_equal(res["cells"][idx].sum(), ref["cells"]) and np.array_equal(res["cigar_len"][idx], ref["cig_len"]), rg
+        for t, p in enumerate(idx[:200]):
+            want = ref["cig_ops"][int(ref["cig_off"][t]): int(ref["cig_off"][t]) + int(ref["cig_len"][t])]
+            assert np.array_equal(runs[int(off[p]): int(off[p + 1])], want), (rg, p)
+    b.close()
